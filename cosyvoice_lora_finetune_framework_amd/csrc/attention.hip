@@ -1,0 +1,628 @@
+// attention.hip -- fused (flash-style) attention forward / backward, head_dim 64.
+//   REL=false : softmax(QK^T*scale + (-1e10 on keys >= klen)) V      (U-Net estimator blocks)
+//   REL=true  : softmax(((q+u)K^T + shift((q+v)P^T))*scale, -inf mask: pad / causal) V
+// No (B,H,L,L) tensor is ever materialised: scores live in MFMA accumulators, the rel-pos
+// term is produced per tile from an LDS-staged band of P rows and skew-read (rel_shift
+// index law  bd[i,j] = (q_i+v).p[L-1-i+j]).  Backward = dQ kernel + dK/dV kernel, both
+// recomputing P from the saved row log-sum-exp (no atomics, deterministic).
+//
+// Replaces (reference): modules.py:253-293 / diffusers Attention; attention.py:200-330, 82-127.
+#include "attn_common.cuh"
+
+template <typename T>
+struct AP {
+    int B, H, L;
+    const T *q, *k, *v; int ld;
+    const T* p; int ldp;
+    const float *bu, *bv;
+    const int* len;
+    int causal; float scale;
+    T* o; int ldo; float* lse;
+    const T* d_o; const float* delta;
+    T *dq, *dk, *dv; int ldg;
+};
+
+#define NEG_INF (-__builtin_inff())
+
+// ------------------------------------------------------------------------ forward
+template <typename T, bool REL>
+__global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
+    typedef AttnCfg<T> A;
+    typedef Mma<T> MM;
+    typedef typename MM::Frag Frag;
+    constexpr int LDK = A::LDK, NK = A::NK, LDG = 84;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* Ks = reinterpret_cast<T*>(smem);
+    T* Vs = Ks + A::TILE;
+    T* Ps = Vs + A::TILE;                 // 4 x 16 x LDK
+    T* Pb = Ps + 4 * 16 * LDK;            // REL: 128 x LDK
+    float* Gs = reinterpret_cast<float*>(Pb + 128 * LDK);   // REL: 4 x 16 x LDG
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int L = p.L;
+    const size_t rowbase = (size_t)b * L;
+    const T* qg = p.q + rowbase * p.ld + h * 64;
+    const T* kg = p.k + rowbase * p.ld + h * 64;
+    const T* vg = p.v + rowbase * p.ld + h * 64;
+    const T* pg = REL ? p.p + h * 64 : nullptr;
+    const int lb = p.len ? p.len[b] : L;
+
+    stage64(qg, p.ld, q0, L, Ks, tid);
+    __syncthreads();
+    Frag qf[NK], qv[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        qf[ks] = FragLd<T, T>::kc(Ks, LDK, 16 * w, ks * MM::K, lane);
+        qv[ks] = qf[ks];
+        if (REL) {
+            qv[ks] = frag_add_bias(qf[ks], p.bv + h * 64, ks * MM::K, lane);
+            qf[ks] = frag_add_bias(qf[ks], p.bu + h * 64, ks * MM::K, lane);
+        }
+    }
+    __syncthreads();
+
+    int jmax;
+    if (REL) {
+        jmax = min(L, lb);
+        if (p.causal) jmax = min(jmax, q0 + 64);
+    } else {
+        jmax = (lb >= 1) ? min(L, lb) : L;
+    }
+    float m_run[4], l_run[4];
+    f32x4 oacc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_run[r] = NEG_INF; l_run[r] = 0.f; oacc[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    T* Pw = Ps + w * 16 * LDK;
+    float* Gw = Gs + w * 16 * LDG;
+
+    for (int j0 = 0; j0 < jmax; j0 += 64) {
+        stage64(kg, p.ld, j0, L, Ks, tid);
+        stage64(vg, p.ld, j0, L, Vs, tid);
+        if (REL) {
+            const int mb = (L - 1) - (q0 + 63) + j0;
+            stage64(pg, p.ldp, mb, 2 * L - 1, Pb, tid);
+            stage64(pg, p.ldp, mb + 64, 2 * L - 1, Pb + 64 * LDK, tid);
+        }
+        __syncthreads();
+        f32x4 s[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mma_regA_kc<T, 4>(s, qf, Ks, LDK, 0, lane);
+        if (REL) {
+            f32x4 g[5];
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) g[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma_regA_kc<T, 5>(g, qv, Pb, LDK, 48 - 16 * w, lane);
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Gw[((lane >> 4) * 4 + r) * LDG + nt * 16 + (lane & 15)] = g[nt][r];
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row = (lane >> 4) * 4 + r;
+                    s[nt][r] += Gw[row * LDG + 15 - row + nt * 16 + (lane & 15)];
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = q0 + 16 * w + (lane >> 4) * 4 + r;
+            float tm = NEG_INF;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int j = j0 + nt * 16 + (lane & 15);
+                float x = s[nt][r] * p.scale;
+                if (REL) {
+                    bool valid = (j < lb) && (j < L) && (!p.causal || j <= i);
+                    x = valid ? x : NEG_INF;
+                } else {
+                    x = (j < L) ? x + (j < lb ? 0.f : -1.0e10f) : NEG_INF;
+                }
+                s[nt][r] = x;
+                tm = fmaxf(tm, x);
+            }
+            tm = row16_max(tm);
+            const float mn = fmaxf(m_run[r], tm);
+            const float ms = (mn == NEG_INF) ? 0.f : mn;
+            const float alpha = expf(m_run[r] - ms);
+            float rs = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float pv = expf(s[nt][r] - ms);
+                s[nt][r] = pv;
+                rs += pv;
+            }
+            rs = row16_sum(rs);
+            l_run[r] = l_run[r] * alpha + rs;
+            m_run[r] = mn;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt][r] *= alpha;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pw[((lane >> 4) * 4 + r) * LDK + nt * 16 + (lane & 15)] = from_f32<T>(s[nt][r]);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            Frag a = FragLd<T, T>::kc(Pw, LDK, 0, ks * MM::K, lane);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) MM::mma(oacc[dt], a, FragLd<T, T>::km(Vs, LDK, dt * 16, ks * MM::K, lane));
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = q0 + 16 * w + (lane >> 4) * 4 + r;
+        if (i >= L) continue;
+        const float inv = l_run[r] > 0.f ? 1.f / l_run[r] : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            p.o[(rowbase + i) * p.ldo + h * 64 + dt * 16 + (lane & 15)] = from_f32<T>(oacc[dt][r] * inv);
+        if ((lane & 15) == 0)
+            p.lse[((size_t)b * p.H + h) * L + i] = l_run[r] > 0.f ? m_run[r] + logf(l_run[r]) : __builtin_inff();
+    }
+}
+
+// ------------------------------------------------------------------------ backward: dQ
+template <typename T, bool REL>
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
+    typedef AttnCfg<T> A;
+    typedef Mma<T> MM;
+    typedef typename MM::Frag Frag;
+    constexpr int LDK = A::LDK, NK = A::NK, LDG = 100;
+    constexpr int KB = (sizeof(T) == 2) ? 96 : 80;     // skewed dS width, padded to the MFMA k-step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* Ks = reinterpret_cast<T*>(smem);
+    T* Vs = Ks + A::TILE;
+    T* Ds = Vs + A::TILE;                 // 4 x 16 x LDK
+    T* Pb = Ds + 4 * 16 * LDK;            // REL: 192 x LDK
+    float* Gs = reinterpret_cast<float*>(Pb + 192 * LDK);   // REL: 4 x 16 x LDG
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int L = p.L;
+    const size_t rowbase = (size_t)b * L;
+    const T* qg = p.q + rowbase * p.ld + h * 64;
+    const T* kg = p.k + rowbase * p.ld + h * 64;
+    const T* vg = p.v + rowbase * p.ld + h * 64;
+    const T* dog = p.d_o + rowbase * p.ldo + h * 64;
+    const T* pg = REL ? p.p + h * 64 : nullptr;
+    const int lb = p.len ? p.len[b] : L;
+
+    stage64(qg, p.ld, q0, L, Ks, tid);
+    stage64(dog, p.ldo, q0, L, Vs, tid);
+    __syncthreads();
+    Frag qf[NK], qv[NK], dof[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        qf[ks] = FragLd<T, T>::kc(Ks, LDK, 16 * w, ks * MM::K, lane);
+        dof[ks] = FragLd<T, T>::kc(Vs, LDK, 16 * w, ks * MM::K, lane);
+        qv[ks] = qf[ks];
+        if (REL) {
+            qv[ks] = frag_add_bias(qf[ks], p.bv + h * 64, ks * MM::K, lane);
+            qf[ks] = frag_add_bias(qf[ks], p.bu + h * 64, ks * MM::K, lane);
+        }
+    }
+    float lse_r[4], del_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = q0 + 16 * w + (lane >> 4) * 4 + r;
+        lse_r[r] = (i < L) ? p.lse[((size_t)b * p.H + h) * L + i] : __builtin_inff();
+        del_r[r] = (i < L) ? p.delta[((size_t)b * p.H + h) * L + i] : 0.f;
+    }
+    __syncthreads();
+
+    int jmax;
+    if (REL) {
+        jmax = min(L, lb);
+        if (p.causal) jmax = min(jmax, q0 + 64);
+    } else {
+        jmax = (lb >= 1) ? min(L, lb) : L;
+    }
+    f32x4 dqacc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dqacc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    T* Dw = Ds + w * 16 * LDK;
+    float* Gw = Gs + w * 16 * LDG;
+
+    for (int j0 = 0; j0 < jmax; j0 += 64) {
+        stage64(kg, p.ld, j0, L, Ks, tid);
+        stage64(vg, p.ld, j0, L, Vs, tid);
+        if (REL) {
+            const int mb = (L - 1) - (q0 + 63) + j0;
+            stage64(pg, p.ldp, mb, 2 * L - 1, Pb, tid);
+            stage64(pg, p.ldp, mb + 64, 2 * L - 1, Pb + 64 * LDK, tid);
+            stage64(pg, p.ldp, mb + 128, 2 * L - 1, Pb + 128 * LDK, tid);
+        }
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { s[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_regA_kc<T, 4>(s, qf, Ks, LDK, 0, lane);
+        mma_regA_kc<T, 4>(dp, dof, Vs, LDK, 0, lane);
+        if (REL) {
+            f32x4 g[5];
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) g[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma_regA_kc<T, 5>(g, qv, Pb, LDK, 48 - 16 * w, lane);
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Gw[((lane >> 4) * 4 + r) * LDG + nt * 16 + (lane & 15)] = g[nt][r];
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row = (lane >> 4) * 4 + r;
+                    s[nt][r] += Gw[row * LDG + 15 - row + nt * 16 + (lane & 15)];
+                }
+            __syncthreads();
+            for (int e = lane; e < 16 * KB; e += 64) Gw[(e / KB) * LDG + (e % KB)] = 0.f;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = q0 + 16 * w + (lane >> 4) * 4 + r;
+            const int row = (lane >> 4) * 4 + r;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int j = j0 + nt * 16 + (lane & 15);
+                float x = s[nt][r] * p.scale;
+                bool valid;
+                if (REL) {
+                    valid = (j < lb) && (j < L) && (!p.causal || j <= i);
+                } else {
+                    valid = (j < L);
+                    x += (j < lb ? 0.f : -1.0e10f);
+                }
+                const float pv = valid ? expf(x - lse_r[r]) : 0.f;
+                const float ds = pv * (dp[nt][r] - del_r[r]) * p.scale;
+                Dw[row * LDK + nt * 16 + (lane & 15)] = from_f32<T>(ds);
+                if (REL) Gw[row * LDG + 15 - row + nt * 16 + (lane & 15)] = ds;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            Frag a = FragLd<T, T>::kc(Dw, LDK, 0, ks * MM::K, lane);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) MM::mma(dqacc[dt], a, FragLd<T, T>::km(Ks, LDK, dt * 16, ks * MM::K, lane));
+        }
+        if (REL) {
+#pragma unroll
+            for (int k0 = 0; k0 < KB; k0 += MM::K) {
+                Frag a = FragLd<T, float>::kc(Gw, LDG, 0, k0, lane);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    MM::mma(dqacc[dt], a, FragLd<T, T>::km(Pb, LDK, dt * 16, (48 - 16 * w) + k0, lane));
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = q0 + 16 * w + (lane >> 4) * 4 + r;
+        if (i >= L) continue;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            p.dq[(rowbase + i) * p.ldg + h * 64 + dt * 16 + (lane & 15)] = from_f32<T>(dqacc[dt][r]);
+    }
+}
+
+// ------------------------------------------------------------------------ backward: dK, dV
+template <typename T, bool REL>
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) {
+    typedef AttnCfg<T> A;
+    typedef Mma<T> MM;
+    typedef typename MM::Frag Frag;
+    constexpr int LDK = A::LDK, NK = A::NK, LDG = 36;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* Ks = reinterpret_cast<T*>(smem);
+    T* Vs = Ks + A::TILE;
+    T* Qs = Vs + A::TILE;
+    T* Os = Qs + A::TILE;
+    T* Pt = Os + A::TILE;                 // 4 x 16 x LDK  : P^T  [j][i]
+    T* Dt = Pt + 4 * 16 * LDK;            // 4 x 16 x LDK  : dS^T [j][i]
+    float* lse_s = reinterpret_cast<float*>(Dt + 4 * 16 * LDK);   // 64
+    float* del_s = lse_s + 64;                                     // 64
+    T* Pb = reinterpret_cast<T*>(del_s + 64);                      // REL: 128 x LDK
+    float* Gs = reinterpret_cast<float*>(Pb + 128 * LDK);          // REL: 4 x 16 x LDG
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int L = p.L;
+    const size_t rowbase = (size_t)b * L;
+    const T* qg = p.q + rowbase * p.ld + h * 64;
+    const T* kg = p.k + rowbase * p.ld + h * 64;
+    const T* vg = p.v + rowbase * p.ld + h * 64;
+    const T* dog = p.d_o + rowbase * p.ldo + h * 64;
+    const T* pg = REL ? p.p + h * 64 : nullptr;
+    const int lb = p.len ? p.len[b] : L;
+    const int lb_eff = REL ? min(L, lb) : ((lb >= 1) ? min(L, lb) : L);
+    const int jw = j0 + 16 * w;
+
+    f32x4 dkacc[4], dvacc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dkacc[r] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float csum = 0.f;
+
+    if (j0 < lb_eff) {   // block-uniform
+        stage64(kg, p.ld, j0, L, Ks, tid);
+        stage64(vg, p.ld, j0, L, Vs, tid);
+        __syncthreads();
+        Frag kf[NK], vf[NK];
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            kf[ks] = FragLd<T, T>::kc(Ks, LDK, 16 * w, ks * MM::K, lane);
+            vf[ks] = FragLd<T, T>::kc(Vs, LDK, 16 * w, ks * MM::K, lane);
+        }
+        T* Pw = Pt + w * 16 * LDK;
+        T* Dw = Dt + w * 16 * LDK;
+        float* Gw = Gs + w * 16 * LDG;
+        const int ibeg = (REL && p.causal) ? j0 : 0;
+        for (int i0 = ibeg; i0 < L; i0 += 64) {
+            stage64(qg, p.ld, i0, L, Qs, tid);
+            stage64(dog, p.ldo, i0, L, Os, tid);
+            if (tid < 64) {
+                int i = i0 + tid;
+                lse_s[tid] = (i < L) ? p.lse[((size_t)b * p.H + h) * L + i] : __builtin_inff();
+                del_s[tid] = (i < L) ? p.delta[((size_t)b * p.H + h) * L + i] : 0.f;
+            }
+            if (REL) {
+                const int mb = (L - 1) - (i0 + 63) + j0;
+                stage64(pg, p.ldp, mb, 2 * L - 1, Pb, tid);
+                stage64(pg, p.ldp, mb + 64, 2 * L - 1, Pb + 64 * LDK, tid);
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int mt = 0; mt < 4; ++mt) {
+                Frag au[NK], av[NK], ad[NK];
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) {
+                    au[ks] = FragLd<T, T>::kc(Qs, LDK, mt * 16, ks * MM::K, lane);
+                    ad[ks] = FragLd<T, T>::kc(Os, LDK, mt * 16, ks * MM::K, lane);
+                    av[ks] = au[ks];
+                    if (REL) {
+                        av[ks] = frag_add_bias(au[ks], p.bv + h * 64, ks * MM::K, lane);
+                        au[ks] = frag_add_bias(au[ks], p.bu + h * 64, ks * MM::K, lane);
+                    }
+                }
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) {
+                    MM::mma(s, au[ks], kf[ks]);
+                    MM::mma(dp, ad[ks], vf[ks]);
+                }
+                if (REL) {
+                    f32x4 g[2];
+                    g[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    g[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma_regA_kc<T, 2>(g, av, Pb, LDK, (48 - 16 * mt) + 16 * w, lane);
+                    __syncthreads();   // previous mt's skew reads done
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Gw[((lane >> 4) * 4 + r) * LDG + nt * 16 + (lane & 15)] = g[nt][r];
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = (lane >> 4) * 4 + r;
+                        s[r] += Gw[row * LDG + 15 - row + (lane & 15)];
+                    }
+                }
+                const int j = jw + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int il = mt * 16 + (lane >> 4) * 4 + r;
+                    const int i = i0 + il;
+                    float x = s[r] * p.scale;
+                    bool valid;
+                    if (REL) {
+                        valid = (j < lb) && (j < L) && (i < L) && (!p.causal || j <= i);
+                    } else {
+                        valid = (j < L) && (i < L);
+                        x += (j < lb ? 0.f : -1.0e10f);
+                    }
+                    const float pv = valid ? expf(x - lse_s[il]) : 0.f;
+                    const float ds = pv * (dp[r] - del_s[il]) * p.scale;
+                    Pw[(lane & 15) * LDK + il] = from_f32<T>(pv);
+                    Dw[(lane & 15) * LDK + il] = from_f32<T>(ds);
+                    csum += ds;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                Frag ap = FragLd<T, T>::kc(Pw, LDK, 0, ks * MM::K, lane);
+                Frag ads = FragLd<T, T>::kc(Dw, LDK, 0, ks * MM::K, lane);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    MM::mma(dvacc[dt], ap, FragLd<T, T>::km(Os, LDK, dt * 16, ks * MM::K, lane));
+                    MM::mma(dkacc[dt], ads, FragLd<T, T>::km(Qs, LDK, dt * 16, ks * MM::K, lane));
+                }
+            }
+            __syncthreads();
+        }
+        if (REL) {   // dK_j += (sum_i dS[i,j]) * u   (A operand was raw q)
+            float ct = csum + __shfl_xor(csum, 16, 64);
+            ct += __shfl_xor(ct, 32, 64);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float cj = __shfl(ct, (lane >> 4) * 4 + r, 64);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dkacc[dt][r] += cj * p.bu[h * 64 + dt * 16 + (lane & 15)];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = jw + (lane >> 4) * 4 + r;
+        if (j >= L) continue;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const size_t off = (rowbase + j) * p.ldg + h * 64 + dt * 16 + (lane & 15);
+            p.dk[off] = from_f32<T>(dkacc[dt][r]);
+            p.dv[off] = from_f32<T>(dvacc[dt][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------ host side
+template <typename T> static size_t smem_fwd(bool rel) {
+    typedef AttnCfg<T> A;
+    size_t s = (size_t)(2 * A::TILE + 4 * 16 * A::LDK) * sizeof(T);
+    if (rel) s += (size_t)128 * A::LDK * sizeof(T) + 4 * 16 * 84 * sizeof(float);
+    return s;
+}
+template <typename T> static size_t smem_dq(bool rel) {
+    typedef AttnCfg<T> A;
+    size_t s = (size_t)(2 * A::TILE + 4 * 16 * A::LDK) * sizeof(T);
+    if (rel) s += (size_t)192 * A::LDK * sizeof(T) + 4 * 16 * 100 * sizeof(float);
+    return s;
+}
+template <typename T> static size_t smem_dkv(bool rel) {
+    typedef AttnCfg<T> A;
+    size_t s = (size_t)(4 * A::TILE + 2 * 4 * 16 * A::LDK) * sizeof(T) + 128 * sizeof(float);
+    if (rel) s += (size_t)128 * A::LDK * sizeof(T) + 4 * 16 * 36 * sizeof(float);
+    return s;
+}
+
+template <typename K>
+static int set_smem(K kernel, size_t bytes, const char* name) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        cvft_set_error("%s: hipFuncSetAttribute(%zu bytes) failed: %s", name, bytes, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+template <typename T, bool REL>
+static int launch_fwd(const AP<T>& p, hipStream_t st) {
+    size_t sm = smem_fwd<T>(REL);
+    if (set_smem(attn_fwd_kernel<T, REL>, sm, "attn_fwd")) return -2;
+    dim3 grid((p.L + 63) / 64, p.H, p.B);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, REL>), grid, dim3(256), sm, st, p);
+    CVFT_LAUNCH_CHECK("attn_fwd");
+    return 0;
+}
+template <typename T, bool REL>
+static int launch_bwd(const AP<T>& p, float* delta, const T* o, hipStream_t st) {
+    size_t total = (size_t)p.B * p.L * p.H;
+    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.B, p.H, p.L, o,
+                       p.d_o, p.ldo, delta);
+    CVFT_LAUNCH_CHECK("attn_delta");
+    size_t s1 = smem_dq<T>(REL), s2 = smem_dkv<T>(REL);
+    if (set_smem(attn_bwd_dq_kernel<T, REL>, s1, "attn_bwd_dq")) return -2;
+    if (set_smem(attn_bwd_dkv_kernel<T, REL>, s2, "attn_bwd_dkv")) return -2;
+    dim3 grid((p.L + 63) / 64, p.H, p.B);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, REL>), grid, dim3(256), s1, st, p);
+    CVFT_LAUNCH_CHECK("attn_bwd_dq");
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, REL>), grid, dim3(256), s2, st, p);
+    CVFT_LAUNCH_CHECK("attn_bwd_dkv");
+    return 0;
+}
+
+static int check_common(const char* name, int dtype, int B, int H, int L, int ld, int ldo, const void* q, const void* k,
+                        const void* v) {
+    CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "%s: bad dtype", name);
+    CVFT_CHECK_ARG(B > 0 && H > 0 && L > 0 && B <= 65535 && H <= 65535, "%s: bad dims B%d H%d L%d", name, B, H, L);
+    int vec = dtype == CVFT_BF16 ? 8 : 4;
+    CVFT_CHECK_ARG(ld >= H * 64 && ldo >= H * 64 && ld % vec == 0 && ldo % vec == 0, "%s: bad leading dims", name);
+    CVFT_CHECK_ARG(q && k && v, "%s: null operand", name);
+    CVFT_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, "%s: q/k/v must be 16-byte aligned", name);
+    return 0;
+}
+
+template <typename T>
+static AP<T> make_ap(int B, int H, int L, const void* q, const void* k, const void* v, int ld, const void* pp, int ldp,
+                     const float* bu, const float* bv, const int32_t* len, int causal, float scale) {
+    AP<T> a;
+    a.B = B; a.H = H; a.L = L; a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.ld = ld;
+    a.p = (const T*)pp; a.ldp = ldp; a.bu = bu; a.bv = bv; a.len = len; a.causal = causal; a.scale = scale;
+    a.o = nullptr; a.ldo = 0; a.lse = nullptr; a.d_o = nullptr; a.delta = nullptr; a.dq = a.dk = a.dv = nullptr; a.ldg = 0;
+    return a;
+}
+
+extern "C" int cvft_attn_bias_fwd(int dtype, int B, int H, int T_, const void* q, const void* k, const void* v, int ld,
+                                  const int32_t* klen, float scale, void* o, int ldo, float* lse, void* stream) {
+    if (check_common("cvft_attn_bias_fwd", dtype, B, H, T_, ld, ldo, q, k, v)) return -1;
+    CVFT_CHECK_ARG(o && lse, "cvft_attn_bias_fwd: null output");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CVFT_F32) {
+        AP<float> a = make_ap<float>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
+        a.o = (float*)o; a.ldo = ldo; a.lse = lse;
+        return launch_fwd<float, false>(a, st);
+    }
+    AP<bf16_t> a = make_ap<bf16_t>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
+    a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse;
+    return launch_fwd<bf16_t, false>(a, st);
+}
+
+extern "C" int cvft_attn_bias_bwd(int dtype, int B, int H, int T_, const void* q, const void* k, const void* v, int ld,
+                                  const int32_t* klen, float scale, const void* o, const void* d_o, int ldo,
+                                  const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg, void* stream) {
+    if (check_common("cvft_attn_bias_bwd", dtype, B, H, T_, ld, ldo, q, k, v)) return -1;
+    CVFT_CHECK_ARG(o && d_o && lse && delta && dq && dk && dv && ldg >= H * 64, "cvft_attn_bias_bwd: bad args");
+    CVFT_CHECK_ARG((((uintptr_t)d_o) & 15) == 0, "cvft_attn_bias_bwd: dO must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CVFT_F32) {
+        AP<float> a = make_ap<float>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
+        a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const float*)d_o; a.delta = delta;
+        a.dq = (float*)dq; a.dk = (float*)dk; a.dv = (float*)dv; a.ldg = ldg;
+        return launch_bwd<float, false>(a, delta, (const float*)o, st);
+    }
+    AP<bf16_t> a = make_ap<bf16_t>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
+    a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const bf16_t*)d_o; a.delta = delta;
+    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg;
+    return launch_bwd<bf16_t, false>(a, delta, (const bf16_t*)o, st);
+}
+
+extern "C" int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
+                                    const void* pp, int ldp, const float* bias_u, const float* bias_v,
+                                    const int32_t* len, int causal, float scale, void* o, int ldo, float* lse,
+                                    void* stream) {
+    if (check_common("cvft_attn_relpos_fwd", dtype, B, H, L, ld, ldo, q, k, v)) return -1;
+    int vec = dtype == CVFT_BF16 ? 8 : 4;
+    CVFT_CHECK_ARG(pp && bias_u && bias_v && o && lse && ldp >= H * 64 && ldp % vec == 0 && (((uintptr_t)pp) & 15) == 0,
+                   "cvft_attn_relpos_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CVFT_F32) {
+        AP<float> a = make_ap<float>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
+        a.o = (float*)o; a.ldo = ldo; a.lse = lse;
+        return launch_fwd<float, true>(a, st);
+    }
+    AP<bf16_t> a = make_ap<bf16_t>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
+    a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse;
+    return launch_fwd<bf16_t, true>(a, st);
+}
+
+extern "C" int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
+                                    const void* pp, int ldp, const float* bias_u, const float* bias_v,
+                                    const int32_t* len, int causal, float scale, const void* o, const void* d_o, int ldo,
+                                    const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg, float* dp,
+                                    void* stream) {
+    if (check_common("cvft_attn_relpos_bwd", dtype, B, H, L, ld, ldo, q, k, v)) return -1;
+    int vec = dtype == CVFT_BF16 ? 8 : 4;
+    CVFT_CHECK_ARG(pp && bias_u && bias_v && ldp >= H * 64 && ldp % vec == 0 && (((uintptr_t)pp) & 15) == 0,
+                   "cvft_attn_relpos_bwd: bad p");
+    CVFT_CHECK_ARG(o && d_o && lse && delta && dq && dk && dv && ldg >= H * 64, "cvft_attn_relpos_bwd: bad args");
+    CVFT_CHECK_ARG((((uintptr_t)d_o) & 15) == 0, "cvft_attn_relpos_bwd: dO must be 16-byte aligned");
+    CVFT_CHECK_ARG(dp == nullptr, "cvft_attn_relpos_bwd: gradient w.r.t. p (LoRA on linear_pos) is not implemented");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CVFT_F32) {
+        AP<float> a = make_ap<float>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
+        a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const float*)d_o; a.delta = delta;
+        a.dq = (float*)dq; a.dk = (float*)dk; a.dv = (float*)dv; a.ldg = ldg;
+        return launch_bwd<float, true>(a, delta, (const float*)o, st);
+    }
+    AP<bf16_t> a = make_ap<bf16_t>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
+    a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const bf16_t*)d_o; a.delta = delta;
+    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg;
+    return launch_bwd<bf16_t, true>(a, delta, (const bf16_t*)o, st);
+}

@@ -1,0 +1,112 @@
+// attn_common.cuh -- shared pieces of the fused attention kernels (head_dim 64).
+// LDS tiles are [64 rows][64 cols] with row stride LDK.  Every MFMA operand is read
+// through one of two loaders:
+//   ld_kc : operand stored with its reduction index contiguous  ([rc][k])  -> 16-byte read
+//   ld_km : operand stored reduction-index-major               ([k][rc])  -> strided gather
+// (MFMA lane maps: cdna_hip_programming.md section 3.)
+#pragma once
+#include "common.cuh"
+
+template <typename T> struct AttnCfg {
+    static constexpr int VEC = 16 / sizeof(T);
+    static constexpr int LDK = 64 + VEC;         // padded row stride (elements)
+    static constexpr int CPR = 64 / VEC;         // 16-byte chunks per 64-wide row
+    static constexpr int NK = 64 / Mma<T>::K;    // MFMA k-steps across 64
+    static constexpr int TILE = 64 * LDK;        // elements per staged tile
+};
+
+// global rows r0..r0+63 (64 columns each, leading dim ld) -> LDS S[r][c]; rows outside [0,rlim) are zero
+template <typename T>
+__device__ __forceinline__ void stage64(const T* __restrict__ g, int ld, int r0, int rlim, T* S, int tid) {
+    typedef AttnCfg<T> A;
+    for (int c = tid; c < 64 * A::CPR; c += 256) {
+        int r = c / A::CPR, cc = c % A::CPR;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < rlim && r0 + r >= 0) v = *reinterpret_cast<const uint4*>(g + (size_t)(r0 + r) * ld + cc * A::VEC);
+        *reinterpret_cast<uint4*>(&S[r * A::LDK + cc * A::VEC]) = v;
+    }
+}
+
+// ---- operand loaders -------------------------------------------------------------
+template <typename T, typename S> struct FragLd;
+template <> struct FragLd<bf16_t, bf16_t> {
+    static __device__ __forceinline__ bf16x8 kc(const bf16_t* base, int ld, int rc0, int k0, int lane) {
+        return *reinterpret_cast<const bf16x8*>(base + (rc0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4));
+    }
+    static __device__ __forceinline__ bf16x8 km(const bf16_t* base, int ld, int rc0, int k0, int lane) {
+        bf16x8 f;
+        const bf16_t* p = base + (k0 + 8 * (lane >> 4)) * ld + rc0 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = p[j * ld];
+        return f;
+    }
+};
+template <> struct FragLd<bf16_t, float> {
+    static __device__ __forceinline__ bf16x8 kc(const float* base, int ld, int rc0, int k0, int lane) {
+        bf16x8 f;
+        const float* p = base + (rc0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (bf16_t)p[j];
+        return f;
+    }
+};
+template <> struct FragLd<float, float> {
+    static __device__ __forceinline__ float kc(const float* base, int ld, int rc0, int k0, int lane) {
+        return base[(rc0 + (lane & 15)) * ld + k0 + (lane >> 4)];
+    }
+    static __device__ __forceinline__ float km(const float* base, int ld, int rc0, int k0, int lane) {
+        return base[(k0 + (lane >> 4)) * ld + rc0 + (lane & 15)];
+    }
+};
+
+// add a per-column fp32 bias (indexed by the k position the fragment element holds)
+__device__ __forceinline__ bf16x8 frag_add_bias(bf16x8 f, const float* bias, int k0, int lane) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)((float)f[j] + bias[k0 + 8 * (lane >> 4) + j]);
+    return r;
+}
+__device__ __forceinline__ float frag_add_bias(float f, const float* bias, int k0, int lane) {
+    return f + bias[k0 + (lane >> 4)];
+}
+
+// acc[nt] += Areg(16 x 64) . Btile(rows rc0 + nt*16 .., k-contiguous)^T
+template <typename T, int NT>
+__device__ __forceinline__ void mma_regA_kc(f32x4 (&acc)[NT], const typename Mma<T>::Frag (&a)[AttnCfg<T>::NK],
+                                            const T* Bt, int ldb, int rc0, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < AttnCfg<T>::NK; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            Mma<T>::mma(acc[nt], a[ks], FragLd<T, T>::kc(Bt, ldb, rc0 + nt * 16, ks * Mma<T>::K, lane));
+}
+
+// reductions across the 16 lanes that share (lane>>4): one score-tile row lives on them
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// delta[b,h,i] = sum_d dO[i,d] * O[i,d]
+template <typename T>
+__global__ void __launch_bounds__(256) attn_delta_kernel(int B, int H, int L, const T* __restrict__ o,
+                                                          const T* __restrict__ d_o, int ldo, float* __restrict__ delta) {
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // one thread per (b, i, h)
+    size_t total = (size_t)B * L * H;
+    if (idx >= total) return;
+    int h = (int)(idx % H);
+    size_t bi = idx / H;
+    int i = (int)(bi % L), b = (int)(bi / L);
+    const T* po = o + bi * ldo + h * 64;
+    const T* pd = d_o + bi * ldo + h * 64;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < 64; ++d) s += to_f32(po[d]) * to_f32(pd[d]);
+    delta[((size_t)b * H + h) * L + i] = s;
+}

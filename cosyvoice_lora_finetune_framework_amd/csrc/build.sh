@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libcvft.so for gfx950 in-tree (travels to the GPU box with the snapshot).
+set -e
+cd "$(dirname "$0")"
+OUT=../libcvft.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value"
+mkdir -p build
+pids=()
+for f in core gemm norm attention elementwise ce; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.cuh -nt build/$f.o ] || [ attn_common.cuh -nt build/$f.o ] || [ ../../include/cvft.h -nt build/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/core.o build/gemm.o build/norm.o build/attention.o build/elementwise.o build/ce.o
+echo "built $(realpath $OUT)"

@@ -1,0 +1,136 @@
+// common.cuh -- shared device helpers for libcvft (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+#include "../../include/cvft.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define WAVE 64
+
+extern "C" void cvft_set_error(const char* fmt, ...);
+
+#define CVFT_CHECK_ARG(cond, ...)                      \
+    do {                                               \
+        if (!(cond)) {                                 \
+            cvft_set_error(__VA_ARGS__);               \
+            return -1;                                 \
+        }                                              \
+    } while (0)
+
+#define CVFT_LAUNCH_CHECK(name)                                                 \
+    do {                                                                        \
+        hipError_t e__ = hipGetLastError();                                     \
+        if (e__ != hipSuccess) {                                                \
+            cvft_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return -2;                                                          \
+        }                                                                       \
+    } while (0)
+
+// ---------------------------------------------------------------- conversions
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// ---------------------------------------------------------------- MFMA traits
+// One 16x16 output tile per wave-instruction; operands are "k-contiguous rows":
+// A[row][k], B[col][k] (i.e. both row-major with k fastest), see
+// cdna_hip_programming.md section 3 (A/B operand lane maps, C/D map).
+//   C/D: acc[i] = C[row = (lane>>4)*4 + i][col = lane&15]
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int K = 32;
+    typedef bf16x8 Frag;
+    // p points at element [row = lane&15][k0]; lane reads k0 + 8*(lane>>4) .. +7 (16 B)
+    static __device__ __forceinline__ Frag load(const bf16_t* p, int lane) {
+        return *reinterpret_cast<const bf16x8*>(p + 8 * (lane >> 4));
+    }
+    static __device__ __forceinline__ void mma(f32x4& acc, Frag a, Frag b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ Frag zero() { Frag z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
+};
+template <> struct Mma<float> {
+    static constexpr int K = 4;
+    typedef float Frag;
+    static __device__ __forceinline__ Frag load(const float* p, int lane) { return p[lane >> 4]; }
+    static __device__ __forceinline__ void mma(f32x4& acc, Frag a, Frag b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ Frag zero() { return 0.f; }
+};
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float act_apply(int act, float x) {
+    switch (act) {
+        case CVFT_ACT_RELU: return x > 0.f ? x : 0.f;
+        case CVFT_ACT_SILU: return x / (1.f + expf(-x));
+        case CVFT_ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+        case CVFT_ACT_GELU_TANH: {
+            const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
+            return 0.5f * x * (1.f + tanhf(k0 * (x + k1 * x * x * x)));
+        }
+        case CVFT_ACT_MISH: {
+            float sp = x > 20.f ? x : log1pf(expf(x));
+            return x * tanhf(sp);
+        }
+        default: return x;
+    }
+}
+__device__ __forceinline__ float act_grad(int act, float x) {
+    switch (act) {
+        case CVFT_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case CVFT_ACT_SILU: {
+            float s = 1.f / (1.f + expf(-x));
+            return s * (1.f + x * (1.f - s));
+        }
+        case CVFT_ACT_GELU_ERF: {
+            float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+            float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case CVFT_ACT_GELU_TANH: {
+            const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
+            float x2 = x * x;
+            float th = tanhf(k0 * (x + k1 * x * x2));
+            return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x2);
+        }
+        case CVFT_ACT_MISH: {
+            float sp = x > 20.f ? x : log1pf(expf(x));
+            float th = tanhf(sp);
+            float sg = 1.f / (1.f + expf(-x));
+            return th + x * (1.f - th * th) * sg;
+        }
+        default: return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum, blockDim.x multiple of 64, <= 1024; `sm` >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    v = wave_sum(v);
+    int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sm[i];
+    return r;
+}

@@ -1,0 +1,479 @@
+// elementwise.hip -- small HBM-bound fused ops of the hot path (gathers, CFM prepare,
+// masked MSE, interpolation, depthwise conv, time embedding, optimiser pieces).
+// All are grid-stride, coalesced along the channel (fastest) axis.
+#include "common.cuh"
+
+static inline unsigned ew_grid(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (unsigned)(g > 8192 ? 8192 : (g == 0 ? 1 : g));
+}
+#define EW_LOOP(i, total) for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (total); i += (size_t)gridDim.x * 256)
+#define CHECK_DTYPE(name, dtype) CVFT_CHECK_ARG((dtype) == CVFT_F32 || (dtype) == CVFT_BF16, name ": bad dtype")
+
+// ---------------------------------------------------------------- embedding gather
+template <typename T>
+__global__ void embed_gather_kernel(int B, int L, int D, const int64_t* __restrict__ tok, const int* __restrict__ len,
+                                    const T* __restrict__ table, T* __restrict__ out) {
+    const size_t total = (size_t)B * L * D;
+    EW_LOOP(i, total) {
+        int d = (int)(i % D);
+        size_t bl = i / D;
+        int l = (int)(bl % L), b = (int)(bl / L);
+        int64_t t = tok[bl];
+        if (t < 0) t = 0;
+        T v = table[(size_t)t * D + d];
+        if (len && l >= len[b]) v = from_f32<T>(0.f);
+        out[i] = v;
+    }
+}
+extern "C" int cvft_embed_gather(int dtype, int B, int L, int D, const int64_t* tok, const int32_t* len,
+                                 const void* table, void* out, void* stream) {
+    CHECK_DTYPE("cvft_embed_gather", dtype);
+    CVFT_CHECK_ARG(B > 0 && L > 0 && D > 0 && tok && table && out, "cvft_embed_gather: bad args");
+    size_t total = (size_t)B * L * D;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((embed_gather_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, L, D, tok, len,
+                           (const float*)table, (float*)out);
+    else
+        hipLaunchKernelGGL((embed_gather_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, L, D, tok, len,
+                           (const bf16_t*)table, (bf16_t*)out);
+    CVFT_LAUNCH_CHECK("cvft_embed_gather");
+    return 0;
+}
+
+// ---------------------------------------------------------------- ragged row gather / scatter
+template <typename T>
+__global__ void gather_rows_kernel(int n, int D, const int* __restrict__ idx, const T* __restrict__ src, float fill,
+                                   T* __restrict__ out) {
+    const size_t total = (size_t)n * D;
+    EW_LOOP(i, total) {
+        int d = (int)(i % D);
+        int r = (int)(i / D);
+        int s = idx[r];
+        out[i] = s >= 0 ? src[(size_t)s * D + d] : from_f32<T>(fill);
+    }
+}
+template <typename T>
+__global__ void scatter_rows_kernel(int n, int D, const int* __restrict__ idx, const T* __restrict__ dout,
+                                    T* __restrict__ dsrc) {
+    const size_t total = (size_t)n * D;
+    EW_LOOP(i, total) {
+        int d = (int)(i % D);
+        int r = (int)(i / D);
+        int s = idx[r];
+        if (s >= 0) dsrc[(size_t)s * D + d] = dout[i];
+    }
+}
+extern "C" int cvft_gather_rows(int dtype, int n, int D, const int32_t* idx, const void* src, float fill, void* out,
+                                void* stream) {
+    CHECK_DTYPE("cvft_gather_rows", dtype);
+    CVFT_CHECK_ARG(n >= 0 && D > 0 && idx && src && out, "cvft_gather_rows: bad args");
+    if (n == 0) return 0;
+    size_t total = (size_t)n * D;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, n, D, idx,
+                           (const float*)src, fill, (float*)out);
+    else
+        hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, n, D, idx,
+                           (const bf16_t*)src, fill, (bf16_t*)out);
+    CVFT_LAUNCH_CHECK("cvft_gather_rows");
+    return 0;
+}
+extern "C" int cvft_scatter_rows(int dtype, int n, int D, const int32_t* idx, const void* dout, void* dsrc, void* stream) {
+    CHECK_DTYPE("cvft_scatter_rows", dtype);
+    CVFT_CHECK_ARG(n >= 0 && D > 0 && idx && dout && dsrc, "cvft_scatter_rows: bad args");
+    if (n == 0) return 0;
+    size_t total = (size_t)n * D;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, n, D, idx,
+                           (const float*)dout, (float*)dsrc);
+    else
+        hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, n, D, idx,
+                           (const bf16_t*)dout, (bf16_t*)dsrc);
+    CVFT_LAUNCH_CHECK("cvft_scatter_rows");
+    return 0;
+}
+
+// ---------------------------------------------------------------- row L2 normalise (one wave per row)
+template <typename T>
+__global__ void l2norm_rows_kernel(int rows, int D, const float* __restrict__ x, T* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c] * xr[c];
+    const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int c = lane; c < D; c += 64) y[(size_t)row * D + c] = from_f32<T>(xr[c] / nrm);
+}
+extern "C" int cvft_l2norm_rows(int dtype, int rows, int D, const float* x, void* y, void* stream) {
+    CHECK_DTYPE("cvft_l2norm_rows", dtype);
+    CVFT_CHECK_ARG(rows > 0 && D > 0 && x && y, "cvft_l2norm_rows: bad args");
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((l2norm_rows_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, D, x, (float*)y);
+    else
+        hipLaunchKernelGGL((l2norm_rows_kernel<bf16_t>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, D, x, (bf16_t*)y);
+    CVFT_LAUNCH_CHECK("cvft_l2norm_rows");
+    return 0;
+}
+
+// ---------------------------------------------------------------- sinusoidal time embedding (scale 1000)
+template <typename T>
+__global__ void time_embed_kernel(int B, int dim, const float* __restrict__ t, const float* __restrict__ freqs,
+                                  float scale, T* __restrict__ out) {
+    const int half = dim / 2;
+    const size_t total = (size_t)B * dim;
+    EW_LOOP(i, total) {
+        int d = (int)(i % dim), b = (int)(i / dim);
+        int k = d < half ? d : d - half;
+        float e = scale * t[b] * freqs[k];
+        out[i] = from_f32<T>(d < half ? sinf(e) : cosf(e));
+    }
+}
+extern "C" int cvft_time_embed(int dtype, int B, int dim, const float* t, const float* freqs, float scale, void* out,
+                               void* stream) {
+    CHECK_DTYPE("cvft_time_embed", dtype);
+    CVFT_CHECK_ARG(B > 0 && dim >= 4 && dim % 2 == 0 && t && freqs && out, "cvft_time_embed: bad args");
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((time_embed_kernel<float>), dim3(ew_grid((size_t)B * dim)), dim3(256), 0, (hipStream_t)stream, B, dim, t, freqs, scale, (float*)out);
+    else
+        hipLaunchKernelGGL((time_embed_kernel<bf16_t>), dim3(ew_grid((size_t)B * dim)), dim3(256), 0, (hipStream_t)stream, B, dim, t, freqs, scale, (bf16_t*)out);
+    CVFT_LAUNCH_CHECK("cvft_time_embed");
+    return 0;
+}
+
+// ---------------------------------------------------------------- elementwise activation
+template <typename T>
+__global__ void act_fwd_kernel(size_t n, int act, const T* __restrict__ x, T* __restrict__ y) {
+    EW_LOOP(i, n) y[i] = from_f32<T>(act_apply(act, to_f32(x[i])));
+}
+extern "C" int cvft_act_fwd(int dtype, int64_t n, int act, const void* x, void* y, void* stream) {
+    CHECK_DTYPE("cvft_act_fwd", dtype);
+    CVFT_CHECK_ARG(n >= 0 && x && y, "cvft_act_fwd: bad args");
+    if (n == 0) return 0;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((act_fwd_kernel<float>), dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, (size_t)n, act, (const float*)x, (float*)y);
+    else
+        hipLaunchKernelGGL((act_fwd_kernel<bf16_t>), dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, (size_t)n, act, (const bf16_t*)x, (bf16_t*)y);
+    CVFT_LAUNCH_CHECK("cvft_act_fwd");
+    return 0;
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(size_t n, int act, const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz) {
+    EW_LOOP(i, n) dz[i] = from_f32<T>(to_f32(dy[i]) * act_grad(act, to_f32(z[i])));
+}
+extern "C" int cvft_act_bwd(int dtype, int64_t n, int act, const void* z, const void* dy, void* dz, void* stream) {
+    CHECK_DTYPE("cvft_act_bwd", dtype);
+    CVFT_CHECK_ARG(n >= 0 && z && dy && dz, "cvft_act_bwd: bad args");
+    if (n == 0) return 0;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((act_bwd_kernel<float>), dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, (size_t)n, act, (const float*)z, (const float*)dy, (float*)dz);
+    else
+        hipLaunchKernelGGL((act_bwd_kernel<bf16_t>), dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, (size_t)n, act, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz);
+    CVFT_LAUNCH_CHECK("cvft_act_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------- CFM prepare
+template <typename T>
+__global__ void cfm_prepare_kernel(int B, int T_, const float* __restrict__ feat, const float* __restrict__ z,
+                                   const float* __restrict__ t_raw, const float* __restrict__ keep,
+                                   const T* __restrict__ mu, const T* __restrict__ spk, float mel_mean, float mel_std,
+                                   float sigma_min, T* __restrict__ xin, float* __restrict__ u, float* __restrict__ tout) {
+    const size_t total = (size_t)B * T_ * 80;
+    EW_LOOP(i, total) {
+        int c = (int)(i % 80);
+        size_t bt = i / 80;
+        int b = (int)(bt / T_);
+        const float t = 1.f - cosf(t_raw[b] * 0.5f * 3.14159265358979323846f);
+        const float x1 = (feat[i] - mel_mean) / mel_std;
+        const float zz = z[i];
+        const float y = (1.f - (1.f - sigma_min) * t) * zz + t * x1;
+        u[i] = x1 - (1.f - sigma_min) * zz;
+        const float kp = keep[b];
+        T* row = xin + bt * 320;
+        row[c] = from_f32<T>(y);
+        row[80 + c] = from_f32<T>(to_f32(mu[i]) * kp);
+        row[160 + c] = from_f32<T>(to_f32(spk[(size_t)b * 80 + c]) * kp);
+        row[240 + c] = from_f32<T>(0.f);
+        if (c == 0 && (bt % T_) == 0) tout[b] = t;
+    }
+}
+extern "C" int cvft_cfm_prepare(int dtype, int B, int T, const float* feat, const float* z, const float* t_raw,
+                                const float* cfg_keep, const void* mu, const void* spk, float mel_mean, float mel_std,
+                                float sigma_min, void* xin, float* u, float* t, void* stream) {
+    CHECK_DTYPE("cvft_cfm_prepare", dtype);
+    CVFT_CHECK_ARG(B > 0 && T > 0 && feat && z && t_raw && cfg_keep && mu && spk && xin && u && t, "cvft_cfm_prepare: bad args");
+    size_t total = (size_t)B * T * 80;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((cfm_prepare_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, feat, z,
+                           t_raw, cfg_keep, (const float*)mu, (const float*)spk, mel_mean, mel_std, sigma_min, (float*)xin, u, t);
+    else
+        hipLaunchKernelGGL((cfm_prepare_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, feat, z,
+                           t_raw, cfg_keep, (const bf16_t*)mu, (const bf16_t*)spk, mel_mean, mel_std, sigma_min, (bf16_t*)xin, u, t);
+    CVFT_LAUNCH_CHECK("cvft_cfm_prepare");
+    return 0;
+}
+
+// ---------------------------------------------------------------- masked MSE
+template <typename T>
+__global__ void __launch_bounds__(256) masked_mse_fwd_kernel(int B, int T_, int C, const T* __restrict__ pred,
+                                                              const float* __restrict__ u, const int* __restrict__ len,
+                                                              float* __restrict__ loss_sum) {
+    __shared__ float sm[16];
+    const size_t total = (size_t)B * T_ * C;
+    float s = 0.f;
+    EW_LOOP(i, total) {
+        size_t bt = i / C;
+        int t = (int)(bt % T_), b = (int)(bt / T_);
+        if (!len || t < len[b]) {
+            float d = to_f32(pred[i]) - u[i];
+            s += d * d;
+        }
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, s);
+}
+template <typename T>
+__global__ void masked_mse_bwd_kernel(int B, int T_, int C, const T* __restrict__ pred, const float* __restrict__ u,
+                                      const int* __restrict__ len, const float* __restrict__ gscale, T* __restrict__ dpred) {
+    const size_t total = (size_t)B * T_ * C;
+    const float g = 2.f * gscale[0];
+    EW_LOOP(i, total) {
+        size_t bt = i / C;
+        int t = (int)(bt % T_), b = (int)(bt / T_);
+        float d = 0.f;
+        if (!len || t < len[b]) d = g * (to_f32(pred[i]) - u[i]);
+        dpred[i] = from_f32<T>(d);
+    }
+}
+extern "C" int cvft_masked_mse_fwd(int dtype, int B, int T, int C, const void* pred, const float* u, const int32_t* len,
+                                   float* loss_sum, void* stream) {
+    CHECK_DTYPE("cvft_masked_mse_fwd", dtype);
+    CVFT_CHECK_ARG(B > 0 && T > 0 && C > 0 && pred && u && loss_sum, "cvft_masked_mse_fwd: bad args");
+    size_t total = (size_t)B * T * C;
+    unsigned g = ew_grid(total);
+    if (g > 1024) g = 1024;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((masked_mse_fwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, B, T, C, (const float*)pred, u, len, loss_sum);
+    else
+        hipLaunchKernelGGL((masked_mse_fwd_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, B, T, C, (const bf16_t*)pred, u, len, loss_sum);
+    CVFT_LAUNCH_CHECK("cvft_masked_mse_fwd");
+    return 0;
+}
+extern "C" int cvft_masked_mse_bwd(int dtype, int B, int T, int C, const void* pred, const float* u, const int32_t* len,
+                                   const float* gscale, void* dpred, void* stream) {
+    CHECK_DTYPE("cvft_masked_mse_bwd", dtype);
+    CVFT_CHECK_ARG(B > 0 && T > 0 && C > 0 && pred && u && gscale && dpred, "cvft_masked_mse_bwd: bad args");
+    size_t total = (size_t)B * T * C;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((masked_mse_bwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, C, (const float*)pred, u, len, gscale, (float*)dpred);
+    else
+        hipLaunchKernelGGL((masked_mse_bwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, C, (const bf16_t*)pred, u, len, gscale, (bf16_t*)dpred);
+    CVFT_LAUNCH_CHECK("cvft_masked_mse_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------- linear interpolation along time
+// torch upsample_linear1d, align_corners=False: src = max(scale*(dst+0.5)-0.5, 0), scale = Lin/Lout
+__device__ __forceinline__ void interp_src(int j, float scale, int Lin, int& i0, int& i1, float& w0, float& w1) {
+    float src = scale * ((float)j + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > Lin - 1) i0 = Lin - 1;
+    i1 = i0 + ((i0 < Lin - 1) ? 1 : 0);
+    w1 = src - (float)i0;
+    w0 = 1.f - w1;
+}
+template <typename T>
+__global__ void interp_fwd_kernel(int B, int Lin, int Lout, int C, const T* __restrict__ x, T* __restrict__ y) {
+    const size_t total = (size_t)B * Lout * C;
+    const float scale = (float)Lin / (float)Lout;
+    EW_LOOP(i, total) {
+        int c = (int)(i % C);
+        size_t bj = i / C;
+        int j = (int)(bj % Lout), b = (int)(bj / Lout);
+        int i0, i1;
+        float w0, w1;
+        interp_src(j, scale, Lin, i0, i1, w0, w1);
+        const T* xb = x + (size_t)b * Lin * C;
+        y[i] = from_f32<T>(w0 * to_f32(xb[(size_t)i0 * C + c]) + w1 * to_f32(xb[(size_t)i1 * C + c]));
+    }
+}
+template <typename T>
+__global__ void interp_bwd_kernel(int B, int Lin, int Lout, int C, const T* __restrict__ dy, T* __restrict__ dx) {
+    const size_t total = (size_t)B * Lin * C;
+    const float scale = (float)Lin / (float)Lout;
+    const float inv = (float)Lout / (float)Lin;
+    EW_LOOP(i, total) {
+        int c = (int)(i % C);
+        size_t bi = i / C;
+        int ii = (int)(bi % Lin), b = (int)(bi / Lin);
+        // candidate outputs: src in (ii-1, ii+1)  =>  j in ((ii-0.5)*inv-0.5, (ii+1.5)*inv-0.5); widen by one
+        int jlo = (int)floorf(((float)ii - 0.5f) * inv - 0.5f) - 1;
+        int jhi = (int)ceilf(((float)ii + 1.5f) * inv - 0.5f) + 1;
+        if (jlo < 0) jlo = 0;
+        if (jhi > Lout - 1) jhi = Lout - 1;
+        const T* dyb = dy + (size_t)b * Lout * C;
+        float s = 0.f;
+        for (int j = jlo; j <= jhi; ++j) {
+            int i0, i1;
+            float w0, w1;
+            interp_src(j, scale, Lin, i0, i1, w0, w1);
+            float g = to_f32(dyb[(size_t)j * C + c]);
+            if (i0 == ii) s += w0 * g;
+            if (i1 == ii) s += w1 * g;
+        }
+        dx[i] = from_f32<T>(s);
+    }
+}
+extern "C" int cvft_interp_linear_fwd(int dtype, int B, int Lin, int Lout, int C, const void* x, void* y, void* stream) {
+    CHECK_DTYPE("cvft_interp_linear_fwd", dtype);
+    CVFT_CHECK_ARG(B > 0 && Lin > 0 && Lout > 0 && C > 0 && x && y, "cvft_interp_linear_fwd: bad args");
+    size_t total = (size_t)B * Lout * C;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((interp_fwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const float*)x, (float*)y);
+    else
+        hipLaunchKernelGGL((interp_fwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const bf16_t*)x, (bf16_t*)y);
+    CVFT_LAUNCH_CHECK("cvft_interp_linear_fwd");
+    return 0;
+}
+extern "C" int cvft_interp_linear_bwd(int dtype, int B, int Lin, int Lout, int C, const void* dy, void* dx, void* stream) {
+    CHECK_DTYPE("cvft_interp_linear_bwd", dtype);
+    CVFT_CHECK_ARG(B > 0 && Lin > 0 && Lout > 0 && C > 0 && dy && dx, "cvft_interp_linear_bwd: bad args");
+    size_t total = (size_t)B * Lin * C;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((interp_bwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const float*)dy, (float*)dx);
+    else
+        hipLaunchKernelGGL((interp_bwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const bf16_t*)dy, (bf16_t*)dx);
+    CVFT_LAUNCH_CHECK("cvft_interp_linear_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------- depthwise conv1d (groups = C), channel-last
+// One block = 64 frames x 64 channels; the (64 + Kw - 1) x 64 input window is staged in LDS so every
+// frame is read from HBM once, coalesced along channels.
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) dwconv_kernel(int B, int T_, int C, int Kw, int pad_left, const T* __restrict__ x,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const int* __restrict__ len, T* __restrict__ y) {
+    extern __shared__ float win[];   // (64 + Kw - 1) x 64
+    const int tt = (T_ + 63) / 64;
+    const int b = blockIdx.x / tt, t0 = (blockIdx.x % tt) * 64, c0 = blockIdx.y * 64;
+    const int lb = len ? len[b] : T_;
+    const int rows = 64 + Kw - 1;
+    // fwd: y[t] = sum_k w[k] * xm[t + k - pad_left];  bwd: dx[t] = m[t] * sum_k w[k] * dy[t - k + pad_left]
+    const int base = BWD ? t0 - (Kw - 1 - pad_left) : t0 - pad_left;
+    for (int e = threadIdx.x; e < rows * 64; e += 256) {
+        int r = e >> 6, c = e & 63;
+        int t = base + r;
+        float v = 0.f;
+        if (t >= 0 && t < T_ && c0 + c < C && (BWD || t < lb)) v = to_f32(x[((size_t)b * T_ + t) * C + c0 + c]);
+        win[e] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        int r = e >> 6, c = e & 63;
+        int t = t0 + r;
+        if (t >= T_ || c0 + c >= C) continue;
+        const float* wc = w + (size_t)(c0 + c) * Kw;
+        float s = (!BWD && bias) ? bias[c0 + c] : 0.f;
+        for (int k = 0; k < Kw; ++k) s += wc[k] * win[(BWD ? (r + Kw - 1 - k) : (r + k)) * 64 + c];
+        if (BWD && t >= lb) s = 0.f;
+        y[((size_t)b * T_ + t) * C + c0 + c] = from_f32<T>(s);
+    }
+}
+extern "C" int cvft_dwconv1d_fwd(int dtype, int B, int T, int C, int Kw, int pad_left, const void* x, const float* w,
+                                 const float* bias, const int32_t* len, void* y, void* stream) {
+    CHECK_DTYPE("cvft_dwconv1d_fwd", dtype);
+    CVFT_CHECK_ARG(B > 0 && T > 0 && C > 0 && Kw > 0 && Kw <= 129 && pad_left >= 0 && pad_left < Kw && x && w && y, "cvft_dwconv1d_fwd: bad args");
+    dim3 grid(B * ((T + 63) / 64), (C + 63) / 64);
+    size_t sm = (size_t)(64 + Kw - 1) * 64 * sizeof(float);
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((dwconv_kernel<float, false>), grid, dim3(256), sm, (hipStream_t)stream, B, T, C, Kw, pad_left, (const float*)x, w, bias, len, (float*)y);
+    else
+        hipLaunchKernelGGL((dwconv_kernel<bf16_t, false>), grid, dim3(256), sm, (hipStream_t)stream, B, T, C, Kw, pad_left, (const bf16_t*)x, w, bias, len, (bf16_t*)y);
+    CVFT_LAUNCH_CHECK("cvft_dwconv1d_fwd");
+    return 0;
+}
+extern "C" int cvft_dwconv1d_bwd(int dtype, int B, int T, int C, int Kw, int pad_left, const void* dy, const float* w,
+                                 const int32_t* len, void* dx, void* stream) {
+    CHECK_DTYPE("cvft_dwconv1d_bwd", dtype);
+    CVFT_CHECK_ARG(B > 0 && T > 0 && C > 0 && Kw > 0 && Kw <= 129 && pad_left >= 0 && pad_left < Kw && dy && w && dx, "cvft_dwconv1d_bwd: bad args");
+    dim3 grid(B * ((T + 63) / 64), (C + 63) / 64);
+    size_t sm = (size_t)(64 + Kw - 1) * 64 * sizeof(float);
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((dwconv_kernel<float, true>), grid, dim3(256), sm, (hipStream_t)stream, B, T, C, Kw, pad_left, (const float*)dy, w, nullptr, len, (float*)dx);
+    else
+        hipLaunchKernelGGL((dwconv_kernel<bf16_t, true>), grid, dim3(256), sm, (hipStream_t)stream, B, T, C, Kw, pad_left, (const bf16_t*)dy, w, nullptr, len, (bf16_t*)dx);
+    CVFT_LAUNCH_CHECK("cvft_dwconv1d_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------- flat optimiser pieces
+__global__ void __launch_bounds__(256) sumsq_kernel(size_t n, const float* __restrict__ g, float* __restrict__ out) {
+    __shared__ float sm[16];
+    float s = 0.f;
+    EW_LOOP(i, n) s += g[i] * g[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+extern "C" int cvft_sumsq(int64_t n, const float* g, float* out, void* stream) {
+    CVFT_CHECK_ARG(n >= 0 && g && out, "cvft_sumsq: bad args");
+    if (n == 0) return 0;
+    unsigned grid = ew_grid((size_t)n);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (size_t)n, g, out);
+    CVFT_LAUNCH_CHECK("cvft_sumsq");
+    return 0;
+}
+
+__global__ void adamw_flat_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, const float* __restrict__ lr_p, float b1, float b2, float eps,
+                                  float wd, const float* __restrict__ step_p, const float* __restrict__ gnorm_sq,
+                                  float max_norm, float grad_scale) {
+    const float lr = lr_p[0];
+    const float step = step_p[0];
+    float clip = 1.f;
+    if (max_norm > 0.f && gnorm_sq) {
+        float tn = sqrtf(gnorm_sq[0]) * fabsf(grad_scale);
+        clip = fminf(1.f, max_norm / (tn + 1e-6f));
+    }
+    const float gs = grad_scale * clip;
+    const float bc1 = 1.f - powf(b1, step);
+    const float bc2 = 1.f - powf(b2, step);
+    const float step_size = lr / bc1;
+    const float bc2s = sqrtf(bc2);
+    EW_LOOP(i, n) {
+        float gi = g[i] * gs;
+        float pi = p[i] * (1.f - lr * wd);
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        float denom = sqrtf(vi) / bc2s + eps;
+        p[i] = pi - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+extern "C" int cvft_adamw_flat(int64_t n, float* p, const float* g, float* m, float* v, const float* lr, float beta1,
+                               float beta2, float eps, float wd, const float* step, const float* gnorm_sq, float max_norm,
+                               float grad_scale, void* stream) {
+    CVFT_CHECK_ARG(n >= 0 && p && g && m && v && lr && step, "cvft_adamw_flat: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, (size_t)n, p, g, m, v, lr,
+                       beta1, beta2, eps, wd, step, gnorm_sq, max_norm, grad_scale);
+    CVFT_LAUNCH_CHECK("cvft_adamw_flat");
+    return 0;
+}
+
+__global__ void cast_bf16_kernel(size_t n, const float* __restrict__ s, bf16_t* __restrict__ d) {
+    EW_LOOP(i, n) d[i] = (bf16_t)s[i];
+}
+extern "C" int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream) {
+    CVFT_CHECK_ARG(n >= 0 && src && dst, "cvft_cast_f32_to_bf16: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, (size_t)n, src, (bf16_t*)dst);
+    CVFT_LAUNCH_CHECK("cvft_cast_f32_to_bf16");
+    return 0;
+}

@@ -1,0 +1,268 @@
+// norm.hip -- LayerNorm (one wavefront per row) and channel-last GroupNorm+Mish.
+// HBM-bound wavefront-level ops; statistics in fp32, two-pass (mean, then centred
+// variance) to match torch's numerics.
+//
+// Replaces (reference): nn.LayerNorm call sites in encoder_layer.py:90-106,
+// subsampling.py:69-113/338-383, matcha transformer.py:255-316; Block1D /
+// ResnetBlock1D GroupNorm(8)+Mish (modules.py:60-94) and InterpolateRegulator's
+// GroupNorm(1)+Mish (length_regulator.py:34-41).
+#include "common.cuh"
+
+template <typename T>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(int rows, int C, const T* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, int relu, float post, T* __restrict__ y,
+                                                      float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += to_f32(xr[c]);
+    const float mu = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float d = to_f32(xr[c]) - mu;
+        v += d * d;
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(v) / (float)C + eps);
+    T* yr = y + (size_t)row * C;
+    for (int c = lane; c < C; c += 64) {
+        float o = (to_f32(xr[c]) - mu) * rs * gamma[c] + beta[c];
+        if (relu) o = fmaxf(o, 0.f);
+        yr[c] = from_f32<T>(o * post);
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      int relu, float post, const T* __restrict__ dy,
+                                                      T* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + (size_t)row * C;
+    const T* dr = dy + (size_t)row * C;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float xh = (to_f32(xr[c]) - mu) * rs;
+        float g = to_f32(dr[c]) * post;
+        if (relu && (xh * gamma[c] + beta[c]) <= 0.f) g = 0.f;
+        g *= gamma[c];
+        s1 += g;
+        s2 += g * xh;
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    T* ox = dx + (size_t)row * C;
+    for (int c = lane; c < C; c += 64) {
+        float xh = (to_f32(xr[c]) - mu) * rs;
+        float g = to_f32(dr[c]) * post;
+        if (relu && (xh * gamma[c] + beta[c]) <= 0.f) g = 0.f;
+        g *= gamma[c];
+        ox[c] = from_f32<T>(rs * (g - s1 - xh * s2));
+    }
+}
+
+extern "C" int cvft_layernorm_fwd(int dtype, int rows, int C, const void* x, const float* gamma, const float* beta,
+                                  float eps, int relu, float post_scale, void* y, float* mean, float* rstd,
+                                  void* stream) {
+    CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_layernorm_fwd: bad dtype");
+    CVFT_CHECK_ARG(rows >= 0 && C > 0 && x && gamma && beta && y && mean && rstd, "cvft_layernorm_fwd: bad args");
+    if (rows == 0) return 0;
+    dim3 grid((rows + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((ln_fwd_kernel<float>), grid, dim3(256), 0, st, rows, C, (const float*)x, gamma, beta, eps,
+                           relu, post_scale, (float*)y, mean, rstd);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, rows, C, (const bf16_t*)x, gamma, beta, eps,
+                           relu, post_scale, (bf16_t*)y, mean, rstd);
+    CVFT_LAUNCH_CHECK("cvft_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, const float* gamma, const float* beta,
+                                  const float* mean, const float* rstd, int relu, float post_scale, const void* dy,
+                                  void* dx, void* stream) {
+    CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_layernorm_bwd: bad dtype");
+    CVFT_CHECK_ARG(rows >= 0 && C > 0 && x && gamma && beta && mean && rstd && dy && dx, "cvft_layernorm_bwd: bad args");
+    if (rows == 0) return 0;
+    dim3 grid((rows + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((ln_bwd_kernel<float>), grid, dim3(256), 0, st, rows, C, (const float*)x, gamma, beta, mean,
+                           rstd, relu, post_scale, (const float*)dy, (float*)dx);
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, rows, C, (const bf16_t*)x, gamma, beta, mean,
+                           rstd, relu, post_scale, (const bf16_t*)dy, (bf16_t*)dx);
+    CVFT_LAUNCH_CHECK("cvft_layernorm_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ GroupNorm + Mish
+// stats: one block per (b, g); elements (t, cc) with cc fastest => Cg-element runs per frame.
+template <typename T>
+__global__ void __launch_bounds__(256) gn_stats_kernel(int T_, int C, int G, const T* __restrict__ x, float eps,
+                                                        float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ float sm[16];
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int Cg = C / G;
+    const T* xb = x + (size_t)b * T_ * C + g * Cg;
+    const int n = T_ * Cg;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) s += to_f32(xb[(size_t)(e / Cg) * C + (e % Cg)]);
+    const float mu = block_sum(s, sm) / (float)n;
+    float v = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        float d = to_f32(xb[(size_t)(e / Cg) * C + (e % Cg)]) - mu;
+        v += d * d;
+    }
+    const float var = block_sum(v, sm) / (float)n;
+    if (threadIdx.x == 0) {
+        mean[blockIdx.x] = mu;
+        rstd[blockIdx.x] = 1.0f / sqrtf(var + eps);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply_fwd_kernel(int B, int T_, int C, int G, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const int* __restrict__ len,
+                                                            const T* __restrict__ add, int apply_mish,
+                                                            T* __restrict__ y) {
+    const size_t total = (size_t)B * T_ * C;
+    const int Cg = C / G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c = (int)(i % C);
+        size_t bt = i / C;
+        int t = (int)(bt % T_), b = (int)(bt / T_);
+        int sg = b * G + c / Cg;
+        float z = (to_f32(x[i]) - mean[sg]) * rstd[sg] * gamma[c] + beta[c];
+        float o = apply_mish ? act_apply(CVFT_ACT_MISH, z) : z;
+        if (len && t >= len[b]) o = 0.f;
+        if (add) o += to_f32(add[(size_t)b * C + c]);
+        y[i] = from_f32<T>(o);
+    }
+}
+
+// backward stats: s1 = sum(gamma*dz), s2 = sum(gamma*dz*xhat) over the group
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(int T_, int C, int G, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const int* __restrict__ len,
+                                                            int apply_mish, const T* __restrict__ dy,
+                                                            float* __restrict__ ws) {
+    __shared__ float sm[16];
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int Cg = C / G;
+    const size_t off = (size_t)b * T_ * C + g * Cg;
+    const int n = T_ * Cg;
+    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+    const int lb = len ? len[b] : T_;
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        int t = e / Cg, cc = e % Cg, c = g * Cg + cc;
+        if (t >= lb) continue;
+        size_t i = off + (size_t)t * C + cc;
+        float xh = (to_f32(x[i]) - mu) * rs;
+        float dz = to_f32(dy[i]);
+        if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c] + beta[c]);
+        dz *= gamma[c];
+        s1 += dz;
+        s2 += dz * xh;
+    }
+    s1 = block_sum(s1, sm);
+    s2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+        ws[blockIdx.x * 2 + 0] = s1 / (float)n;
+        ws[blockIdx.x * 2 + 1] = s2 / (float)n;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply_bwd_kernel(int B, int T_, int C, int G, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const int* __restrict__ len,
+                                                            int apply_mish, const T* __restrict__ dy,
+                                                            const float* __restrict__ ws, T* __restrict__ dx) {
+    const size_t total = (size_t)B * T_ * C;
+    const int Cg = C / G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c = (int)(i % C);
+        size_t bt = i / C;
+        int t = (int)(bt % T_), b = (int)(bt / T_);
+        int sg = b * G + c / Cg;
+        float rs = rstd[sg];
+        float xh = (to_f32(x[i]) - mean[sg]) * rs;
+        float dz = 0.f;
+        if (!len || t < len[b]) {
+            dz = to_f32(dy[i]);
+            if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c] + beta[c]);
+            dz *= gamma[c];
+        }
+        dx[i] = from_f32<T>(rs * (dz - ws[sg * 2] - xh * ws[sg * 2 + 1]));
+    }
+}
+
+static inline unsigned ew_grid(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (unsigned)(g > 4096 ? 4096 : (g == 0 ? 1 : g));
+}
+
+extern "C" int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, const void* x, const float* gamma,
+                                       const float* beta, float eps, const int32_t* len, const void* add,
+                                       int apply_mish, void* y, float* mean, float* rstd, void* stream) {
+    CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_groupnorm_mish_fwd: bad dtype");
+    CVFT_CHECK_ARG(B > 0 && T > 0 && C > 0 && G > 0 && C % G == 0, "cvft_groupnorm_mish_fwd: bad dims B%d T%d C%d G%d", B, T, C, G);
+    CVFT_CHECK_ARG(x && gamma && beta && y && mean && rstd, "cvft_groupnorm_mish_fwd: null operand");
+    hipStream_t st = (hipStream_t)stream;
+    size_t total = (size_t)B * T * C;
+    if (dtype == CVFT_F32) {
+        hipLaunchKernelGGL((gn_stats_kernel<float>), dim3(B * G), dim3(256), 0, st, T, C, G, (const float*)x, eps, mean, rstd);
+        hipLaunchKernelGGL((gn_apply_fwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
+                           (const float*)x, gamma, beta, mean, rstd, len, (const float*)add, apply_mish, (float*)y);
+    } else {
+        hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), dim3(B * G), dim3(256), 0, st, T, C, G, (const bf16_t*)x, eps, mean, rstd);
+        hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
+                           (const bf16_t*)x, gamma, beta, mean, rstd, len, (const bf16_t*)add, apply_mish, (bf16_t*)y);
+    }
+    CVFT_LAUNCH_CHECK("cvft_groupnorm_mish_fwd");
+    return 0;
+}
+
+extern "C" int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, const void* x, const float* gamma,
+                                       const float* beta, const float* mean, const float* rstd, const int32_t* len,
+                                       int apply_mish, const void* dy, void* dx, float* ws, void* stream) {
+    CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_groupnorm_mish_bwd: bad dtype");
+    CVFT_CHECK_ARG(B > 0 && T > 0 && C > 0 && G > 0 && C % G == 0, "cvft_groupnorm_mish_bwd: bad dims");
+    CVFT_CHECK_ARG(x && gamma && beta && mean && rstd && dy && dx && ws, "cvft_groupnorm_mish_bwd: null operand");
+    hipStream_t st = (hipStream_t)stream;
+    size_t total = (size_t)B * T * C;
+    if (dtype == CVFT_F32) {
+        hipLaunchKernelGGL((gn_bwd_stats_kernel<float>), dim3(B * G), dim3(256), 0, st, T, C, G, (const float*)x, gamma,
+                           beta, mean, rstd, len, apply_mish, (const float*)dy, ws);
+        hipLaunchKernelGGL((gn_apply_bwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
+                           (const float*)x, gamma, beta, mean, rstd, len, apply_mish, (const float*)dy, ws, (float*)dx);
+    } else {
+        hipLaunchKernelGGL((gn_bwd_stats_kernel<bf16_t>), dim3(B * G), dim3(256), 0, st, T, C, G, (const bf16_t*)x, gamma,
+                           beta, mean, rstd, len, apply_mish, (const bf16_t*)dy, ws);
+        hipLaunchKernelGGL((gn_apply_bwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
+                           (const bf16_t*)x, gamma, beta, mean, rstd, len, apply_mish, (const bf16_t*)dy, ws, (bf16_t*)dx);
+    }
+    CVFT_LAUNCH_CHECK("cvft_groupnorm_mish_bwd");
+    return 0;
+}

@@ -1,0 +1,611 @@
+"""torch.autograd wrappers over the libcvft C ABI (include/cvft.h).
+
+Every op here launches hand-written gfx950 kernels on torch's current stream; torch only
+owns the memory.  Activations are 2-D, channel-last ``[rows, C]`` contiguous tensors
+(rows = batch * time).  Backward passes produce input gradients and LoRA A/B gradients
+only: every other parameter is frozen by ``lora.apply_lora_to_model``
+(reference lora.py:214-216), so no frozen-weight / norm-affine gradients are computed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import binding as cb
+from .binding import ACT, GemmArgs, check, dt, lib, ptr, stream
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------
+# raw launches
+# ---------------------------------------------------------------------------------
+@dataclass
+class Geo:
+    """Row geometry of one tap-GEMM launch (see cvft_gemm in include/cvft.h)."""
+    Tm: int
+    Tin: int
+    Tout: int
+    in_stride: int = 1
+    out_stride: int = 1
+    out_off: int = 0
+    taps: Tuple[int, ...] = (0,)
+
+
+def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Optional[int] = None,
+         bias: Optional[torch.Tensor] = None, U: Optional[torch.Tensor] = None, Bl: Optional[torch.Tensor] = None,
+         alpha: float = 1.0, act: Optional[str] = None, preact: Optional[torch.Tensor] = None,
+         dact_src: Optional[torch.Tensor] = None, dact: Optional[str] = None,
+         residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+         geo: Optional[Geo] = None, nb: int = 1, in_len: Optional[torch.Tensor] = None,
+         out_len: Optional[torch.Tensor] = None, out_rows: Optional[int] = None) -> torch.Tensor:
+    """C = epi(alpha * (taps(x) @ W^T + U @ Bl^T) + bias); W is [N][ntaps*K] (k contiguous)."""
+    assert x.dim() == 2 and W.dim() == 2 and x.dtype == W.dtype
+    N = W.shape[0] if N is None else N
+    a = GemmArgs()
+    a.dtype = dt(x)
+    if geo is None:
+        geo = Geo(Tm=x.shape[0], Tin=x.shape[0], Tout=x.shape[0])
+        nb = 1
+    ntaps = len(geo.taps)
+    K = (W.shape[1] // ntaps) if K is None else K
+    assert x.shape[1] >= K and W.shape[1] >= ntaps * K
+    assert x.shape[0] == nb * geo.Tin, (x.shape, nb, geo)
+    a.M, a.N, a.K = nb * geo.Tm, N, K
+    a.Tm, a.Tin, a.Tout = geo.Tm, geo.Tin, geo.Tout
+    a.in_stride, a.out_stride, a.out_off, a.ntaps = geo.in_stride, geo.out_stride, geo.out_off, ntaps
+    for i in range(4):
+        a.tap_off[i] = geo.taps[i] if i < ntaps else 0
+    a.in_len, a.out_len = ptr(in_len), ptr(out_len)
+    a.A, a.lda = ptr(x), x.stride(0)
+    a.W, a.ldw = ptr(W), W.stride(0)
+    if U is not None:
+        assert Bl is not None and U.shape[0] == a.M and Bl.shape[0] == N and U.shape[1] == Bl.shape[1]
+        a.U, a.ldu, a.R = ptr(U), U.stride(0), U.shape[1]
+        a.Bl, a.ldbl = ptr(Bl), Bl.stride(0)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= N
+    a.bias, a.alpha, a.act = ptr(bias), float(alpha), ACT[act]
+    if out is None:
+        rows = nb * geo.Tout if out_rows is None else out_rows
+        out = torch.empty((rows, N), dtype=x.dtype, device=x.device)
+    assert out.shape[0] == nb * geo.Tout and out.shape[1] >= N
+    if preact is not None:
+        a.preact, a.ldp = ptr(preact), preact.stride(0)
+    if dact_src is not None:
+        a.dact_src, a.ldd, a.dact = ptr(dact_src), dact_src.stride(0), ACT[dact]
+    if residual is not None:
+        assert residual.shape[0] == out.shape[0]
+        a.residual, a.ldr = ptr(residual), residual.stride(0)
+    a.C, a.ldc = ptr(out), out.stride(0)
+    check(lib().cvft_gemm(C.byref(a), stream()), "cvft_gemm")
+    return out
+
+
+def tn_accum(P: torch.Tensor, Q: torch.Tensor, G: torch.Tensor) -> None:
+    """G[p,q] += sum_m P[m,p] Q[m,q]  (G fp32)."""
+    assert P.shape[0] == Q.shape[0] and G.dtype == torch.float32 and G.shape == (P.shape[1], Q.shape[1])
+    check(lib().cvft_tn_accum(dt(P), P.shape[0], P.shape[1], Q.shape[1], ptr(P), P.stride(0), ptr(Q), Q.stride(0),
+                              ptr(G), G.stride(0), stream()), "cvft_tn_accum")
+
+
+def act_fwd(x: torch.Tensor, act: str) -> torch.Tensor:
+    x = _c(x)
+    y = torch.empty_like(x)
+    check(lib().cvft_act_fwd(dt(x), x.numel(), ACT[act], ptr(x), ptr(y), stream()), "cvft_act_fwd")
+    return y
+
+
+def act_bwd(z: torch.Tensor, dy: torch.Tensor, act: str) -> torch.Tensor:
+    dz = torch.empty_like(z)
+    check(lib().cvft_act_bwd(dt(z), z.numel(), ACT[act], ptr(z), ptr(_c(dy)), ptr(dz), stream()), "cvft_act_bwd")
+    return dz
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act: str):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return act_fwd(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return act_bwd(x, dy, ctx.act), None
+
+
+# ---------------------------------------------------------------------------------
+# frozen-weight packs
+# ---------------------------------------------------------------------------------
+class LinearPack:
+    """Frozen Linear weight in compute dtype: Wf [N][K] (forward), Wb [K][N] (dgrad), bias fp32."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype):
+        self.N, self.K = weight.shape
+        self.Wf = weight.detach().to(dtype).contiguous()
+        self._Wb = None
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+
+    @property
+    def Wb(self) -> torch.Tensor:
+        if self._Wb is None:
+            self._Wb = self.Wf.t().contiguous()
+        return self._Wb
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b + scale * (x A^T) B^T) (+ residual): reference lora.py:64-76 as ONE
+    GEMM launch plus a rank-r pre-GEMM; backward = dgrad (+ rank-r side path) and dA/dB."""
+
+    @staticmethod
+    def forward(ctx, x, A, B, residual, pack: LinearPack, scale: float, act: Optional[str]):
+        x = _c(x)
+        has_lora = A is not None
+        need_grad = any(ctx.needs_input_grad[:3])
+        U = Ac = Bc = None
+        if has_lora:
+            Ac, Bc = A.detach().to(x.dtype), B.detach().to(x.dtype)
+            U = gemm(x, _c(Ac), alpha=scale)
+        z = torch.empty((x.shape[0], pack.N), dtype=x.dtype, device=x.device) if (act and need_grad) else None
+        y = gemm(x, pack.Wf, bias=pack.bias, U=U, Bl=Bc, act=act, preact=z, residual=None if residual is None else _c(residual))
+        ctx.pack, ctx.scale, ctx.act, ctx.has_lora = pack, scale, act, has_lora
+        ctx.save_for_backward(x, U, z, Ac, Bc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, U, z, Ac, Bc = ctx.saved_tensors
+        dy = _c(dy)
+        dz = act_bwd(z, dy, ctx.act) if ctx.act else dy
+        dx = dA = dB = None
+        V = None
+        if ctx.has_lora:
+            V = gemm(dz, Bc.t().contiguous(), alpha=ctx.scale)          # [M, r] = s * dz B
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dz, ctx.pack.Wb, U=V, Bl=None if V is None else Ac.t().contiguous())
+        if ctx.has_lora:
+            dA = torch.zeros(Ac.shape, dtype=torch.float32, device=x.device)
+            dB = torch.zeros(Bc.shape, dtype=torch.float32, device=x.device)
+            tn_accum(V, x, dA)
+            tn_accum(dz, U, dB)
+        dres = dy if ctx.needs_input_grad[3] else None
+        return dx, dA, dB, dres, None, None, None
+
+
+def lora_linear(x, pack: LinearPack, A=None, B=None, scale: float = 1.0, act: Optional[str] = None, residual=None):
+    return LinearFn.apply(x, A, B, residual, pack, scale, act)
+
+
+# ---------------------------------------------------------------------------------
+# 1-D convolutions as tap-GEMMs (frozen weights, no LoRA)
+# ---------------------------------------------------------------------------------
+class ConvPack:
+    """Conv1d(k in {1,3}, stride in {1,2}, pad (k-1)/2) or ConvTranspose1d(k4,s2,p1), channel-last.
+    Holds tap-major packed weights for forward and for the input-gradient pass."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype, stride: int = 1,
+                 transposed: bool = False):
+        w = weight.detach().float()
+        self.transposed, self.stride = transposed, stride
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+        if not transposed:
+            self.N, self.Cin, self.k = w.shape                     # [Cout][Cin][k]
+            assert self.k in (1, 3) and stride in (1, 2)
+            self.Wf = w.permute(0, 2, 1).reshape(self.N, self.k * self.Cin).to(dtype).contiguous()
+            if stride == 1:
+                # dx[t] = sum_j dy[t + j - pad] . w[:, :, k-1-j]
+                self.Wb = [w.flip(2).permute(1, 2, 0).reshape(self.Cin, self.k * self.N).to(dtype).contiguous()]
+            else:
+                assert self.k == 3
+                # even rows 2m: dy[m].w1 ; odd rows 2m+1: dy[m].w2 + dy[m+1].w0
+                self.Wb = [w[:, :, 1].t().to(dtype).contiguous(),
+                           torch.cat([w[:, :, 2].t(), w[:, :, 0].t()], dim=1).to(dtype).contiguous()]
+        else:
+            self.Cin, self.N, self.k = w.shape                     # [Cin][Cout][4]
+            assert self.k == 4 and stride == 2
+            # even out 2m: x[m].w1 + x[m-1].w3 ; odd out 2m+1: x[m+1].w0 + x[m].w2
+            self.Wf = [torch.cat([w[:, :, 1].t(), w[:, :, 3].t()], dim=1).to(dtype).contiguous(),
+                       torch.cat([w[:, :, 0].t(), w[:, :, 2].t()], dim=1).to(dtype).contiguous()]
+            # dx[t] = sum_j dy[2t - 1 + j] . w[:, :, j]^T
+            self.Wb = [w.permute(0, 2, 1).reshape(self.Cin, 4 * self.N).to(dtype).contiguous()]
+
+    def out_len(self, Tin: int) -> int:
+        if self.transposed:
+            return 2 * Tin
+        return Tin if self.stride == 1 else (Tin - 1) // 2 + 1
+
+
+class ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, pack: ConvPack, B: int, Tin: int, Tout: int, in_len, out_len):
+        x = _c(x)
+        pad = (pack.k - 1) // 2
+        if not pack.transposed:
+            taps = tuple(range(-pad, pad + 1))
+            geo = Geo(Tm=Tout, Tin=Tin, Tout=Tout, in_stride=pack.stride, taps=taps)
+            y = gemm(x, pack.Wf, bias=pack.bias, geo=geo, nb=B, in_len=in_len, out_len=out_len,
+                     residual=None if residual is None else _c(residual))
+        else:
+            assert residual is None
+            y = torch.empty((B * Tout, pack.N), dtype=x.dtype, device=x.device)
+            gemm(x, pack.Wf[0], bias=pack.bias, geo=Geo(Tm=Tin, Tin=Tin, Tout=Tout, out_stride=2, out_off=0, taps=(0, -1)),
+                 nb=B, in_len=in_len, out_len=out_len, out=y)
+            gemm(x, pack.Wf[1], bias=pack.bias, geo=Geo(Tm=Tin, Tin=Tin, Tout=Tout, out_stride=2, out_off=1, taps=(1, 0)),
+                 nb=B, in_len=in_len, out_len=out_len, out=y)
+        ctx.pack, ctx.B, ctx.Tin, ctx.Tout = pack, B, Tin, Tout
+        ctx.in_len, ctx.out_len = in_len, out_len
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pack, B, Tin, Tout = ctx.pack, ctx.B, ctx.Tin, ctx.Tout
+        dy = _c(dy)
+        if not ctx.needs_input_grad[0]:
+            return None, (dy if ctx.needs_input_grad[1] else None), None, None, None, None, None, None
+        # forward's output mask zeroes dy rows >= out_len; forward's input mask zeroes dx rows >= in_len
+        kw = dict(nb=B, in_len=ctx.out_len, out_len=ctx.in_len)
+        if not pack.transposed and pack.stride == 1:
+            pad = (pack.k - 1) // 2
+            dx = gemm(dy, pack.Wb[0], geo=Geo(Tm=Tin, Tin=Tout, Tout=Tin, taps=tuple(range(-pad, pad + 1))), **kw)
+        elif not pack.transposed:
+            dx = torch.empty((B * Tin, pack.Cin), dtype=dy.dtype, device=dy.device)
+            gemm(dy, pack.Wb[0], geo=Geo(Tm=(Tin + 1) // 2, Tin=Tout, Tout=Tin, out_stride=2, out_off=0, taps=(0,)), out=dx, **kw)
+            if Tin // 2 > 0:
+                gemm(dy, pack.Wb[1], geo=Geo(Tm=Tin // 2, Tin=Tout, Tout=Tin, out_stride=2, out_off=1, taps=(0, 1)), out=dx, **kw)
+        else:
+            dx = gemm(dy, pack.Wb[0], geo=Geo(Tm=Tin, Tin=Tout, Tout=Tin, in_stride=2, taps=(-1, 0, 1, 2)), **kw)
+        # residual is added after the output mask only when out_len is None (the only use: ResnetBlock1D)
+        dres = dy if ctx.needs_input_grad[1] else None
+        return dx, dres, None, None, None, None, None, None
+
+
+def conv1d(x, pack: ConvPack, B: int, Tin: int, Tout: Optional[int] = None, in_len=None, out_len=None, residual=None):
+    """x [B*Tin, Cin] -> [B*Tout, Cout]; in_len masks input frames (x*mask), out_len zeroes output frames;
+    `residual` [B*Tout, Cout] is added in the GEMM epilogue (stride-1 convs, no out_len)."""
+    Tout = pack.out_len(Tin) if Tout is None else Tout
+    assert residual is None or out_len is None
+    return ConvFn.apply(x, residual, pack, B, Tin, Tout, in_len, out_len)
+
+
+# ---------------------------------------------------------------------------------
+# normalisation
+# ---------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float, relu: bool, post_scale: float):
+        x = _c(x)
+        rows, Cn = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib().cvft_layernorm_fwd(dt(x), rows, Cn, ptr(x), ptr(gamma), ptr(beta), eps, int(relu), post_scale,
+                                       ptr(y), ptr(mean), ptr(rstd), stream()), "cvft_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.relu, ctx.post = relu, post_scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        check(lib().cvft_layernorm_bwd(dt(x), x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                       int(ctx.relu), ctx.post, ptr(dy), ptr(dx), stream()), "cvft_layernorm_bwd")
+        return dx, None, None, None, None, None
+
+
+def layernorm(x, gamma, beta, eps: float = 1e-5, relu: bool = False, post_scale: float = 1.0):
+    return LayerNormFn.apply(x, gamma, beta, eps, relu, post_scale)
+
+
+class GroupNormMishFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, B: int, T: int, G: int, eps: float, length, add, mish: bool):
+        x = _c(x)
+        Cn = x.shape[1]
+        assert x.shape[0] == B * T
+        y = torch.empty_like(x)
+        mean = torch.empty(B * G, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(B * G, dtype=torch.float32, device=x.device)
+        check(lib().cvft_groupnorm_mish_fwd(dt(x), B, T, Cn, G, ptr(x), ptr(gamma), ptr(beta), eps, ptr(length),
+                                            ptr(None if add is None else _c(add)), int(mish), ptr(y), ptr(mean),
+                                            ptr(rstd), stream()), "cvft_groupnorm_mish_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.dims, ctx.length, ctx.mish = (B, T, Cn, G), length, mish
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        B, T, Cn, G = ctx.dims
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        ws = torch.empty(B * G * 2, dtype=torch.float32, device=x.device)
+        check(lib().cvft_groupnorm_mish_bwd(dt(x), B, T, Cn, G, ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                            ptr(ctx.length), int(ctx.mish), ptr(dy), ptr(dx), ptr(ws), stream()),
+              "cvft_groupnorm_mish_bwd")
+        return dx, None, None, None, None, None, None, None, None, None
+
+
+def groupnorm_mish(x, gamma, beta, B: int, T: int, G: int, eps: float = 1e-5, length=None, add=None, mish: bool = True):
+    """x [B*T, C] channel-last; y = mish(GN(x)) * (t < length[b]) + add[b]  (add carries no gradient)."""
+    return GroupNormMishFn.apply(x, gamma, beta, B, T, G, eps, length, add, mish)
+
+
+# ---------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------
+class AttnBiasFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, B: int, H: int, T: int, klen, scale: float):
+        assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+        assert q.stride(0) == k.stride(0) == v.stride(0)
+        o = torch.empty((B * T, H * 64), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+        check(lib().cvft_attn_bias_fwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, ptr(o),
+                                       o.stride(0), ptr(lse), stream()), "cvft_attn_bias_fwd")
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.args = (B, H, T, klen, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        B, H, T, klen, scale = ctx.args
+        do = _c(do)
+        dqkv = torch.empty((B * T, 3 * H * 64), dtype=q.dtype, device=q.device)
+        dq, dk, dv = dqkv[:, :H * 64], dqkv[:, H * 64:2 * H * 64], dqkv[:, 2 * H * 64:]
+        delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+        check(lib().cvft_attn_bias_bwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, ptr(o),
+                                       ptr(do), o.stride(0), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                       dqkv.stride(0), stream()), "cvft_attn_bias_bwd")
+        return dq, dk, dv, None, None, None, None, None
+
+
+def attn_bias(q, k, v, B: int, H: int, T: int, klen, scale: float):
+    return AttnBiasFn.apply(q, k, v, B, H, T, klen, scale)
+
+
+class AttnRelPosFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, p, bias_u, bias_v, B: int, H: int, L: int, length, causal: bool, scale: float):
+        assert q.stride(1) == 1 and q.stride(0) == k.stride(0) == v.stride(0)
+        assert p.shape[0] == 2 * L - 1 and p.stride(1) == 1
+        o = torch.empty((B * L, H * 64), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+        check(lib().cvft_attn_relpos_fwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
+                                         ptr(bias_u), ptr(bias_v), ptr(length), int(causal), scale, ptr(o), o.stride(0),
+                                         ptr(lse), stream()), "cvft_attn_relpos_fwd")
+        ctx.save_for_backward(q, k, v, p, bias_u, bias_v, o, lse)
+        ctx.args = (B, H, L, length, causal, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, p, bu, bv, o, lse = ctx.saved_tensors
+        B, H, L, length, causal, scale = ctx.args
+        if ctx.needs_input_grad[3]:
+            raise cb.CvftError("gradient w.r.t. the projected positional encoding (LoRA on linear_pos) is not implemented")
+        do = _c(do)
+        dqkv = torch.empty((B * L, 3 * H * 64), dtype=q.dtype, device=q.device)
+        dq, dk, dv = dqkv[:, :H * 64], dqkv[:, H * 64:2 * H * 64], dqkv[:, 2 * H * 64:]
+        delta = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+        check(lib().cvft_attn_relpos_bwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
+                                         ptr(bu), ptr(bv), ptr(length), int(causal), scale, ptr(o), ptr(do), o.stride(0),
+                                         ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), None, stream()),
+              "cvft_attn_relpos_bwd")
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None
+
+
+def attn_relpos(q, k, v, p, bias_u, bias_v, B: int, H: int, L: int, length, causal: bool, scale: float):
+    return AttnRelPosFn.apply(q, k, v, p, bias_u, bias_v, B, H, L, length, causal, scale)
+
+
+# ---------------------------------------------------------------------------------
+# gathers, interpolation
+# ---------------------------------------------------------------------------------
+def embed_gather(tok: torch.Tensor, table: torch.Tensor, length: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[B, L] int64 -> [B*L, D]; rows l >= length[b] are zero; negative ids clamp to 0. No gradient (frozen table)."""
+    B, L = tok.shape
+    out = torch.empty((B * L, table.shape[1]), dtype=table.dtype, device=table.device)
+    check(lib().cvft_embed_gather(dt(table), B, L, table.shape[1], ptr(_c(tok)), ptr(length), ptr(table), ptr(out), stream()),
+          "cvft_embed_gather")
+    return out
+
+
+class GatherRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx, fill: float):
+        src = _c(src)
+        n, D = idx.numel(), src.shape[1]
+        out = torch.empty((n, D), dtype=src.dtype, device=src.device)
+        check(lib().cvft_gather_rows(dt(src), n, D, ptr(idx), ptr(src), fill, ptr(out), stream()), "cvft_gather_rows")
+        ctx.save_for_backward(idx)
+        ctx.src_rows = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dout = _c(dout)
+        dsrc = torch.zeros((ctx.src_rows, dout.shape[1]), dtype=dout.dtype, device=dout.device)
+        check(lib().cvft_scatter_rows(dt(dout), idx.numel(), dout.shape[1], ptr(idx), ptr(dout), ptr(dsrc), stream()),
+              "cvft_scatter_rows")
+        return dsrc, None, None
+
+
+def gather_rows(src, idx: torch.Tensor, fill: float = 0.0):
+    """out[i] = src[idx[i]] (idx >= 0) else `fill`; each source row may be referenced at most once."""
+    return GatherRowsFn.apply(src, idx, fill)
+
+
+class InterpLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, B: int, Lin: int, Lout: int):
+        x = _c(x)
+        Cn = x.shape[1]
+        y = torch.empty((B * Lout, Cn), dtype=x.dtype, device=x.device)
+        check(lib().cvft_interp_linear_fwd(dt(x), B, Lin, Lout, Cn, ptr(x), ptr(y), stream()), "cvft_interp_linear_fwd")
+        ctx.dims = (B, Lin, Lout, Cn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Lin, Lout, Cn = ctx.dims
+        dy = _c(dy)
+        dx = torch.empty((B * Lin, Cn), dtype=dy.dtype, device=dy.device)
+        check(lib().cvft_interp_linear_bwd(dt(dy), B, Lin, Lout, Cn, ptr(dy), ptr(dx), stream()), "cvft_interp_linear_bwd")
+        return dx, None, None, None
+
+
+def interp_linear(x, B: int, Lin: int, Lout: int):
+    return InterpLinearFn.apply(x, B, Lin, Lout)
+
+
+def l2norm_rows(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    x = _c(x.float())
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib().cvft_l2norm_rows(cb.F32 if dtype == torch.float32 else cb.BF16, x.shape[0], x.shape[1], ptr(x), ptr(y),
+                                 stream()), "cvft_l2norm_rows")
+    return y
+
+
+def time_embed(t: torch.Tensor, freqs: torch.Tensor, dtype: torch.dtype, scale: float = 1000.0) -> torch.Tensor:
+    B, dim = t.numel(), 2 * freqs.numel()
+    out = torch.empty((B, dim), dtype=dtype, device=t.device)
+    check(lib().cvft_time_embed(cb.F32 if dtype == torch.float32 else cb.BF16, B, dim, ptr(_c(t.float())), ptr(freqs),
+                                scale, ptr(out), stream()), "cvft_time_embed")
+    return out
+
+
+# ---------------------------------------------------------------------------------
+# CFM prepare + losses
+# ---------------------------------------------------------------------------------
+class CfmPrepareFn(torch.autograd.Function):
+    """feat/z/t_raw/keep -> packed estimator input [B*T, 320] = [y | mu*keep | spk*keep | 0], target u, t.
+    Gradient flows to mu only (dmu = dxin[:, 80:160] * keep)."""
+
+    @staticmethod
+    def forward(ctx, mu, spk, feat, z, t_raw, keep, B: int, T: int, mel_mean: float, mel_std: float, sigma_min: float):
+        mu = _c(mu)
+        xin = torch.empty((B * T, 320), dtype=mu.dtype, device=mu.device)
+        u = torch.empty((B * T, 80), dtype=torch.float32, device=mu.device)
+        t = torch.empty(B, dtype=torch.float32, device=mu.device)
+        check(lib().cvft_cfm_prepare(dt(mu), B, T, ptr(_c(feat)), ptr(_c(z)), ptr(_c(t_raw)), ptr(_c(keep)), ptr(mu),
+                                     ptr(_c(spk)), mel_mean, mel_std, sigma_min, ptr(xin), ptr(u), ptr(t), stream()),
+              "cvft_cfm_prepare")
+        ctx.save_for_backward(keep)
+        ctx.dims = (B, T)
+        ctx.mark_non_differentiable(u, t)
+        return xin, u, t
+
+    @staticmethod
+    def backward(ctx, dxin, du, dt_):
+        (keep,) = ctx.saved_tensors
+        B, T = ctx.dims
+        dmu = (dxin[:, 80:160].reshape(B, T, 80) * keep.view(B, 1, 1).to(dxin.dtype)).reshape(B * T, 80)
+        return dmu, None, None, None, None, None, None, None, None, None, None
+
+
+def cfm_prepare(mu, spk, feat, z, t_raw, keep, B: int, T: int, mel_mean: float, mel_std: float, sigma_min: float):
+    return CfmPrepareFn.apply(mu, spk, feat, z, t_raw, keep, B, T, mel_mean, mel_std, sigma_min)
+
+
+class MaskedMseFn(torch.autograd.Function):
+    """sum(((pred-u)*mask)^2) / denom   (reference flow_matching.py:192), denom a device scalar."""
+
+    @staticmethod
+    def forward(ctx, pred, u, length, denom, B: int, T: int):
+        pred = _c(pred)
+        Cn = pred.shape[1]
+        s = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        check(lib().cvft_masked_mse_fwd(dt(pred), B, T, Cn, ptr(pred), ptr(u), ptr(length), ptr(s), stream()),
+              "cvft_masked_mse_fwd")
+        ctx.save_for_backward(pred, u, length, denom)
+        ctx.dims = (B, T, Cn)
+        return (s / denom).squeeze(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, u, length, denom = ctx.saved_tensors
+        B, T, Cn = ctx.dims
+        gs = (g.float() / denom).reshape(1).contiguous()
+        dpred = torch.empty_like(pred)
+        check(lib().cvft_masked_mse_bwd(dt(pred), B, T, Cn, ptr(pred), ptr(u), ptr(length), ptr(gs), ptr(dpred), stream()),
+              "cvft_masked_mse_bwd")
+        return dpred, None, None, None, None, None
+
+
+def masked_mse(pred, u, length, denom, B: int, T: int):
+    return MaskedMseFn.apply(pred, u, length, denom, B, T)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """Token-mean CE with ignore index -1 (label_smoothing_loss.py:68-96, smoothing 0) + accuracy."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits = _c(logits)
+        n, V = logits.shape
+        out3 = torch.zeros(3, dtype=torch.float32, device=logits.device)
+        row_lse = torch.empty(n, dtype=torch.float32, device=logits.device)
+        check(lib().cvft_ce_fwd(dt(logits), n, V, ptr(logits), logits.stride(0), ptr(target), ptr(out3), ptr(row_lse),
+                                stream()), "cvft_ce_fwd")
+        ctx.save_for_backward(logits, target, row_lse, out3)
+        loss = out3[0] / out3[1]
+        acc = out3[2] / out3[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, g, gacc):
+        logits, target, row_lse, out3 = ctx.saved_tensors
+        n, V = logits.shape
+        gs = (g.float() / out3[1]).reshape(1).contiguous()
+        dl = torch.empty_like(logits)
+        check(lib().cvft_ce_bwd(dt(logits), n, V, ptr(logits), logits.stride(0), ptr(target), ptr(row_lse), ptr(gs),
+                                ptr(dl), dl.stride(0), stream()), "cvft_ce_bwd")
+        return dl, None
+
+
+def cross_entropy(logits, target):
+    """logits [n, V]; target [n] int32 (-1 = ignore) -> (loss, accuracy)."""
+    return CrossEntropyFn.apply(logits, target)
+
+
+# ---------------------------------------------------------------------------------
+# depthwise conv (Conformer ConvolutionModule; not executed by the 300M config)
+# ---------------------------------------------------------------------------------
+class DwConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, B: int, T: int, pad_left: int, length):
+        x = _c(x)
+        Cn, Kw = w.shape
+        y = torch.empty_like(x)
+        check(lib().cvft_dwconv1d_fwd(dt(x), B, T, Cn, Kw, pad_left, ptr(x), ptr(w), ptr(bias), ptr(length), ptr(y), stream()),
+              "cvft_dwconv1d_fwd")
+        ctx.save_for_backward(w)
+        ctx.args = (B, T, pad_left, length)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        B, T, pad_left, length = ctx.args
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib().cvft_dwconv1d_bwd(dt(dy), B, T, w.shape[0], w.shape[1], pad_left, ptr(dy), ptr(w), ptr(length), ptr(dx),
+                                      stream()), "cvft_dwconv1d_bwd")
+        return dx, None, None, None, None, None, None
+
+
+def dwconv1d(x, w, bias, B: int, T: int, pad_left: int, length=None):
+    """x [B*T, C] channel-last, w [C, Kw] fp32; input frames t >= length[b] are treated as zero."""
+    return DwConvFn.apply(x, w, bias, B, T, pad_left, length)

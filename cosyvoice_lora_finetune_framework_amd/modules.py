@@ -1,0 +1,582 @@
+"""HIP-backed building blocks with the reference's module tree / state-dict keys.
+
+Leaf modules are ordinary ``nn.Linear`` / ``nn.Conv1d`` / ``nn.LayerNorm`` / ``nn.GroupNorm`` /
+``nn.Embedding`` objects (so ``state_dict()`` keys, ``lora.apply_lora_to_model`` name matching
+and ``load_state_dict(strict=True)`` behave exactly like the reference's modules.py /
+cosyvoice.transformer.*), but they are used as *parameter containers only*: every forward in
+this file runs hand-written gfx950 kernels through ``hipops.functional`` on channel-last
+``[batch*time, channels]`` activations.  Lengths travel as int32 device tensors -- no
+(B,T,T) mask / bias tensors and no host syncs inside a step.
+
+Reference mapping: modules.py:20-1106 (self-contained twin) == cosyvoice/flow/decoder.py,
+matcha/models/components/{decoder,transformer}.py (vendored); cosyvoice/transformer/
+{encoder,encoder_layer,attention,embedding,subsampling,positionwise_feed_forward}.py.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .hipops import functional as HF
+from .lora import LoRAConv1d, LoRALinear
+
+
+@dataclass
+class Numerics:
+    """Numerics switches.  Defaults = the vendored path train_joint.py runs."""
+    dtype: torch.dtype = torch.float32     # activation / frozen-weight storage + MFMA input type
+    gelu: str = "gelu_erf"                 # diffusers GELU (erf); twin modules.GELU uses "gelu_tanh"
+    xscale: bool = True                    # x*sqrt(d) in EspnetRelPositionalEncoding (twin omits it)
+    enc_ln_eps: float = 1e-12              # encoder-layer LayerNorm eps (twin: 1e-5)
+
+    @staticmethod
+    def twin(dtype=torch.float32) -> "Numerics":
+        return Numerics(dtype=dtype, gelu="gelu_tanh", xscale=False, enc_ln_eps=1e-5)
+
+
+# ---------------------------------------------------------------------------------
+# weight packs cached on the parameter-container modules
+# ---------------------------------------------------------------------------------
+def _cached(mod: nn.Module, key: str, weight: torch.Tensor, dtype, build):
+    tag = (dtype, weight._version, weight.data_ptr())
+    cache = mod.__dict__.setdefault("_cvft_cache", {})
+    hit = cache.get(key)
+    if hit is None or hit[0] != tag:
+        hit = (tag, build())
+        cache[key] = hit
+    return hit[1]
+
+
+def _lin_parts(mod: nn.Module):
+    """(weight 2-D, bias, A, B, scale, dropout) of nn.Linear / LoRALinear / 1x1 Conv1d / LoRAConv1d."""
+    A = Bm = drop = None
+    scale = 1.0
+    base = mod
+    if isinstance(mod, LoRALinear):
+        base, A, Bm, scale, drop = mod.original_layer, mod.lora_A, mod.lora_B, mod.scaling, mod.lora_dropout
+    elif isinstance(mod, LoRAConv1d):
+        base, scale, drop = mod.original_layer, mod.scaling, mod.lora_dropout
+        A, Bm = mod.lora_A.weight.squeeze(-1), mod.lora_B.weight.squeeze(-1)
+    w = base.weight
+    if w.dim() == 3:
+        assert w.shape[-1] == 1
+        w = w.squeeze(-1)
+    return base, w, base.bias, A, Bm, scale, drop
+
+
+def hip_linear(mod: nn.Module, x: torch.Tensor, dtype: Optional[torch.dtype] = None, act: Optional[str] = None,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [rows, in] -> [rows, out] through the fused LoRA tap-GEMM.  `mod` is an nn.Linear,
+    a 1x1 nn.Conv1d, or their LoRA wrappers."""
+    dtype = x.dtype if dtype is None else dtype
+    base, w, b, A, Bm, scale, drop = _lin_parts(mod)
+    pack = _cached(base, "lin", base.weight, dtype, lambda: HF.LinearPack(w, b, dtype))
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    if A is not None and mod.training and isinstance(drop, nn.Dropout) and drop.p > 0:
+        # reference lora.py:70: dropout on the side-path input only
+        return _lora_dropout_path(x, pack, A, Bm, scale, drop, act, residual)
+    return HF.lora_linear(x, pack, A, Bm, scale, act, residual)
+
+
+def _lora_dropout_path(x, pack, A, Bm, scale, drop, act, residual):
+    # y = act(x W^T + b + s * (drop(x) A^T) B^T): main GEMM without side path + separate rank-r GEMMs
+    assert act is None, "LoRA dropout with a fused activation is not supported"
+    y = HF.lora_linear(x, pack, None, None, 1.0, None, residual)
+    xd = drop(x)
+    zero_pack = _ZeroPack.get(pack.N, pack.K, x.dtype, x.device)
+    return HF.lora_linear(xd, zero_pack, A, Bm, scale, None, y)
+
+
+class _ZeroPack:
+    _cache = {}
+
+    @staticmethod
+    def get(N, K, dtype, device):
+        key = (N, K, dtype, str(device))
+        if key not in _ZeroPack._cache:
+            _ZeroPack._cache[key] = HF.LinearPack(torch.zeros(N, K, device=device), None, dtype)
+        return _ZeroPack._cache[key]
+
+
+def conv_pack(mod: nn.Module, dtype) -> HF.ConvPack:
+    transposed = isinstance(mod, nn.ConvTranspose1d)
+    return _cached(mod, "conv", mod.weight, dtype,
+                   lambda: HF.ConvPack(mod.weight, mod.bias, dtype, stride=mod.stride[0], transposed=transposed))
+
+
+def _f32(p: torch.Tensor) -> torch.Tensor:
+    return p.detach() if p.dtype == torch.float32 else p.detach().float()
+
+
+def hip_layernorm(ln: nn.LayerNorm, x, eps: Optional[float] = None, relu=False, post_scale=1.0):
+    return HF.layernorm(x, _f32(ln.weight), _f32(ln.bias), ln.eps if eps is None else eps, relu, post_scale)
+
+
+def to_len(lens: torch.Tensor, device) -> torch.Tensor:
+    return lens.to(device=device, dtype=torch.int32).contiguous()
+
+
+# =================================================================================
+# U-Net1D estimator bricks (matcha decoder.py:14-158 == modules.py:20-120)
+# =================================================================================
+class SinusoidalPosEmb(nn.Module):
+    """modules.py:20-42; the constant frequency table is built on the host with the reference's
+    exact torch ops, the sin/cos of scale*t*f runs in the HIP time-embed kernel."""
+
+    def __init__(self, dim):
+        super().__init__()
+        assert dim % 2 == 0
+        self.dim = dim
+        half = dim // 2
+        self._freqs_cpu = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1)))
+        self._freqs_dev = None
+
+    def freqs(self, device):
+        if self._freqs_dev is None or self._freqs_dev.device != device:
+            self._freqs_dev = self._freqs_cpu.to(device)
+        return self._freqs_dev
+
+    def forward(self, t, scale=1000, dtype=torch.float32):
+        if t.ndim < 1:
+            t = t.unsqueeze(0)
+        return HF.time_embed(t, self.freqs(t.device), dtype, float(scale))
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act_name = "silu" if act_fn == "silu" else "mish"
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, sample):
+        return hip_linear(self.linear_2, hip_linear(self.linear_1, sample, act=self.act_name))
+
+
+class Block1D(nn.Module):
+    """Conv1d(k3,p1) + GroupNorm(groups) + Mish with mask before/after (modules.py:60-73).
+    Channel-last: x [B*T, C]; `length` int32 [B]; optional per-(b,c) additive term fused after the mask."""
+
+    def __init__(self, dim, dim_out, groups=8):
+        super().__init__()
+        self.block = nn.Sequential(nn.Conv1d(dim, dim_out, 3, padding=1), nn.GroupNorm(groups, dim_out), nn.Mish())
+
+    def forward(self, x, B, T, length, add=None):
+        conv, gn = self.block[0], self.block[1]
+        h = HF.conv1d(x, conv_pack(conv, x.dtype), B, T, in_len=length)
+        return HF.groupnorm_mish(h, _f32(gn.weight), _f32(gn.bias), B, T, gn.num_groups, gn.eps, length, add, True)
+
+
+class ResnetBlock1D(nn.Module):
+    """modules.py:76-94."""
+
+    def __init__(self, dim, dim_out, time_emb_dim, groups=8):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Mish(), nn.Linear(time_emb_dim, dim_out))
+        self.block1 = Block1D(dim, dim_out, groups=groups)
+        self.block2 = Block1D(dim_out, dim_out, groups=groups)
+        self.res_conv = nn.Conv1d(dim, dim_out, 1)
+
+    def forward(self, x, B, T, length, temb_mish):
+        with torch.no_grad():
+            add = hip_linear(self.mlp[1], temb_mish)                       # [B, dim_out]; depends on t only
+        h = self.block1(x, B, T, length, add=add)
+        h = self.block2(h, B, T, length)
+        # h + res_conv(x * mask): 1x1 conv == tap-GEMM with the input-length mask, residual fused
+        return HF.conv1d(x, conv_pack(self.res_conv, x.dtype), B, T, in_len=length, residual=h)
+
+
+class Downsample1D(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.conv = nn.Conv1d(dim, dim, 3, 2, 1)
+
+
+class Upsample1D(nn.Module):
+    def __init__(self, dim, use_conv_transpose=True):
+        super().__init__()
+        assert use_conv_transpose
+        self.conv = nn.ConvTranspose1d(dim, dim, 4, 2, 1)
+
+
+# ---- diffusers-style transformer block (modules.py:127-375) ----------------------
+class GELU(nn.Module):
+    def __init__(self, dim_in, dim_out, approximate="none"):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out)
+        self.approximate = approximate
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="gelu"):
+        super().__init__()
+        if activation_fn not in ("gelu", "gelu-approximate"):
+            raise NotImplementedError(f"activation_fn={activation_fn!r}: only the CosyVoice-300M 'gelu' estimator is built")
+        inner = int(dim * mult)
+        self.net = nn.ModuleList([GELU(dim, inner, "tanh" if activation_fn == "gelu-approximate" else "none"),
+                                  nn.Dropout(dropout), nn.Linear(inner, dim_out or dim)])
+
+
+class Attention(nn.Module):
+    def __init__(self, query_dim, heads=8, dim_head=64, dropout=0.0, bias=False):
+        super().__init__()
+        if dim_head != 64:
+            raise NotImplementedError("fused attention kernels are specialised to head_dim 64")
+        inner = dim_head * heads
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(query_dim, inner, bias=bias)
+        self.to_v = nn.Linear(query_dim, inner, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+
+
+class BasicTransformerBlock(nn.Module):
+    """x += Attn(LN(x), key-padding bias) ; x += W2 GELU(W1 LN(x))   (modules.py:349-375)."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim, dropout=0.0, activation_fn="gelu"):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, num_attention_heads, attention_head_dim, dropout)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
+
+    def forward(self, x, B, T, length, gelu: str):
+        a = self.attn1
+        y = hip_layernorm(self.norm1, x)
+        q, k, v = hip_linear(a.to_q, y), hip_linear(a.to_k, y), hip_linear(a.to_v, y)
+        o = HF.attn_bias(q, k, v, B, a.heads, T, length, a.scale)
+        x = hip_linear(a.to_out[0], o, residual=x)
+        y = hip_layernorm(self.norm3, x)
+        act = "gelu_tanh" if self.ff.net[0].approximate == "tanh" else gelu
+        h = hip_linear(self.ff.net[0].proj, y, act=act)
+        return hip_linear(self.ff.net[2], h, residual=x)
+
+
+class ConditionalDecoder(nn.Module):
+    """U-Net1D flow-matching estimator (cosyvoice/flow/decoder.py:88-291 == modules.py:886-1106,
+    prompt isolation off).  Channel-last fast path: ``forward_cl``; ``forward`` keeps the
+    reference's (B,C,T) signature."""
+
+    def __init__(self, in_channels, out_channels, channels=(256, 256), dropout=0.05, attention_head_dim=64,
+                 n_blocks=1, num_mid_blocks=2, num_heads=4, act_fn="gelu"):
+        super().__init__()
+        channels = tuple(channels)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.prompt_isolation_enabled = False
+        self.prompt_isolation_len = 0
+        self.time_embeddings = SinusoidalPosEmb(in_channels)
+        ted = channels[0] * 4
+        self.time_mlp = TimestepEmbedding(in_channels, ted, act_fn="silu")
+        self.down_blocks, self.mid_blocks, self.up_blocks = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+
+        def tbs(ch):
+            return nn.ModuleList([BasicTransformerBlock(ch, num_heads, attention_head_dim, dropout, act_fn)
+                                  for _ in range(n_blocks)])
+        oc = in_channels
+        for i, ch in enumerate(channels):
+            ic, oc = oc, ch
+            last = i == len(channels) - 1
+            self.down_blocks.append(nn.ModuleList([ResnetBlock1D(ic, oc, ted), tbs(oc),
+                                                   Downsample1D(oc) if not last else nn.Conv1d(oc, oc, 3, padding=1)]))
+        for _ in range(num_mid_blocks):
+            self.mid_blocks.append(nn.ModuleList([ResnetBlock1D(channels[-1], channels[-1], ted), tbs(channels[-1])]))
+        ch2 = channels[::-1] + (channels[0],)
+        for i in range(len(ch2) - 1):
+            ic, oc = ch2[i] * 2, ch2[i + 1]
+            last = i == len(ch2) - 2
+            self.up_blocks.append(nn.ModuleList([ResnetBlock1D(ic, oc, ted), tbs(oc),
+                                                 Upsample1D(oc) if not last else nn.Conv1d(oc, oc, 3, padding=1)]))
+        self.final_block = Block1D(ch2[-1], ch2[-1])
+        self.final_proj = nn.Conv1d(ch2[-1], out_channels, 1)
+        self._initialize_weights()
+
+    def _initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv1d, nn.Linear)):
+                nn.init.kaiming_normal_(m.weight, nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.GroupNorm):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward_cl(self, xin, t, B: int, T: int, length, gelu: str = "gelu_erf"):
+        """xin [B*T, in_channels] (already [y|mu|spk|cond] packed), t [B] fp32, length int32 [B]
+        -> [B*T, out_channels] (masked)."""
+        if self.prompt_isolation_len:
+            raise NotImplementedError("prompt-isolation attention mask (SURVEY 8f rank 4) is not built yet")
+        dtype = xin.dtype
+        with torch.no_grad():
+            temb = self.time_mlp(self.time_embeddings(t, dtype=dtype))
+            temb_mish = HF.act_fwd(temb, "mish")
+        x = xin
+        hiddens: List[Tuple[torch.Tensor, int, torch.Tensor]] = []
+        Tc, lc = T, length
+        for resnet, tblocks, down in self.down_blocks:
+            x = resnet(x, B, Tc, lc, temb_mish)
+            for tb in tblocks:
+                x = tb(x, B, Tc, lc, gelu)
+            hiddens.append((x, Tc, lc))
+            if isinstance(down, Downsample1D):
+                pk = conv_pack(down.conv, dtype)
+                Tn = pk.out_len(Tc)
+                x = HF.conv1d(x, pk, B, Tc, Tn, in_len=lc)
+                Tc, lc = Tn, (lc + 1) // 2          # mask[:, :, ::2]
+            else:
+                x = HF.conv1d(x, conv_pack(down, dtype), B, Tc, in_len=lc)
+                # reference appends mask_down[:, :, ::2] then drops it (masks = masks[:-1])
+        for resnet, tblocks in self.mid_blocks:
+            x = resnet(x, B, Tc, lc, temb_mish)
+            for tb in tblocks:
+                x = tb(x, B, Tc, lc, gelu)
+        for resnet, tblocks, up in self.up_blocks:
+            skip, Ts, ls = hiddens.pop()
+            assert Ts == Tc, (Ts, Tc)
+            x = torch.cat([x, skip], dim=1)
+            x = resnet(x, B, Ts, ls, temb_mish)
+            for tb in tblocks:
+                x = tb(x, B, Ts, ls, gelu)
+            if isinstance(up, Upsample1D):
+                Tn = hiddens[-1][1]                 # cropped to the next skip's length
+                x = HF.conv1d(x, conv_pack(up.conv, dtype), B, Ts, Tn, in_len=ls)
+                Tc, lc = Tn, hiddens[-1][2]
+            else:
+                x = HF.conv1d(x, conv_pack(up, dtype), B, Ts, in_len=ls)
+                Tc, lc = Ts, ls
+        x = self.final_block(x, B, Tc, lc)
+        return HF.conv1d(x, conv_pack(self.final_proj, dtype), B, Tc, in_len=lc, out_len=lc)
+
+    def forward(self, x, mask, mu, t, spks=None, cond=None, dtype: Optional[torch.dtype] = None, gelu="gelu_erf"):
+        """Reference signature: x,mu,cond (B,80,T); mask (B,1,T); t (B,); spks (B,80) -> (B,80,T)."""
+        B, _, T = x.shape
+        dtype = x.dtype if dtype is None else dtype
+        parts = [x, mu]
+        if spks is not None:
+            parts.append(spks.unsqueeze(-1).expand(-1, -1, T))
+        if cond is not None:
+            parts.append(cond)
+        xin = torch.cat(parts, dim=1).transpose(1, 2).reshape(B * T, -1).to(dtype).contiguous()
+        length = mask.reshape(B, T).sum(dim=1).to(torch.int32)
+        out = self.forward_cl(xin, t.reshape(-1).float(), B, T, length, gelu)
+        return out.reshape(B, T, -1).transpose(1, 2).to(x.dtype)
+
+
+# =================================================================================
+# Encoders (cosyvoice/transformer/*; twin modules.py:382-793)
+# =================================================================================
+class EspnetRelPositionalEncoding(nn.Module):
+    """embedding.py:201-302.  The (1, 2L-1, d) sin/cos table is a host-built constant (the
+    reference builds ``self.pe`` on the CPU in __init__ as well); x*sqrt(d) is fused into the
+    preceding LayerNorm kernel as its post-scale."""
+
+    def __init__(self, d_model: int, dropout_rate: float = 0.0, max_len: int = 5000):
+        super().__init__()
+        self.d_model = d_model
+        self.xscale = math.sqrt(d_model)
+        self.dropout_rate = dropout_rate
+        self._cache = {}
+
+    def table(self, L: int, device, dtype) -> torch.Tensor:
+        key = (L, str(device), dtype)
+        if key not in self._cache:
+            d = self.d_model
+            pos = (L - 1 - torch.arange(0, 2 * L - 1, dtype=torch.float32)).unsqueeze(1)
+            div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+            pe = torch.zeros(2 * L - 1, d, dtype=torch.float32)
+            pe[:, 0::2] = torch.sin(pos * div)
+            pe[:, 1::2] = torch.cos(pos * div)
+            if len(self._cache) > 64:
+                self._cache.clear()
+            self._cache[key] = pe.to(device=device, dtype=dtype).contiguous()
+        return self._cache[key]
+
+
+class LinearNoSubsampling(nn.Module):
+    """subsampling.py:69-113 (legacy=False) / 338-383 (legacy=True: + ReLU)."""
+
+    def __init__(self, idim, odim, dropout_rate, pos_enc, legacy=False):
+        super().__init__()
+        mods = [nn.Linear(idim, odim), nn.LayerNorm(odim, eps=1e-5), nn.Dropout(dropout_rate)]
+        if legacy:
+            mods.append(nn.ReLU())
+        self.out = nn.Sequential(*mods)
+        self.pos_enc = pos_enc
+        self.legacy = legacy
+
+
+class RelPositionMultiHeadedAttention(nn.Module):
+    """attention.py:200-330 parameters; compute = fused rel-pos flash kernel."""
+
+    def __init__(self, n_head, n_feat, dropout_rate, key_bias=True):
+        super().__init__()
+        assert n_feat % n_head == 0
+        self.d_k, self.h = n_feat // n_head, n_head
+        if self.d_k != 64:
+            raise NotImplementedError("fused attention kernels are specialised to head_dim 64")
+        self.linear_q = nn.Linear(n_feat, n_feat)
+        self.linear_k = nn.Linear(n_feat, n_feat, bias=key_bias)
+        self.linear_v = nn.Linear(n_feat, n_feat)
+        self.linear_out = nn.Linear(n_feat, n_feat)
+        self.dropout_rate = dropout_rate
+        self.linear_pos = nn.Linear(n_feat, n_feat, bias=False)
+        self.pos_bias_u = nn.Parameter(torch.Tensor(self.h, self.d_k))
+        self.pos_bias_v = nn.Parameter(torch.Tensor(self.h, self.d_k))
+        nn.init.xavier_uniform_(self.pos_bias_u)
+        nn.init.xavier_uniform_(self.pos_bias_v)
+
+    def forward(self, y, residual, pos_emb, B, L, length, causal):
+        q, k, v = hip_linear(self.linear_q, y), hip_linear(self.linear_k, y), hip_linear(self.linear_v, y)
+        p = hip_linear(self.linear_pos, pos_emb)
+        o = HF.attn_relpos(q, k, v, p, _f32(self.pos_bias_u), _f32(self.pos_bias_v), B, self.h, L, length, causal,
+                           1.0 / math.sqrt(self.d_k))
+        return hip_linear(self.linear_out, o, residual=residual)
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, idim, hidden_units, dropout_rate, activation: str):
+        super().__init__()
+        self.w_1 = nn.Linear(idim, hidden_units)
+        self.activation = activation          # "relu" | "silu"
+        self.w_2 = nn.Linear(hidden_units, idim)
+
+    def forward(self, y, residual):
+        return hip_linear(self.w_2, hip_linear(self.w_1, y, act=self.activation), residual=residual)
+
+
+class EncoderLayer(nn.Module):
+    """TransformerEncoderLayer (encoder_layer.py:27-106: norm1/norm2) or ConformerEncoderLayer without
+    macaron / cnn module (encoder_layer.py:109-236: norm_mha/norm_ff), pre-norm."""
+
+    def __init__(self, size, self_attn, feed_forward, conformer: bool, eps: float):
+        super().__init__()
+        self.self_attn = self_attn
+        self.feed_forward = feed_forward
+        self.conformer = conformer
+        if conformer:
+            self.norm_ff = nn.LayerNorm(size, eps=eps)
+            self.norm_mha = nn.LayerNorm(size, eps=eps)
+        else:
+            self.norm1 = nn.LayerNorm(size, eps=eps)
+            self.norm2 = nn.LayerNorm(size, eps=eps)
+
+    def forward(self, x, pos_emb, B, L, length, causal, eps):
+        n_att, n_ff = (self.norm_mha, self.norm_ff) if self.conformer else (self.norm1, self.norm2)
+        x = self.self_attn(hip_layernorm(n_att, x, eps), x, pos_emb, B, L, length, causal)
+        return self.feed_forward(hip_layernorm(n_ff, x, eps), x)
+
+
+class RelPosEncoder(nn.Module):
+    """BaseEncoder.forward (encoder.py:111-170) for the two encoder flavours CosyVoice-300M uses:
+    ConformerEncoder(no cnn, no macaron, swish) and TransformerEncoder(relu), both with
+    rel_pos_espnet + rel_selfattn and optional static_chunk_size=1 (causal)."""
+
+    def __init__(self, input_size, output_size=256, attention_heads=4, linear_units=2048, num_blocks=6,
+                 dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.0, input_layer="linear",
+                 kind="conformer", static_chunk_size=0, key_bias=True, ln_eps=1e-12):
+        super().__init__()
+        assert kind in ("conformer", "transformer") and input_layer in ("linear", "linear_legacy")
+        self._output_size = output_size
+        self.kind, self.static_chunk_size = kind, static_chunk_size
+        pos = EspnetRelPositionalEncoding(output_size, positional_dropout_rate)
+        self.embed = LinearNoSubsampling(input_size, output_size, dropout_rate, pos, legacy=(input_layer == "linear_legacy"))
+        self.normalize_before = True
+        self.after_norm = nn.LayerNorm(output_size, eps=1e-5)
+        act = "silu" if kind == "conformer" else "relu"
+        self.encoders = nn.ModuleList([
+            EncoderLayer(output_size,
+                         RelPositionMultiHeadedAttention(attention_heads, output_size, attention_dropout_rate, key_bias),
+                         PositionwiseFeedForward(output_size, linear_units, dropout_rate, act),
+                         conformer=(kind == "conformer"), eps=ln_eps)
+            for _ in range(num_blocks)])
+
+    def output_size(self) -> int:
+        return self._output_size
+
+    def forward_cl(self, xs, B: int, L: int, length, num: Numerics, causal: Optional[bool] = None):
+        """xs [B*L, input_size] -> [B*L, d]."""
+        causal = (self.static_chunk_size > 0) if causal is None else causal
+        d = self._output_size
+        x = hip_linear(self.embed.out[0], xs, dtype=num.dtype)
+        x = hip_layernorm(self.embed.out[1], x, relu=self.embed.legacy, post_scale=math.sqrt(d) if num.xscale else 1.0)
+        pos_emb = self.embed.pos_enc.table(L, x.device, num.dtype)
+        for layer in self.encoders:
+            x = layer(x, pos_emb, B, L, length, causal, num.enc_ln_eps)
+        return hip_layernorm(self.after_norm, x)
+
+    def forward(self, xs, xs_lens, decoding_chunk_size: int = 0, num_decoding_left_chunks: int = -1,
+                num: Optional[Numerics] = None):
+        """Reference signature: xs (B,L,D), xs_lens (B,) -> (B,L,d), masks (B,1,L) bool."""
+        num = num or Numerics(dtype=xs.dtype)
+        B, L, D = xs.shape
+        length = to_len(xs_lens, xs.device)
+        out = self.forward_cl(xs.reshape(B * L, D), B, L, length, num)
+        masks = (torch.arange(L, device=xs.device).unsqueeze(0) < length.unsqueeze(1)).unsqueeze(1)
+        return out.reshape(B, L, -1), masks
+
+
+class InterpolateRegulator(nn.Module):
+    """length_regulator.py:21-50 == modules.py:800-821."""
+
+    def __init__(self, channels: int, sampling_ratios: Tuple, out_channels: int = None, groups: int = 1):
+        super().__init__()
+        self.sampling_ratios = sampling_ratios
+        out_channels = out_channels or channels
+        model = nn.ModuleList([])
+        for _ in sampling_ratios:
+            model.extend([nn.Conv1d(channels, channels, 3, 1, 1), nn.GroupNorm(groups, channels), nn.Mish()])
+        model.append(nn.Conv1d(channels, out_channels, 1, 1))
+        self.model = nn.Sequential(*model)
+
+    def forward_cl(self, x, B: int, Lin: int, T: int, ylen):
+        """x [B*Lin, C] -> [B*T, C] masked by ylen (int32 [B])."""
+        x = HF.interp_linear(x, B, Lin, T)
+        mods = list(self.model)
+        i = 0
+        while i + 2 < len(mods):
+            conv, gn = mods[i], mods[i + 1]
+            x = HF.conv1d(x, conv_pack(conv, x.dtype), B, T)
+            x = HF.groupnorm_mish(x, _f32(gn.weight), _f32(gn.bias), B, T, gn.num_groups, gn.eps, None, None, True)
+            i += 3
+        return HF.conv1d(x, conv_pack(mods[-1], x.dtype), B, T, out_len=ylen)
+
+    def forward(self, x, ylens=None):
+        B, Lin, Cc = x.shape
+        T = int(ylens.max())
+        out = self.forward_cl(x.reshape(B * Lin, Cc), B, Lin, T, to_len(ylens, x.device))
+        return out.reshape(B, T, -1), ylens
+
+
+class ConvolutionModule(nn.Module):
+    """Conformer convolution module (convolution.py:24-145, layer_norm variant): pointwise 1x1 -> GLU ->
+    depthwise Conv1d(k, groups=C) -> LayerNorm -> act -> pointwise 1x1.  Not executed by the
+    CosyVoice-300M config (use_cnn_module=False); provided op-complete with HIP kernels."""
+
+    def __init__(self, channels, kernel_size=15, activation="silu", norm="layer_norm", causal=False):
+        super().__init__()
+        if norm != "layer_norm":
+            raise NotImplementedError("batch_norm variant is not built")
+        self.pointwise_conv1 = nn.Conv1d(channels, 2 * channels, 1)
+        self.lorder = kernel_size - 1 if causal else 0
+        pad = 0 if causal else (kernel_size - 1) // 2
+        self.depthwise_conv = nn.Conv1d(channels, channels, kernel_size, padding=pad, groups=channels)
+        self.norm = nn.LayerNorm(channels)
+        self.pointwise_conv2 = nn.Conv1d(channels, channels, 1)
+        self.activation = activation
+
+    def forward_cl(self, x, B: int, T: int, length):
+        Cc = x.shape[1]
+        h = HF.conv1d(x, conv_pack(self.pointwise_conv1, x.dtype), B, T, in_len=length)
+        a, g = h[:, :Cc], h[:, Cc:]
+        h = a * torch.sigmoid(g.float()).to(a.dtype)                       # GLU (glue; op not on the 300M path)
+        dw = self.depthwise_conv
+        pad_left = self.lorder if self.lorder > 0 else (dw.kernel_size[0] - 1) // 2
+        h = HF.dwconv1d(h, _f32(dw.weight).reshape(Cc, -1).contiguous(), _f32(dw.bias), B, T, pad_left)
+        h = hip_layernorm(self.norm, h)
+        h = HF.ActFn.apply(h, self.activation)
+        return HF.conv1d(h, conv_pack(self.pointwise_conv2, x.dtype), B, T, out_len=length)

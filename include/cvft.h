@@ -1,0 +1,212 @@
+/*
+ * cvft.h -- C ABI of libcvft.so: the MI355X (gfx950) compute kernels behind the
+ * joint LLM+Flow LoRA fine-tuning hot path of CosyVoice-300M.
+ *
+ * The reference (leeoisaboy/cosyvoice-lora-finetune-framework) has NO native / FFI
+ * layer: its hot path is plain torch ops inside Python modules.
+ * Each entry point below therefore cites the reference *torch-op sequence* it replaces
+ * (paths relative to /root/reference/cosyvoice_flow_finetune/).  A ctypes binding is in
+ * cosyvoice_lora_finetune_framework_amd/hipops/binding.py; the reference-side stub a
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer supplied by the caller (torch owns all memory);
+ *    the library never allocates, frees or retains pointers; no global mutable state
+ *    except a thread-local error string.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *    synchronises the host (safe under hipGraph capture).
+ *  - activations are row-major, channel-last: [rows][channels]; rows = batch*time.
+ *  - `dtype`: CVFT_F32 (0) = fp32 storage + exact-fp32 MFMA (parity path),
+ *             CVFT_BF16 (1) = bf16 storage + bf16 MFMA with fp32 accumulation.
+ *    Biases, norm affine params, statistics, losses and LoRA master grads are fp32.
+ *  - return 0 on success, negative on bad argument / launch failure; message via
+ *    cvft_last_error().
+ */
+#ifndef CVFT_H
+#define CVFT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CVFT_F32 = 0, CVFT_BF16 = 1 };
+enum { CVFT_ACT_NONE = 0, CVFT_ACT_RELU = 1, CVFT_ACT_SILU = 2, CVFT_ACT_GELU_ERF = 3,
+       CVFT_ACT_GELU_TANH = 4, CVFT_ACT_MISH = 5 };
+
+int cvft_version(void);
+const char* cvft_last_error(void);
+
+/* ---------------------------------------------------------------------------------
+ * Tap-GEMM with fused rank-r LoRA side path and epilogue.
+ *
+ *   C[orow(m), n] = epi( alpha * ( sum_{j<ntaps} A[irow_j(m), :K] . W[n, j*K:(j+1)*K]
+ *                                 + U[m, :R] . Bl[n, :R] ) + bias[n] )
+ *
+ * m = b*Tm + t (t < Tm):   irow_j(m) = b*Tin + (t*in_stride + tap_off[j])   (zero row if the
+ * time index is outside [0,Tin) or >= in_len[b]);   orow(m) = b*Tout + t*out_stride + out_off
+ * (skipped if >= Tout; written as 0 if >= out_len[b]).
+ * epi(v): if preact: preact[orow,n] = v;  v = act(v);  if dact_src: v *= act'_{dact}(dact_src[orow,n]);
+ *         if residual: v += residual[orow,n].
+ *
+ * Replaces: nn.Linear / lora.LoRALinear.forward (lora.py:64-76: 3x F.linear + scale + add),
+ * nn.Conv1d k=1/k=3 stride 1/2 and nn.ConvTranspose1d(k4,s2,p1) of the U-Net estimator
+ * (matcha/models/components/decoder.py:35-158 == modules.py:60-120) with their
+ * `x * mask` pre/post multiplies, activation (positionwise_feed_forward.py:55,
+ * diffusers GELU) and residual adds; and each of their input-gradient passes.
+ * ------------------------------------------------------------------------------- */
+typedef struct {
+    int dtype;
+    int M, N, K;
+    int Tm, Tin, Tout, in_stride, out_stride, out_off;
+    int ntaps;
+    int tap_off[4];
+    const int32_t* in_len;    /* [M/Tm] or NULL */
+    const int32_t* out_len;   /* [M/Tm] or NULL */
+    const void* A;  int lda;
+    const void* W;  int ldw;
+    const void* U;  int ldu; int R;      /* LoRA: U = s * x A^T (rows indexed by m) or NULL */
+    const void* Bl; int ldbl;            /* LoRA B [N][R] */
+    const float* bias;                   /* [N] or NULL */
+    float alpha;
+    int act;
+    void* preact; int ldp;               /* or NULL */
+    const void* dact_src; int ldd; int dact;   /* or NULL */
+    const void* residual; int ldr;       /* or NULL */
+    void* C; int ldc;
+} cvft_gemm_args;
+
+int cvft_gemm(const cvft_gemm_args* a, void* stream);
+
+/* LoRA adapter gradients (lora.py:71-76 backward; W frozen => no wgrad):
+ *   dA[r,k] += sum_m V[m,r] * X[m,k]      (V = s * dY B,  already scaled)
+ *   dB[n,r] += sum_m dY[m,n] * U[m,r]     (U = s * X A^T, already scaled)
+ * Generic form:  G[p,q] += sum_m P[m,p] * Q[m,q]  with fp32 atomics into G (fp32). */
+int cvft_tn_accum(int dtype, int M, int P, int Q, const void* Pm, int ldp, const void* Qm, int ldq,
+                  float* G, int ldg, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * LayerNorm over the channel axis (+ optional ReLU, + optional post-scale).
+ * Replaces nn.LayerNorm (+ReLU, + x*sqrt(d)) in encoder_layer.py:90-106,
+ * subsampling.py:69-113/338-383 + embedding.py:267-270, matcha transformer.py:255-316.
+ * Backward returns dX only (affine params are frozen under LoRA: lora.py:214-216).
+ * ------------------------------------------------------------------------------- */
+int cvft_layernorm_fwd(int dtype, int rows, int C, const void* x, const float* gamma, const float* beta,
+                       float eps, int relu, float post_scale, void* y, float* mean, float* rstd, void* stream);
+int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, const float* gamma, const float* beta,
+                       const float* mean, const float* rstd, int relu, float post_scale,
+                       const void* dy, void* dx, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * GroupNorm(G) + Mish (+ length mask, + per-(batch,channel) additive term), channel-last.
+ * x [B][T][C]; statistics over (T, C/G) per (b, g) exactly as nn.GroupNorm on (B,C,T).
+ *   y[b,t,c] = mish(gn(x)[b,t,c]) * (t < len[b]) + add[b,c]
+ * Replaces Block1D (matcha decoder.py:35-47 == modules.py:60-73), the ResnetBlock1D
+ * time-embedding add (modules.py:91) and InterpolateRegulator's Conv+GroupNorm(1)+Mish
+ * stack (length_regulator.py:34-41).  apply_mish=0 gives plain GroupNorm.
+ * ------------------------------------------------------------------------------- */
+int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, const void* x, const float* gamma,
+                            const float* beta, float eps, const int32_t* len, const void* add /*[B][C] dtype or NULL*/,
+                            int apply_mish, void* y, float* mean /*[B*G]*/, float* rstd /*[B*G]*/, void* stream);
+int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, const void* x, const float* gamma,
+                            const float* beta, const float* mean, const float* rstd, const int32_t* len,
+                            int apply_mish, const void* dy, void* dx, float* ws /*[B*G*2]*/, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused attention, head_dim 64, additive key-padding bias -1e10 (NOT -inf):
+ *   O = softmax(Q K^T * scale + bias(key >= klen[b])) V
+ * Q,K,V,O: [B*T][ld] with head h at columns [h*64, h*64+64).  lse [B][H][T] fp32.
+ * Replaces diffusers Attention / modules.Attention.forward (modules.py:253-293) and the
+ * (B,T,T) mask_to_bias tensor (decoder.py:238-240, utils.py:103-109).
+ * ------------------------------------------------------------------------------- */
+int cvft_attn_bias_fwd(int dtype, int B, int H, int T, const void* q, const void* k, const void* v, int ld,
+                       const int32_t* klen, float scale, void* o, int ldo, float* lse, void* stream);
+int cvft_attn_bias_bwd(int dtype, int B, int H, int T, const void* q, const void* k, const void* v, int ld,
+                       const int32_t* klen, float scale, const void* o, const void* d_o, int ldo,
+                       const float* lse, float* delta /*[B][H][T] ws*/, void* dq, void* dk, void* dv, int ldg,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused relative-position attention (Transformer-XL / ESPnet), head_dim 64:
+ *   S[i,j] = ((q_i+u_h).k_j + (q_i+v_h).p[L-1-i+j]) * scale ; masked (j>=len[b] or, if causal,
+ *   j>i) -> -inf ; O = softmax(S) V  (post-softmax zero fill is implied).
+ * p [2L-1][ldp] = linear_pos(pos_emb) (batch-independent); u,v [H][64] fp32.
+ * Replaces RelPositionMultiHeadedAttention.forward + rel_shift + forward_attention
+ * (cosyvoice/transformer/attention.py:200-330, 82-127) and the (B,L,L) chunk mask
+ * (cosyvoice/utils/mask.py:161-236).
+ * ------------------------------------------------------------------------------- */
+int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
+                         const void* p, int ldp, const float* bias_u, const float* bias_v,
+                         const int32_t* len, int causal, float scale, void* o, int ldo, float* lse, void* stream);
+int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
+                         const void* p, int ldp, const float* bias_u, const float* bias_v,
+                         const int32_t* len, int causal, float scale, const void* o, const void* d_o, int ldo,
+                         const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg,
+                         float* dp /*[2L-1][H*64] fp32 accum or NULL*/, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Small fused ops.
+ * ------------------------------------------------------------------------------- */
+/* out[b,l,:] = table[max(tok[b,l],0), :] * (l < len[b])      (flow.py:92-93, llm_flow_model.py:206-208) */
+int cvft_embed_gather(int dtype, int B, int L, int D, const int64_t* tok, const int32_t* len /*or NULL*/,
+                      const void* table, void* out, void* stream);
+/* ragged gather of rows: out[i,:] = (idx[i] >= 0) ? src[idx[i],:] : fill   (llm.py:88-95 pad_unpad_sequence) */
+int cvft_gather_rows(int dtype, int n, int D, const int32_t* idx, const void* src, float fill, void* out, void* stream);
+/* dsrc[idx[i],:] += dout[i,:] for idx>=0 (each source row referenced at most once) */
+int cvft_scatter_rows(int dtype, int n, int D, const int32_t* idx, const void* dout, void* dsrc, void* stream);
+/* y = x / max(||x||_2, 1e-12) per row (F.normalize, llm_flow_model.py:146,202) */
+int cvft_l2norm_rows(int dtype, int rows, int D, const float* x, void* y, void* stream);
+/* SinusoidalPosEmb(dim)(t, scale) -> [B][dim] = [sin(scale*t*f_k) | cos(scale*t*f_k)]; freqs [dim/2] fp32 is the
+ * constant table exp(-k*ln(1e4)/(dim/2-1)) built once on the host  (matcha decoder.py:14-32 == modules.py:20-42) */
+int cvft_time_embed(int dtype, int B, int dim, const float* t, const float* freqs, float scale, void* out, void* stream);
+/* y = act(x) elementwise */
+int cvft_act_fwd(int dtype, int64_t n, int act, const void* x, void* y, void* stream);
+/* dz = dy * act'(z) elementwise */
+int cvft_act_bwd(int dtype, int64_t n, int act, const void* z, const void* dy, void* dz, void* stream);
+/* CFM prepare (flow_matching.py:173-186 == flow_model.py:143-161), channel-last:
+ *   feat raw log-mel [B][T][80] fp32, z [B][T][80] fp32, t_raw [B], cfg_keep [B] (0/1), mu [B][T][80],
+ *   spk [B][80]  ->  xin [B][T][320] = [y | mu*keep | spk*keep | 0],  u [B][T][80] (fp32), t [B]. */
+int cvft_cfm_prepare(int dtype, int B, int T, const float* feat, const float* z, const float* t_raw,
+                     const float* cfg_keep, const void* mu, const void* spk, float mel_mean, float mel_std,
+                     float sigma_min, void* xin, float* u, float* t, void* stream);
+/* masked MSE (flow_matching.py:192): loss_sum[0] += sum(((pred-u)*m)^2) (caller divides by sum(mask)*80);
+ * backward: dpred = gscale[0] * 2 * (pred-u) * m  with gscale a DEVICE scalar (= upstream grad / denominator). */
+int cvft_masked_mse_fwd(int dtype, int B, int T, int C, const void* pred, const float* u, const int32_t* len,
+                        float* loss_sum, void* stream);
+int cvft_masked_mse_bwd(int dtype, int B, int T, int C, const void* pred, const float* u, const int32_t* len,
+                        const float* gscale, void* dpred, void* stream);
+/* linear interpolation along time (F.interpolate mode='linear', align_corners=False), channel-last.
+ * x [B][Lin][C] -> y [B][Lout][C]   (length_regulator.py:47) */
+int cvft_interp_linear_fwd(int dtype, int B, int Lin, int Lout, int C, const void* x, void* y, void* stream);
+int cvft_interp_linear_bwd(int dtype, int B, int Lin, int Lout, int C, const void* dy, void* dx, void* stream);
+/* token-mean cross entropy with ignore index + argmax accuracy
+ * (label_smoothing_loss.py:68-96 smoothing 0 ; common.py:78-97).
+ * logits [n][V]; target [n] int32 (-1 ignore). out[0]+=sum nll, out[1]+=#valid, out[2]+=#correct.
+ * dlogits = gscale_ptr[0] * (softmax - onehot) for valid rows, 0 otherwise (if dlogits != NULL). */
+int cvft_ce_fwd(int dtype, int n, int V, const void* logits, int ld, const int32_t* target, float* out3,
+                float* row_lse /*[n]*/, void* stream);
+int cvft_ce_bwd(int dtype, int n, int V, const void* logits, int ld, const int32_t* target, const float* row_lse,
+                const float* gscale /*device [1]*/, void* dlogits, int ldd, void* stream);
+/* depthwise Conv1d (groups=C), channel-last, zero padding, optional length mask on the input
+ * (cosyvoice/transformer/convolution.py:62-70,118; not executed by the 300M config). */
+int cvft_dwconv1d_fwd(int dtype, int B, int T, int C, int Kw, int pad_left, const void* x, const float* w /*[C][Kw]*/,
+                      const float* bias, const int32_t* len, void* y, void* stream);
+int cvft_dwconv1d_bwd(int dtype, int B, int T, int C, int Kw, int pad_left, const void* dy, const float* w,
+                      const int32_t* len, void* dx, void* stream);
+
+/* flat-buffer optimiser pieces (train_joint.py:198-226, 349-360): */
+/* out[0] += sum(g^2) */
+int cvft_sumsq(int64_t n, const float* g, float* out, void* stream);
+/* AdamW on a flat fp32 buffer; clip coefficient = min(1, max_norm/(sqrt(gnorm_sq[0])*inv_scale + 1e-6)),
+ * lr read from device lr[0]; step count from device step[0] (float, already incremented). */
+int cvft_adamw_flat(int64_t n, float* p, const float* g, float* m, float* v, const float* lr, float beta1, float beta2,
+                    float eps, float wd, const float* step, const float* gnorm_sq, float max_norm, float grad_scale,
+                    void* stream);
+/* fp32 -> bf16 cast of a flat buffer */
+int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVFT_H */

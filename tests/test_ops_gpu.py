@@ -1,0 +1,371 @@
+"""GPU parity tests of every libcvft kernel through the C ABI (ctypes) against plain fp32/fp64
+torch references of the same op computed on the CPU.  Tolerances: fp32 path (exact-fp32 MFMA)
+relative L2 <= 2e-5; bf16 path <= 2e-2 (bf16 storage)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def HFmod():
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    return HF
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, dtype):
+    """round a CPU fp32 tensor to `dtype` and back (reference sees the same stored values)"""
+    return t.to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(37, 80, 80), (300, 512, 256), (1000, 1536, 256), (129, 4097, 192), (5, 16, 320),
+                                   (2048, 2048, 512)])
+def test_gemm_plain(dtype, M, N, K):
+    HF = HFmod()
+    x, w, b = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2) / math.sqrt(K), dtype), rnd(N, seed=3)
+    y = HF.gemm(x.to(DEV, dtype), w.to(DEV, dtype), bias=b.to(DEV))
+    ref = x.double() @ w.double().t() + b.double()
+    assert rel(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [None, "relu", "silu", "gelu_erf", "gelu_tanh", "mish"])
+def test_gemm_lora_epilogue(dtype, act):
+    HF = HFmod()
+    M, N, K, r = 333, 200, 264, 16
+    x, w = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    u, bl, b, res = q(rnd(M, r, seed=3), dtype), q(rnd(N, r, seed=4) * 0.1, dtype), rnd(N, seed=5), q(rnd(M, N, seed=6), dtype)
+    pre = torch.empty(M, N, device=DEV, dtype=dtype)
+    y = HF.gemm(x.to(DEV, dtype), w.to(DEV, dtype), bias=b.to(DEV), U=u.to(DEV, dtype), Bl=bl.to(DEV, dtype), act=act,
+                preact=pre, residual=res.to(DEV, dtype))
+    z = x.double() @ w.double().t() + u.double() @ bl.double().t() + b.double()
+    acts = {None: lambda t: t, "relu": F.relu, "silu": F.silu, "gelu_erf": F.gelu,
+            "gelu_tanh": lambda t: F.gelu(t, approximate="tanh"), "mish": F.mish}
+    assert rel(pre, z) < TOL[dtype]
+    assert rel(y, acts[act](z) + res.double()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [None, "gelu_erf", "silu"])
+def test_lora_linear_backward(dtype, act):
+    """LoRALinear fwd+bwd (reference lora.py:64-76) vs torch autograd."""
+    HF = HFmod()
+    M, N, K, r, s = 500, 160, 96, 8, 2.0
+    x, w, b = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2) / math.sqrt(K), dtype), rnd(N, seed=3)
+    A, Bm = q(rnd(r, K, seed=4) / math.sqrt(K), dtype), q(rnd(N, r, seed=5) * 0.1, dtype)
+    res, gy = q(rnd(M, N, seed=6), dtype), q(rnd(M, N, seed=7), dtype)
+    xd = x.to(DEV, dtype).requires_grad_(True)
+    Ad, Bd = A.to(DEV).requires_grad_(True), Bm.to(DEV).requires_grad_(True)
+    rd = res.to(DEV, dtype).requires_grad_(True)
+    pack = HF.LinearPack(w.to(DEV), b.to(DEV), dtype)
+    y = HF.lora_linear(xd, pack, Ad, Bd, s, act, rd)
+    y.backward(gy.to(DEV, dtype))
+    xr, Ar, Br, rr = (t.double().requires_grad_(True) for t in (x, A, Bm, res))
+    z = xr @ w.double().t() + b.double() + s * (xr @ Ar.t()) @ Br.t()
+    a = {None: lambda t: t, "gelu_erf": F.gelu, "silu": F.silu}[act](z)
+    (a + rr).backward(gy.double())
+    tol = TOL[dtype] * (3 if dtype == torch.bfloat16 else 1)
+    assert rel(y, a + rr) < tol
+    assert rel(xd.grad, xr.grad) < tol
+    assert rel(Ad.grad, Ar.grad) < tol
+    assert rel(Bd.grad, Br.grad) < tol
+    assert rel(rd.grad, rr.grad) < tol
+
+
+def _masks(lens, T):
+    return (torch.arange(T).unsqueeze(0) < torch.tensor(lens).unsqueeze(1)).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind,T", [("k3s1", 37), ("k3s2", 37), ("k3s2", 40), ("convT", 19), ("k1", 21)])
+def test_conv1d_taps(dtype, kind, T):
+    """Conv1d k3 s1/s2, k1, ConvTranspose1d(k4,s2,p1) with x*mask pre-multiply: fwd + input grad."""
+    HF = HFmod()
+    B, Cin, Cout = 3, 40, 24
+    lens = [T, T - 5, max(1, T // 2)]
+    x = q(rnd(B, Cin, T, seed=1), dtype)
+    m = _masks(lens, T).unsqueeze(1)
+    if kind == "convT":
+        conv = torch.nn.ConvTranspose1d(Cin, Cout, 4, 2, 1)
+    elif kind == "k1":
+        conv = torch.nn.Conv1d(Cin, Cout, 1)
+    else:
+        conv = torch.nn.Conv1d(Cin, Cout, 3, 2 if kind == "k3s2" else 1, 1)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight, dtype))
+    xr = x.double().requires_grad_(True)
+    conv_d = conv.double()
+    yr = conv_d(xr * m.double())
+    Tout = yr.shape[-1]
+    if kind == "convT":
+        Tout = Tout - 1           # exercise the crop-to-skip path
+        yr = yr[:, :, :Tout]
+    gy = q(rnd(B, Cout, Tout, seed=9), dtype)
+    yr.backward(gy.double())
+    pack = HF.ConvPack(conv.weight.float().to(DEV), conv.bias.float().to(DEV), dtype, stride=conv.stride[0],
+                       transposed=(kind == "convT"))
+    xd = x.transpose(1, 2).reshape(B * T, Cin).to(DEV, dtype).requires_grad_(True)
+    ln = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    y = HF.conv1d(xd, pack, B, T, Tout, in_len=ln)
+    y.backward(gy.transpose(1, 2).reshape(B * Tout, Cout).to(DEV, dtype))
+    assert rel(y.reshape(B, Tout, Cout).transpose(1, 2), yr) < TOL[dtype]
+    assert rel(xd.grad.reshape(B, T, Cin).transpose(1, 2), xr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("relu,post", [(False, 1.0), (True, 22.627417)])
+def test_layernorm(dtype, relu, post):
+    HF = HFmod()
+    rows, Cn = 77, 256
+    x, g, b, gy = q(rnd(rows, Cn, seed=1) * 2 + 0.3, dtype), 1 + 0.1 * rnd(Cn, seed=2), 0.1 * rnd(Cn, seed=3), q(rnd(rows, Cn, seed=4), dtype)
+    xd = x.to(DEV, dtype).requires_grad_(True)
+    y = HF.layernorm(xd, g.to(DEV), b.to(DEV), 1e-5, relu, post)
+    y.backward(gy.to(DEV, dtype))
+    xr = x.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (Cn,), g.double(), b.double(), 1e-5)
+    if relu:
+        yr = F.relu(yr)
+    yr = yr * post
+    yr.backward(gy.double())
+    assert rel(y, yr) < TOL[dtype]
+    assert rel(xd.grad, xr.grad) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("G,Cn", [(8, 64), (1, 80)])
+def test_groupnorm_mish(dtype, G, Cn):
+    HF = HFmod()
+    B, T = 3, 29
+    lens = [29, 20, 7]
+    x, g, b = q(rnd(B, Cn, T, seed=1) + 0.2, dtype), 1 + 0.1 * rnd(Cn, seed=2), 0.1 * rnd(Cn, seed=3)
+    add, gy = q(rnd(B, Cn, seed=4), dtype), q(rnd(B, Cn, T, seed=5), dtype)
+    m = _masks(lens, T).unsqueeze(1).double()
+    xr = x.double().requires_grad_(True)
+    yr = F.mish(F.group_norm(xr, G, g.double(), b.double(), 1e-5)) * m + add.double().unsqueeze(-1)
+    yr.backward(gy.double())
+    xd = x.transpose(1, 2).reshape(B * T, Cn).to(DEV, dtype).requires_grad_(True)
+    y = HF.groupnorm_mish(xd, g.to(DEV), b.to(DEV), B, T, G, 1e-5, torch.tensor(lens, dtype=torch.int32, device=DEV),
+                          add.to(DEV, dtype), True)
+    y.backward(gy.transpose(1, 2).reshape(B * T, Cn).to(DEV, dtype))
+    assert rel(y.reshape(B, T, Cn).transpose(1, 2), yr) < TOL[dtype]
+    assert rel(xd.grad.reshape(B, T, Cn).transpose(1, 2), xr.grad) < TOL[dtype] * 3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,lens", [(50, [50, 33]), (131, [131, 64]), (64, [64, 1])])
+def test_attn_bias(dtype, T, lens):
+    """modules.Attention math (modules.py:253-293) with the additive -1e10 key bias."""
+    HF = HFmod()
+    B, H = 2, 2
+    qkv = q(rnd(B, T, 3 * H * 64, seed=1), dtype)
+    gy = q(rnd(B, T, H * 64, seed=2), dtype)
+    qr = qkv.double().requires_grad_(True)
+    qq, kk, vv = (t.reshape(B, T, H, 64).transpose(1, 2) for t in qr.split(H * 64, dim=-1))
+    bias = (1.0 - _masks(lens, T)).double() * -1.0e10
+    sim = qq @ kk.transpose(-1, -2) * 0.125 + bias.view(B, 1, 1, T)
+    orf = (sim.softmax(-1) @ vv).transpose(1, 2).reshape(B, T, H * 64)
+    orf.backward(gy.double())
+    qd = qkv.reshape(B * T, -1).to(DEV, dtype).requires_grad_(True)
+    o = HF.attn_bias(qd[:, :H * 64], qd[:, H * 64:2 * H * 64], qd[:, 2 * H * 64:], B, H, T,
+                     torch.tensor(lens, dtype=torch.int32, device=DEV), 0.125)
+    o.backward(gy.reshape(B * T, -1).to(DEV, dtype))
+    assert rel(o.reshape(B, T, -1), orf) < TOL[dtype]
+    assert rel(qd.grad.reshape(B, T, -1), qr.grad) < TOL[dtype] * 3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("L,lens", [(45, [45, 30]), (130, [130, 77]), (64, [64, 64])])
+def test_attn_relpos(dtype, causal, L, lens):
+    """RelPositionMultiHeadedAttention core (attention.py:276-330, 82-127) vs the oracle's math."""
+    from oracle import ref_math as R
+    HF = HFmod()
+    B, H = 2, 2
+    d = H * 64
+    qkv = q(rnd(B, L, 3 * d, seed=1), dtype)
+    p = q(rnd(2 * L - 1, d, seed=2), dtype)
+    bu, bv = 0.3 * rnd(H, 64, seed=3), 0.3 * rnd(H, 64, seed=4)
+    gy = q(rnd(B, L, d, seed=5), dtype)
+    qr = qkv.double().requires_grad_(True)
+    qq, kk, vv = (t.reshape(B, L, H, 64) for t in qr.split(d, dim=-1))
+    pp = p.double().view(1, -1, H, 64).transpose(1, 2)
+    ac = (qq + bu.double()).transpose(1, 2) @ kk.transpose(1, 2).transpose(-1, -2)
+    bd = R.rel_shift((qq + bv.double()).transpose(1, 2) @ pp.transpose(-1, -2))
+    mask = _masks(lens, L).bool().unsqueeze(1)
+    if causal:
+        mask = mask & torch.tril(torch.ones(L, L, dtype=torch.bool)).unsqueeze(0)
+    mm = mask.unsqueeze(1).eq(0)
+    sc = ((ac + bd) / 8.0).masked_fill(mm, -float("inf"))
+    at = torch.softmax(sc, -1).masked_fill(mm, 0.0)
+    orf = (at @ vv.transpose(1, 2)).transpose(1, 2).reshape(B, L, d)
+    orf.backward(gy.double())
+    qd = qkv.reshape(B * L, -1).to(DEV, dtype).requires_grad_(True)
+    o = HF.attn_relpos(qd[:, :d], qd[:, d:2 * d], qd[:, 2 * d:], p.to(DEV, dtype), bu.to(DEV), bv.to(DEV), B, H, L,
+                       torch.tensor(lens, dtype=torch.int32, device=DEV), causal, 0.125)
+    o.backward(gy.reshape(B * L, -1).to(DEV, dtype))
+    assert rel(o.reshape(B, L, -1), orf) < TOL[dtype]
+    assert rel(qd.grad.reshape(B, L, -1), qr.grad) < TOL[dtype] * 3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Lin,Lout", [(13, 24), (290, 500), (9, 17), (24, 24)])
+def test_interp_linear(dtype, Lin, Lout):
+    HF = HFmod()
+    B, Cn = 2, 80
+    x, gy = q(rnd(B, Lin, Cn, seed=1), dtype), q(rnd(B, Lout, Cn, seed=2), dtype)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr.transpose(1, 2), size=Lout, mode="linear").transpose(1, 2)
+    yr.backward(gy)
+    xd = x.reshape(B * Lin, Cn).to(DEV, dtype).requires_grad_(True)
+    y = HF.interp_linear(xd, B, Lin, Lout)
+    y.backward(gy.reshape(B * Lout, Cn).to(DEV, dtype))
+    assert rel(y.reshape(B, Lout, Cn), yr) < TOL[dtype]
+    assert rel(xd.grad.reshape(B, Lin, Cn), xr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cross_entropy(dtype):
+    from oracle import ref_math as R
+    HF = HFmod()
+    n, V = 37, 4097
+    lg = q(rnd(n, V, seed=1) * 2, dtype)
+    tg = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(2))
+    tg[:5] = -1
+    tg[20] = -1
+    lr = lg.double().requires_grad_(True)
+    loss_r = R.ce_ignore(lr.view(1, n, V), tg.view(1, n))
+    loss_r.backward()
+    acc_r = R.th_accuracy(lg.view(-1, V), tg.view(1, n))
+    ld = lg.to(DEV, dtype).requires_grad_(True)
+    loss, acc = HF.cross_entropy(ld, tg.to(DEV, torch.int32))
+    (loss * 3.0).backward()
+    assert abs(float(loss) - float(loss_r)) / abs(float(loss_r)) < 1e-5
+    assert abs(float(acc) - float(acc_r)) < 1e-7
+    assert rel(ld.grad, 3.0 * lr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cfm_prepare_and_mse(dtype):
+    from oracle import ref_math as R
+    HF = HFmod()
+    B, T = 3, 21
+    lens = [21, 15, 9]
+    feat = rnd(B, T, 80, seed=1) * 2 - 6
+    z = rnd(B, 80, T, seed=2)
+    t_raw = torch.rand(B, 1, 1, generator=torch.Generator().manual_seed(3))
+    keep = torch.tensor([1.0, 0.0, 1.0])
+    mu, spk = q(rnd(B, T, 80, seed=4), dtype), q(rnd(B, 80, seed=5), dtype)
+    x1 = ((feat + 6.0) / 2.0).transpose(1, 2)
+    t, y, u = R.cfm_prepare(x1, t_raw, z, 1e-6)
+    mud = mu.reshape(B * T, 80).to(DEV, dtype).requires_grad_(True)
+    xin, ud, td = HF.cfm_prepare(mud, spk.to(DEV, dtype), feat.to(DEV), z.transpose(1, 2).contiguous().to(DEV),
+                                 t_raw.view(B).to(DEV), keep.to(DEV), B, T, -6.0, 2.0, 1e-6)
+    xin_r = torch.cat([y.transpose(1, 2), mu * keep.view(B, 1, 1), (spk * keep.view(B, 1)).unsqueeze(1).expand(B, T, 80),
+                       torch.zeros(B, T, 80)], dim=-1)
+    assert rel(xin.reshape(B, T, 320), xin_r) < TOL[dtype]
+    assert rel(ud.reshape(B, T, 80), u.transpose(1, 2)) < 1e-6
+    assert rel(td, t.view(B)) < 1e-6
+    # masked MSE through the packed input (grad reaches mu through the keep mask)
+    pred = xin[:, 80:160] * 1.5
+    ln = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    den = (ln.sum() * 80).float()
+    loss = HF.masked_mse(pred, ud, ln, den, B, T)
+    loss.backward()
+    mr = mu.double().requires_grad_(True)
+    m = _masks(lens, T).unsqueeze(-1).double()
+    pr = mr * keep.view(B, 1, 1).double() * 1.5
+    lr = (((pr - u.transpose(1, 2).double()) * m) ** 2).sum() / (m.sum() * 80)
+    lr.backward()
+    assert abs(float(loss) - float(lr)) / float(lr) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert rel(mud.grad.reshape(B, T, 80), mr.grad) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_small_ops(dtype):
+    from oracle import ref_math as R
+    HF = HFmod()
+    # embedding gather with clamp + length mask
+    table = q(rnd(50, 32, seed=1), dtype)
+    tok = torch.tensor([[3, 7, -1, 49], [0, 5, 9, 2]])
+    ln = torch.tensor([4, 2], dtype=torch.int32)
+    out = HF.embed_gather(tok.to(DEV), table.to(DEV, dtype), ln.to(DEV))
+    ref = F.embedding(tok.clamp(min=0), table) * _masks([4, 2], 4).unsqueeze(-1)
+    assert rel(out.reshape(2, 4, 32), ref) < 1e-7
+    # ragged row gather / scatter
+    src = q(rnd(10, 16, seed=2), dtype)
+    idx = torch.tensor([4, -1, 0, 9, -1, 2], dtype=torch.int32)
+    sd = src.to(DEV, dtype).requires_grad_(True)
+    g = HF.gather_rows(sd, idx.to(DEV), -1.0)
+    refg = torch.where(idx.view(-1, 1) >= 0, src[idx.clamp(min=0).long()], torch.tensor(-1.0))
+    assert rel(g, refg) < 1e-7
+    g.backward(torch.ones_like(g))
+    gr = torch.zeros(10, 16)
+    gr[idx[idx >= 0].long()] = 1.0
+    assert rel(sd.grad, gr) < 1e-7
+    # l2 normalise
+    e = rnd(5, 192, seed=3)
+    assert rel(HF.l2norm_rows(e.to(DEV), dtype), F.normalize(e, dim=1)) < TOL[dtype]
+    # sinusoidal time embedding, scale 1000
+    from cosyvoice_lora_finetune_framework_amd.modules import SinusoidalPosEmb
+    t = torch.tensor([0.0, 0.137, 0.5, 0.999])
+    emb = SinusoidalPosEmb(320)(t.to(DEV), dtype=torch.float32)
+    assert float((emb.cpu() - R.sinusoidal_pos_emb(t, 320)).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("causal", [False, True])
+def test_dwconv1d(dtype, causal):
+    """depthwise Conv1d k=15 (convolution.py:62-70,118), LDS-staged frame tiles."""
+    HF = HFmod()
+    B, T, Cn, Kw = 2, 70, 96, 15
+    x, w, b = q(rnd(B, Cn, T, seed=1), dtype), rnd(Cn, 1, Kw, seed=2) * 0.3, rnd(Cn, seed=3) * 0.1
+    gy = q(rnd(B, Cn, T, seed=4), dtype)
+    xr = x.double().requires_grad_(True)
+    xp = F.pad(xr, (Kw - 1, 0)) if causal else xr
+    yr = F.conv1d(xp, w.double(), b.double(), padding=0 if causal else (Kw - 1) // 2, groups=Cn)
+    yr.backward(gy.double())
+    xd = x.transpose(1, 2).reshape(B * T, Cn).to(DEV, dtype).requires_grad_(True)
+    y = HF.dwconv1d(xd, w.reshape(Cn, Kw).to(DEV), b.to(DEV), B, T, Kw - 1 if causal else (Kw - 1) // 2)
+    y.backward(gy.transpose(1, 2).reshape(B * T, Cn).to(DEV, dtype))
+    assert rel(y.reshape(B, T, Cn).transpose(1, 2), yr) < TOL[dtype]
+    assert rel(xd.grad.reshape(B, T, Cn).transpose(1, 2), xr.grad) < TOL[dtype]
+
+
+def test_adamw_flat_matches_torch():
+    from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
+    n = 10007
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2) * 3
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999))
+    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    lr = torch.tensor([1e-3], device=DEV)
+    for step in range(1, 4):
+        g = g0 * step
+        pr.grad = g.clone()
+        gn = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        gd = g.to(DEV)
+        ss = torch.zeros(1, device=DEV)
+        cb.check(cb.lib().cvft_sumsq(n, cb.ptr(gd), cb.ptr(ss), cb.stream()))
+        assert abs(math.sqrt(float(ss)) - float(g.norm())) / float(g.norm()) < 1e-5
+        st = torch.tensor([float(step)], device=DEV)
+        cb.check(cb.lib().cvft_adamw_flat(n, cb.ptr(p), cb.ptr(gd), cb.ptr(m), cb.ptr(v), cb.ptr(lr), 0.9, 0.999, 1e-8,
+                                          0.01, cb.ptr(st), cb.ptr(ss), 1.0, 1.0, cb.stream()))
+        assert rel(p, pr.data) < 1e-6
