@@ -179,8 +179,9 @@ extern "C" int cvft_act_bwd(int dtype, int64_t n, int act, const void* z, const 
 template <typename T>
 __global__ void cfm_prepare_kernel(int B, int T_, const float* __restrict__ feat, const float* __restrict__ z,
                                    const float* __restrict__ t_raw, const float* __restrict__ keep,
-                                   const T* __restrict__ mu, const T* __restrict__ spk, float mel_mean, float mel_std,
-                                   float sigma_min, T* __restrict__ xin, float* __restrict__ u, float* __restrict__ tout) {
+                                   const T* __restrict__ mu, const T* __restrict__ spk, const T* __restrict__ cond,
+                                   float mel_mean, float mel_std, float sigma_min, T* __restrict__ xin,
+                                   float* __restrict__ u, float* __restrict__ tout) {
     const size_t total = (size_t)B * T_ * 80;
     EW_LOOP(i, total) {
         int c = (int)(i % 80);
@@ -196,22 +197,22 @@ __global__ void cfm_prepare_kernel(int B, int T_, const float* __restrict__ feat
         row[c] = from_f32<T>(y);
         row[80 + c] = from_f32<T>(to_f32(mu[i]) * kp);
         row[160 + c] = from_f32<T>(to_f32(spk[(size_t)b * 80 + c]) * kp);
-        row[240 + c] = from_f32<T>(0.f);
+        row[240 + c] = from_f32<T>(cond ? to_f32(cond[i]) * kp : 0.f);
         if (c == 0 && (bt % T_) == 0) tout[b] = t;
     }
 }
 extern "C" int cvft_cfm_prepare(int dtype, int B, int T, const float* feat, const float* z, const float* t_raw,
-                                const float* cfg_keep, const void* mu, const void* spk, float mel_mean, float mel_std,
-                                float sigma_min, void* xin, float* u, float* t, void* stream) {
+                                const float* cfg_keep, const void* mu, const void* spk, const void* cond, float mel_mean,
+                                float mel_std, float sigma_min, void* xin, float* u, float* t, void* stream) {
     CHECK_DTYPE("cvft_cfm_prepare", dtype);
     CVFT_CHECK_ARG(B > 0 && T > 0 && feat && z && t_raw && cfg_keep && mu && spk && xin && u && t, "cvft_cfm_prepare: bad args");
     size_t total = (size_t)B * T * 80;
     if (dtype == CVFT_F32)
         hipLaunchKernelGGL((cfm_prepare_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, feat, z,
-                           t_raw, cfg_keep, (const float*)mu, (const float*)spk, mel_mean, mel_std, sigma_min, (float*)xin, u, t);
+                           t_raw, cfg_keep, (const float*)mu, (const float*)spk, (const float*)cond, mel_mean, mel_std, sigma_min, (float*)xin, u, t);
     else
         hipLaunchKernelGGL((cfm_prepare_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, feat, z,
-                           t_raw, cfg_keep, (const bf16_t*)mu, (const bf16_t*)spk, mel_mean, mel_std, sigma_min, (bf16_t*)xin, u, t);
+                           t_raw, cfg_keep, (const bf16_t*)mu, (const bf16_t*)spk, (const bf16_t*)cond, mel_mean, mel_std, sigma_min, (bf16_t*)xin, u, t);
     CVFT_LAUNCH_CHECK("cvft_cfm_prepare");
     return 0;
 }

@@ -1,0 +1,163 @@
+"""Flow model (speech tokens -> mel, conditional flow matching) on the HIP path.
+
+Same classes / constructor arguments / state-dict keys as the reference's flow_model.py
+(``ConditionalCFM`` flow_model.py:50-204, ``MaskedDiffWithXvec`` 207-246,
+``build_flow_model`` 641-767) == vendored cosyvoice/flow/{flow,flow_matching}.py; only the
+training hot path is built here (``compute_loss`` and the no-prompt forward that
+llm_flow_model.py:181-229 drives); the Euler sampler / anti-leakage strategies are
+SURVEY.md section 8(f) "next" items.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .config import MEL_MEAN, MEL_STD
+from .hipops import functional as HF
+from .modules import (ConditionalDecoder, InterpolateRegulator, Numerics, RelPosEncoder, hip_linear, to_len)
+
+
+class ConditionalCFM(nn.Module):
+    def __init__(self, in_channels: int, n_spks: int = 1, spk_emb_dim: int = 64, sigma_min: float = 1e-6,
+                 t_scheduler: str = 'cosine', training_cfg_rate: float = 0.2, inference_cfg_rate: float = 0.7,
+                 estimator: Optional[nn.Module] = None):
+        super().__init__()
+        if t_scheduler != 'cosine':
+            raise NotImplementedError("only the cosine t-scheduler of CosyVoice-300M is built")
+        self.in_channels, self.n_spks, self.spk_emb_dim = in_channels, n_spks, spk_emb_dim
+        self.sigma_min, self.t_scheduler = sigma_min, t_scheduler
+        self.training_cfg_rate, self.inference_cfg_rate = training_cfg_rate, inference_cfg_rate
+        self.estimator = estimator
+
+    @staticmethod
+    def make_draws(B: int, T: int, device, n_mels: int = 80) -> Dict[str, torch.Tensor]:
+        """The reference's three draws, in its order (flow_matching.py:175-186), on `device`."""
+        return {"t_raw": torch.rand([B, 1, 1], device=device), "z": torch.randn(B, n_mels, T, device=device),
+                "cfg_rand": torch.rand(B, device=device)}
+
+    def compute_loss_cl(self, feat, mu, spk, length, B: int, T: int, num: Numerics, draws=None,
+                        mel_mean: float = 0.0, mel_std: float = 1.0, cond=None):
+        """Channel-last hot path.  feat [B,T,80] fp32 (raw log-mel if mel_mean/std given), mu [B*T,80],
+        spk [B,80], length int32 [B] -> scalar loss (flow_matching.py:154-193)."""
+        dev = mu.device
+        if draws is None:
+            draws = self.make_draws(B, T, dev)
+        t_raw = draws["t_raw"].reshape(B).to(dev, torch.float32)
+        z = draws["z"].to(dev, torch.float32).transpose(1, 2)   # reference layout (B,80,T) -> channel-last
+        keep = (draws["cfg_rand"].to(dev) > self.training_cfg_rate).to(torch.float32) if self.training_cfg_rate > 0 \
+            else torch.ones(B, device=dev)
+        xin, u, t = HF.cfm_prepare(mu, spk, feat.to(dev, torch.float32).contiguous(), z.contiguous(), t_raw, keep, B, T,
+                                   mel_mean, mel_std, self.sigma_min, cond)
+        pred = self.estimator.forward_cl(xin, t, B, T, length, num.gelu)
+        denom = (length.sum() * pred.shape[1]).to(torch.float32)
+        return HF.masked_mse(pred, u, length, denom, B, T), xin
+
+    def compute_loss(self, x1, mask, mu, spks=None, cond=None, prompt_lens=None, draws=None, num: Optional[Numerics] = None):
+        """Reference signature: x1,mu,cond (B,80,T) normalised mel; mask (B,1,T); spks (B,80)."""
+        if prompt_lens:
+            raise NotImplementedError("prompt-region loss masking (SURVEY 8f rank 4) is not built yet")
+        num = num or Numerics(dtype=mu.dtype)
+        B, _, T = mu.shape
+        length = mask.reshape(B, T).sum(dim=1).to(torch.int32)
+        mu_cl = mu.transpose(1, 2).reshape(B * T, -1).to(num.dtype)
+        cond_cl = None if cond is None else cond.transpose(1, 2).reshape(B * T, -1).to(num.dtype).contiguous()
+        loss, xin = self.compute_loss_cl(x1.transpose(1, 2), mu_cl, spks.to(num.dtype), length, B, T, num, draws, cond=cond_cl)
+        y = xin[:, :x1.shape[1]].reshape(B, T, -1).transpose(1, 2)
+        return loss, y
+
+
+class MaskedDiffWithXvec(nn.Module):
+    def __init__(self, input_size: int = 512, output_size: int = 80, spk_embed_dim: int = 192, vocab_size: int = 4096,
+                 input_frame_rate: int = 50, encoder: Optional[nn.Module] = None,
+                 length_regulator: Optional[nn.Module] = None, decoder: Optional[nn.Module] = None):
+        super().__init__()
+        assert encoder is not None
+        self.input_size, self.output_size, self.vocab_size = input_size, output_size, vocab_size
+        self.input_frame_rate = input_frame_rate
+        self.input_embedding = nn.Embedding(vocab_size, input_size)
+        self.spk_embed_affine_layer = nn.Linear(spk_embed_dim, output_size)
+        self.encoder = encoder
+        self.encoder_proj = nn.Linear(self.encoder.output_size(), output_size)
+        self.decoder = decoder
+        self.length_regulator = length_regulator
+        self.mel_mean, self.mel_std = MEL_MEAN, MEL_STD
+        self.numerics = Numerics()
+
+    def normalize_mel(self, mel):
+        return (mel - self.mel_mean) / self.mel_std
+
+    def denormalize_mel(self, mel):
+        return mel * self.mel_std + self.mel_mean
+
+    def _embedding_table(self, dtype):
+        w = self.input_embedding.weight
+        if dtype == w.dtype:
+            return w.detach()
+        from .modules import _cached
+        return _cached(self.input_embedding, "tab", w, dtype, lambda: w.detach().to(dtype))
+
+    def forward_no_prompt(self, batch: dict, device, draws=None) -> Dict[str, Any]:
+        """llm_flow_model.py:181-229: no-prompt flow-matching loss (conditioning all zero)."""
+        num = self.numerics
+        dt = num.dtype
+        token = batch['speech_token'].to(device)
+        B, Lt = token.shape
+        feat = batch['speech_feat'].to(device)
+        T = feat.shape[1]
+        tok_len = to_len(batch['speech_token_len'], device)
+        feat_len = to_len(batch['speech_feat_len'], device)
+        with torch.no_grad():
+            spk = hip_linear(self.spk_embed_affine_layer, HF.l2norm_rows(batch['embedding'].to(device), dt))
+            tok = HF.embed_gather(token, self._embedding_table(dt), tok_len)
+        h = self.encoder.forward_cl(tok, B, Lt, tok_len, num, causal=False)
+        h = hip_linear(self.encoder_proj, h)
+        mu = self.length_regulator.forward_cl(h, B, Lt, T, feat_len)
+        loss, _ = self.decoder.compute_loss_cl(feat, mu, spk, feat_len, B, T, num, draws, self.mel_mean, self.mel_std)
+        return {'loss': loss}
+
+    def forward(self, batch: dict, device) -> Dict[str, Any]:
+        return self.forward_no_prompt(batch, device)
+
+
+def build_flow_model(pretrained_path: Optional[str] = None, device: str = 'cuda', input_size: int = 512,
+                     output_size: int = 80, spk_embed_dim: int = 192, vocab_size: int = 4096,
+                     encoder_attention_heads: int = 8, encoder_linear_units: int = 2048, encoder_num_blocks: int = 6,
+                     decoder_channels: tuple = (256, 256), decoder_attention_head_dim: int = 64,
+                     decoder_n_blocks: int = 4, decoder_num_mid_blocks: int = 12, decoder_num_heads: int = 8,
+                     numerics: Optional[Numerics] = None) -> MaskedDiffWithXvec:
+    """reference flow_model.py:641-767 (CosyVoice-300M dims by default)."""
+    numerics = numerics or Numerics()
+    encoder = RelPosEncoder(input_size=input_size, output_size=input_size, attention_heads=encoder_attention_heads,
+                            linear_units=encoder_linear_units, num_blocks=encoder_num_blocks, dropout_rate=0.1,
+                            positional_dropout_rate=0.1, attention_dropout_rate=0.1, input_layer="linear",
+                            kind="conformer", static_chunk_size=0, ln_eps=numerics.enc_ln_eps)
+    regulator = InterpolateRegulator(channels=output_size, sampling_ratios=(1, 1, 1, 1), out_channels=output_size, groups=1)
+    estimator = ConditionalDecoder(in_channels=320, out_channels=80, channels=decoder_channels, dropout=0.0,
+                                   attention_head_dim=decoder_attention_head_dim, n_blocks=decoder_n_blocks,
+                                   num_mid_blocks=decoder_num_mid_blocks, num_heads=decoder_num_heads, act_fn='gelu')
+    decoder = ConditionalCFM(in_channels=output_size, n_spks=1, spk_emb_dim=output_size, sigma_min=1e-6,
+                             t_scheduler='cosine', training_cfg_rate=0.2, inference_cfg_rate=0.7, estimator=estimator)
+    model = MaskedDiffWithXvec(input_size=input_size, output_size=output_size, spk_embed_dim=spk_embed_dim,
+                               vocab_size=vocab_size, input_frame_rate=50, encoder=encoder,
+                               length_regulator=regulator, decoder=decoder)
+    model.numerics = numerics
+    if pretrained_path is not None:
+        wf = os.path.join(pretrained_path, 'flow.pt') if os.path.isdir(pretrained_path) else pretrained_path
+        if os.path.exists(wf):
+            sd = torch.load(wf, map_location='cpu')
+            try:
+                model.load_state_dict(sd, strict=True)
+                print("Weights loaded successfully (strict=True)")
+            except Exception as e:   # tolerant loading, as the reference does
+                print(f"Strict loading failed: {e}\nAttempting partial loading...")
+                own = model.state_dict()
+                ok = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+                own.update(ok)
+                model.load_state_dict(own, strict=False)
+                print(f"Partial loading: {len(ok)}/{len(sd)} weights loaded")
+        else:
+            print(f"Warning: Weight file not found: {wf}\nUsing random initialization")
+    return model.to(device)

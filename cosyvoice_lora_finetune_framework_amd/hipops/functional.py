@@ -493,13 +493,14 @@ class CfmPrepareFn(torch.autograd.Function):
     Gradient flows to mu only (dmu = dxin[:, 80:160] * keep)."""
 
     @staticmethod
-    def forward(ctx, mu, spk, feat, z, t_raw, keep, B: int, T: int, mel_mean: float, mel_std: float, sigma_min: float):
+    def forward(ctx, mu, spk, feat, z, t_raw, keep, B: int, T: int, mel_mean: float, mel_std: float, sigma_min: float,
+                cond=None):
         mu = _c(mu)
         xin = torch.empty((B * T, 320), dtype=mu.dtype, device=mu.device)
         u = torch.empty((B * T, 80), dtype=torch.float32, device=mu.device)
         t = torch.empty(B, dtype=torch.float32, device=mu.device)
         check(lib().cvft_cfm_prepare(dt(mu), B, T, ptr(_c(feat)), ptr(_c(z)), ptr(_c(t_raw)), ptr(_c(keep)), ptr(mu),
-                                     ptr(_c(spk)), mel_mean, mel_std, sigma_min, ptr(xin), ptr(u), ptr(t), stream()),
+                                     ptr(_c(spk)), ptr(None if cond is None else _c(cond)), mel_mean, mel_std, sigma_min, ptr(xin), ptr(u), ptr(t), stream()),
               "cvft_cfm_prepare")
         ctx.save_for_backward(keep)
         ctx.dims = (B, T)
@@ -511,11 +512,12 @@ class CfmPrepareFn(torch.autograd.Function):
         (keep,) = ctx.saved_tensors
         B, T = ctx.dims
         dmu = (dxin[:, 80:160].reshape(B, T, 80) * keep.view(B, 1, 1).to(dxin.dtype)).reshape(B * T, 80)
-        return dmu, None, None, None, None, None, None, None, None, None, None
+        return dmu, None, None, None, None, None, None, None, None, None, None, None
 
 
-def cfm_prepare(mu, spk, feat, z, t_raw, keep, B: int, T: int, mel_mean: float, mel_std: float, sigma_min: float):
-    return CfmPrepareFn.apply(mu, spk, feat, z, t_raw, keep, B, T, mel_mean, mel_std, sigma_min)
+def cfm_prepare(mu, spk, feat, z, t_raw, keep, B: int, T: int, mel_mean: float, mel_std: float, sigma_min: float,
+                cond=None):
+    return CfmPrepareFn.apply(mu, spk, feat, z, t_raw, keep, B, T, mel_mean, mel_std, sigma_min, cond)
 
 
 class MaskedMseFn(torch.autograd.Function):

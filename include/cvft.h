@@ -166,10 +166,10 @@ int cvft_act_fwd(int dtype, int64_t n, int act, const void* x, void* y, void* st
 int cvft_act_bwd(int dtype, int64_t n, int act, const void* z, const void* dy, void* dz, void* stream);
 /* CFM prepare (flow_matching.py:173-186 == flow_model.py:143-161), channel-last:
  *   feat raw log-mel [B][T][80] fp32, z [B][T][80] fp32, t_raw [B], cfg_keep [B] (0/1), mu [B][T][80],
- *   spk [B][80]  ->  xin [B][T][320] = [y | mu*keep | spk*keep | 0],  u [B][T][80] (fp32), t [B]. */
+ *   spk [B][80], cond (or NULL = zeros)  ->  xin [B][T][320] = [y | mu*keep | spk*keep | cond*keep],  u [B][T][80] (fp32), t [B]. */
 int cvft_cfm_prepare(int dtype, int B, int T, const float* feat, const float* z, const float* t_raw,
-                     const float* cfg_keep, const void* mu, const void* spk, float mel_mean, float mel_std,
-                     float sigma_min, void* xin, float* u, float* t, void* stream);
+                     const float* cfg_keep, const void* mu, const void* spk, const void* cond /*[B][T][80] or NULL*/,
+                     float mel_mean, float mel_std, float sigma_min, void* xin, float* u, float* t, void* stream);
 /* masked MSE (flow_matching.py:192): loss_sum[0] += sum(((pred-u)*m)^2) (caller divides by sum(mask)*80);
  * backward: dpred = gscale[0] * 2 * (pred-u) * m  with gscale a DEVICE scalar (= upstream grad / denominator). */
 int cvft_masked_mse_fwd(int dtype, int B, int T, int C, const void* pred, const float* u, const int32_t* len,

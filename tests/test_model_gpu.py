@@ -1,0 +1,162 @@
+"""Model-level parity on the GPU: the HIP product path (fp32 = exact-fp32 MFMA) against golden
+vectors produced by the REFERENCE's own modules (tests/golden, tools/make_golden.py).
+north_star tolerance: flow-matching loss and LLM CE loss within 1e-4 relative (fp32)."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_json, load_npz
+from helpers import build_flow_product, build_llm_product, lora_grads, rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+LOSS_TOL = 1e-4          # north_star: 1e-4 relative fp32
+GRAD_TOL = 2e-3          # LoRA gradients (fp32 atomics + different summation order)
+
+
+def _batch(g):
+    return {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+
+
+def _numerics(variant, dtype=torch.float32):
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    return Numerics(dtype=dtype) if variant == "vendored" else Numerics.twin(dtype)
+
+
+@pytest.mark.parametrize("variant", ["vendored", "twin"])
+def test_flow_tiny_loss_and_grads(tiny_meta, variant):
+    g = load_npz("flow_tiny.npz")
+    m = build_flow_product(tiny_meta["flow"], DEV, _numerics(variant))
+    draws = dict(t_raw=g["draw_t_raw"], z=g["draw_z"], cfg_rand=g["draw_cfg_rand"])
+    out = m.forward_no_prompt(_batch(g), DEV, draws)
+    ref = float(g[f"loss_{variant}"])
+    assert abs(float(out["loss"]) - ref) / ref < LOSS_TOL, (float(out["loss"]), ref)
+    out["loss"].backward()
+    grads = lora_grads(m)
+    refg = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith(f"grad_{variant}/")}
+    assert set(grads) == set(refg)
+    worst = max(rel(grads[k], refg[k]) for k in refg)
+    assert worst < GRAD_TOL, worst
+
+
+def test_flow_tiny_bf16_close(tiny_meta):
+    g = load_npz("flow_tiny.npz")
+    m = build_flow_product(tiny_meta["flow"], DEV, _numerics("vendored", torch.bfloat16))
+    draws = dict(t_raw=g["draw_t_raw"], z=g["draw_z"], cfg_rand=g["draw_cfg_rand"])
+    out = m.forward_no_prompt(_batch(g), DEV, draws)
+    ref = float(g["loss_vendored"])
+    assert abs(float(out["loss"]) - ref) / ref < 3e-2
+    out["loss"].backward()
+    grads = lora_grads(m)
+    refg = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith("grad_vendored/")}
+    num = math.sqrt(sum(float(((grads[k].double().cpu() - refg[k].double()) ** 2).sum()) for k in refg))
+    den = math.sqrt(sum(float((refg[k].double() ** 2).sum()) for k in refg))
+    assert num / den < 0.1
+
+
+def test_llm_tiny_loss_and_grads(tiny_meta):
+    g = load_npz("llm_tiny.npz")
+    m = build_llm_product(tiny_meta["llm"], DEV, _numerics("vendored"))
+    out = m.forward_no_prompt(_batch(g), DEV)
+    ref = float(g["loss"])
+    assert abs(float(out["loss"]) - ref) / ref < LOSS_TOL, (float(out["loss"]), ref)
+    assert abs(float(out["acc"]) - float(g["acc"])) < 1e-6
+    out["loss"].backward()
+    grads = lora_grads(m)
+    refg = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith("grad/")}
+    assert set(grads) == set(refg)
+    worst = max(rel(grads[k], refg[k]) for k in refg)
+    assert worst < GRAD_TOL, worst
+
+
+def test_joint_model_contract(tiny_meta):
+    """JointLLMFlowModel.forward dict contract + loss weighting (llm_flow_model.py:77-107)."""
+    from cosyvoice_lora_finetune_framework_amd.llm_flow_model import JointLLMFlowModel
+    gf, gl = load_npz("flow_tiny.npz"), load_npz("llm_tiny.npz")
+    flow = build_flow_product(tiny_meta["flow"], DEV, _numerics("vendored"))
+    llm = build_llm_product(tiny_meta["llm"], DEV, _numerics("vendored"))
+    jm = JointLLMFlowModel(llm, flow, 'joint', llm_loss_weight=2.0, flow_loss_weight=1.0)
+    draws = dict(t_raw=gf["draw_t_raw"], z=gf["draw_z"], cfg_rand=gf["draw_cfg_rand"])
+    out = jm(_batch(gf), torch.device(DEV), draws)
+    assert set(out) == {"loss", "llm_loss", "flow_loss", "llm_acc"}
+    ref = 2.0 * float(gl["loss"]) + float(gf["loss_vendored"])
+    assert abs(float(out["loss"]) - ref) / ref < LOSS_TOL
+    for mode, keys in (("llm_only", {"loss", "llm_loss", "llm_acc"}), ("flow_only", {"loss", "flow_loss"})):
+        jm.training_mode = mode
+        assert set(jm(_batch(gf), torch.device(DEV), draws)) == keys
+
+
+def test_merged_export_roundtrip(tiny_meta):
+    """lora.get_merged_state_dict: original key set, strict-loadable into an un-wrapped model, same loss
+    (reference lora.py:284-323; consumer inference_joint.py:113-127)."""
+    from cosyvoice_lora_finetune_framework_amd.lora import get_merged_state_dict
+    g, gm = load_npz("flow_tiny.npz"), load_npz("flow_tiny_merged.npz")
+    fm = tiny_meta["flow"]
+    m = build_flow_product(fm, DEV, _numerics("vendored"))
+    draws = dict(t_raw=g["draw_t_raw"], z=g["draw_z"], cfg_rand=g["draw_cfg_rand"])
+    with torch.no_grad():
+        l0 = float(m.forward_no_prompt(_batch(g), DEV, draws)["loss"])
+    merged = get_merged_state_dict(m)
+    assert sorted(merged.keys()) == fm["base_keys"]
+    for k, v in gm.items():
+        assert rel(merged[k], v) < 1e-6, k
+    base = build_flow_product(fm, "cpu", _numerics("vendored"), lora=False)
+    base.load_state_dict({k: v.cpu() for k, v in merged.items()}, strict=True)
+    base = base.to(DEV)
+    with torch.no_grad():
+        l1 = float(base.forward_no_prompt(_batch(g), DEV, draws)["loss"])
+    assert abs(l1 - l0) / l0 < 2e-5
+    assert abs(l1 - fm["merged_loss"]) / fm["merged_loss"] < LOSS_TOL
+
+
+@pytest.mark.parametrize("case", ["uniform_T500_B2", "ragged_T500_B2"])
+def test_full_size_flow_matches_reference(case):
+    """CosyVoice-300M flow dims, BASELINE shape (T=500, r=16): fp32 loss within 1e-4 of the reference CPU
+    run; LoRA grad norm within 1e-3; bf16 loss within 2e-2."""
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    fs = load_json("full_scalars.json")
+    c = fs[f"flow/{case}"]
+    meta = dict(lora=dict(r=fs["flow_lora"]["r"], alpha=fs["flow_lora"]["alpha"], targets=fs["flow_lora"]["targets"]),
+                weight_seed=fs["flow_lora"]["weight_seed"])
+    m = build_flow_product(meta, DEV, _numerics("vendored"))
+    batch = synth_batch(c["feat_lens"], text_lens=c["text_lens"], seed=c["batch_seed"])
+    draws = cfm_draws(len(c["feat_lens"]), max(c["feat_lens"]), c["draw_seed"])
+    out = m.forward_no_prompt(batch, DEV, draws)
+    assert abs(float(out["loss"]) - c["loss"]) / c["loss"] < LOSS_TOL, (float(out["loss"]), c["loss"])
+    out["loss"].backward()
+    grads = lora_grads(m)
+    tot = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
+    assert abs(tot - c["grads"]["total_norm"]) / c["grads"]["total_norm"] < 1e-3
+    for k, v in c["grads"]["picks"].items():
+        assert abs(float(grads[k].double().norm()) - v) / v < 2e-3, k
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    m.zero_grad(set_to_none=True)
+    m.numerics = Numerics(dtype=torch.bfloat16)
+    with torch.no_grad():
+        lb = float(m.forward_no_prompt(batch, DEV, draws)["loss"])
+    assert abs(lb - c["loss"]) / c["loss"] < 2e-2, lb
+
+
+@pytest.mark.parametrize("case", ["uniform_T500_B2", "ragged_T500_B2"])
+def test_full_size_llm_matches_reference(case):
+    from cosyvoice_lora_finetune_framework_amd.synthetic import synth_batch
+    fs = load_json("full_scalars.json")
+    c = fs[f"llm/{case}"]
+    meta = dict(lora=dict(r=fs["llm_lora"]["r"], alpha=fs["llm_lora"]["alpha"], targets=fs["llm_lora"]["targets"]),
+                weight_seed=fs["llm_lora"]["weight_seed"])
+    m = build_llm_product(meta, DEV, _numerics("vendored"), full=True)
+    batch = synth_batch(c["feat_lens"], text_lens=c["text_lens"], seed=c["batch_seed"])
+    out = m.forward_no_prompt(batch, DEV)
+    assert abs(float(out["loss"]) - c["loss"]) / c["loss"] < LOSS_TOL, (float(out["loss"]), c["loss"])
+    assert abs(float(out["acc"]) - c["acc"]) < 1e-6
+    out["loss"].backward()
+    grads = lora_grads(m)
+    tot = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
+    assert abs(tot - c["grads"]["total_norm"]) / c["grads"]["total_norm"] < 1e-3
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    m.zero_grad(set_to_none=True)
+    m.numerics = Numerics(dtype=torch.bfloat16)
+    with torch.no_grad():
+        lb = float(m.forward_no_prompt(batch, DEV)["loss"])
+    assert abs(lb - c["loss"]) / c["loss"] < 2e-2, lb
