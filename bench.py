@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- train utterances/sec of the joint LLM+Flow LoRA step on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU, RCCL).  W untimed warm-up steps, EXACTLY K timed steps bracketed by
+barrier + torch.cuda.synchronize(), MAX over ranks, rank 0 prints ONE JSON line.
+
+A "step" = one pass of the hot path over one per-GPU batch of synthetic utterances
+(500-frame x 80-mel clips, 290 speech tokens, 40 text tokens; random-init CosyVoice-300M dims,
+LoRA r=16 alpha=32): forward + backward + LoRA-gradient all-reduce + clip + AdamW.  Weak
+scaling: per-GPU batch fixed (default 16 = BASELINE configs[2] at N=1, configs[3] at N=8).
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (by time) of an event-instrumented step run right after the timed
+                  region, same process / stream / data: algorithmic FLOPs per launch / mean launch
+                  duration vs the dense bf16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline -- the CPU oracle (torch fp32, all host cores; oracle/ref_math.py = port of the
+                  reference's math) on a bounded sample of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md chip table)
+PEAK_F32_TFLOPS = 157.3
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build(workload, dtype, device, r, alpha):
+    from cosyvoice_lora_finetune_framework_amd.flow_model import build_flow_model
+    from cosyvoice_lora_finetune_framework_amd.llm_flow_model import JointLLMFlowModel
+    from cosyvoice_lora_finetune_framework_amd.llm_model import build_llm_model
+    from cosyvoice_lora_finetune_framework_amd.lora import apply_lora_to_model
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    from cosyvoice_lora_finetune_framework_amd.config import JOINT_TRAINING_CONFIG as JC
+    num = Numerics(dtype=dtype)
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):
+        flow = build_flow_model(None, 'cpu', numerics=num)
+        llm = build_llm_model(None, 'cpu', numerics=num) if workload != 'flow_only' else torch.nn.Identity()
+        if workload in ('joint', 'flow_only'):
+            apply_lora_to_model(flow, r=r, lora_alpha=alpha, lora_dropout=0.0, target_modules=JC['flow_lora']['target_modules'])
+        if workload in ('joint', 'llm_only'):
+            apply_lora_to_model(llm, r=r, lora_alpha=alpha, lora_dropout=0.0, target_modules=JC['llm_lora']['target_modules'])
+        if workload == 'llm_only':
+            flow.requires_grad_(False)
+        jm = JointLLMFlowModel(llm, flow, workload, llm_loss_weight=JC['llm_loss_weight'],
+                               flow_loss_weight=JC['flow_loss_weight'])
+    return jm.to(device).eval()      # eval(): dropout off (synthetic throughput run; LoRA dropout p=0)
+
+
+def cpu_baseline(jm, workload, T, seconds_budget=30.0):
+    """Time the CPU oracle (port of the reference math) on a bounded sample: B=1 utterances/step."""
+    from oracle import ref_math as R
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd_f = {k: v.detach().float().cpu() for k, v in jm.flow.state_dict().items()}
+    sd_l = {k: v.detach().float().cpu() for k, v in jm.llm.state_dict().items()} if workload != 'flow_only' else {}
+    for sd in (sd_f, sd_l):
+        for k, v in sd.items():
+            if 'lora_' in k:
+                v.requires_grad_(True)
+    cfg = R.OracleConfig(flow_lora_scale=2.0, llm_lora_scale=2.0)
+    B = 1
+    batch = synth_batch([T] * B, seed=99)
+    draws = cfm_draws(B, T, 5)
+
+    def one():
+        out = R.joint_forward(sd_l, sd_f, batch, draws, cfg, workload, jm.llm_loss_weight, jm.flow_loss_weight)
+        params = [v for sd in (sd_f, sd_l) for v in sd.values() if v.requires_grad]
+        torch.autograd.grad(out['loss'], params, allow_unused=True)
+        return float(out['loss'])
+    t0 = time.time()
+    one()
+    first = time.time() - t0
+    n = max(1, min(3, int((seconds_budget - first) / max(first, 1e-3))))
+    t0 = time.time()
+    for _ in range(n):
+        one()
+    dt_ = (time.time() - t0) / n
+    return {"value": B / dt_, "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd steps of {B} utterance(s) ({T}-frame mel, {workload}), torch fp32 CPU oracle "
+                      f"(oracle/ref_math.py), same random-init weights; optimiser step excluded (negligible)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="joint", choices=["joint", "flow_only", "llm_only"])
+    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
+    ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--rank-lora", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--graph", type=int, default=1, help="capture fwd+bwd in a hipGraph (0 = eager launches)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    from cosyvoice_lora_finetune_framework_amd import dp
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
+    from cosyvoice_lora_finetune_framework_amd.synthetic import synth_batch
+
+    rank, local, world = dp.init_from_env()
+    if world != a.gpus:
+        log(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    jm = build(a.workload, dtype, dev, a.rank_lora, 2 * a.rank_lora)
+    opt = FlatAdamW([p for p in jm.parameters() if p.requires_grad], lr=2e-4, weight_decay=0.01, max_grad_norm=1.0)
+    B, T = a.batch, a.frames
+    batch = jm.prepare_batch(synth_batch([T] * B, seed=1234 + rank), dev)
+
+    def fwd_bwd():
+        out = jm(batch, dev)
+        out['loss'].backward()
+        return out['loss'].detach()
+
+    graph = None
+    static_loss = None
+    if a.graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):                 # allocator / pack warm-up on the side stream
+                    fwd_bwd()
+                    opt.zero_grad()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = fwd_bwd()
+            opt.zero_grad()
+        except Exception as e:                      # still the HIP path, just launched eagerly
+            log(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager launches")
+            graph = None
+            torch.cuda.synchronize()
+            opt.zero_grad()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            loss = static_loss
+        else:
+            loss = fwd_bwd()
+        gscale = dp.allreduce_flat_grads(opt.flat_g)
+        opt.step(gscale)
+        opt.zero_grad()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(el)
+    final_loss = float(loss)
+
+    roof = None
+    if not a.no_roofline:
+        # event-instrumented eager step: every tap-GEMM launch bracketed by HIP events on the launch stream
+        HF.PROFILE = []
+        fwd_bwd()
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        groups = {}
+        for rec in HF.PROFILE:
+            g = groups.setdefault(rec["kernel"], {"ms": 0.0, "flop": 0.0, "n": 0})
+            g["ms"] += rec["start"].elapsed_time(rec["end"])
+            g["flop"] += rec["flop"]
+            g["n"] += 1
+        HF.PROFILE = None
+        if groups:
+            name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+            peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+            ach = g["flop"] / (g["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                    "frac": ach / peak, "traffic": None, "launches_per_step": g["n"],
+                    "avg_launch_us": g["ms"] * 1e3 / g["n"], "alg_gflop_per_launch": g["flop"] / g["n"] / 1e9,
+                    "all_gemm_kernels": {k: {"ms": v["ms"], "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12, "n": v["n"]}
+                                         for k, v in groups.items()}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(jm, a.workload, T)
+        except Exception as e:
+            log(f"[bench] cpu_baseline failed: {type(e).__name__}: {e}")
+
+    if rank == 0:
+        utt = world * B * a.steps
+        line = {
+            "metric": "train utterances/sec (500-frame mel, LoRA r=16) at 1/2/4/8 MI355X",
+            "value": utt / elapsed, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{a.workload} LLM+Flow LoRA r={a.rank_lora} step (fwd+bwd+allreduce+clip+AdamW), "
+                                   f"CosyVoice-300M dims random-init, {T}-frame x 80-mel clips, "
+                                   f"{int(T * 50 * 256 / 22050)} speech tokens, 40 text tokens",
+                       "per_gpu_batch": B, "global_batch": world * B, "frames": T, "lora_r": a.rank_lora,
+                       "parallelism": f"dp{world}", "launch": "hipGraph" if graph is not None else "eager",
+                       "final_loss": final_loss},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

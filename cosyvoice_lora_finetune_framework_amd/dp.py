@@ -1,0 +1,77 @@
+"""Data-parallel replicas over RCCL/xGMI: one process per GPU, frozen weights replicated,
+ONE all-reduce(sum) of the flat LoRA-gradient buffer per optimiser step (skipped on
+accumulation micro-steps -- DDP ``no_sync`` semantics, vendored cosyvoice/utils/executor.py:64-65),
+plus a 2-float exchange of loss denominators so that ragged batches reproduce the reference's
+single-process *global-batch* means (flow_matching.py:192; label_smoothing_loss.py:91-96).
+
+The reference itself trains with devices=1 (train_joint.py:352); nothing here is ported.
+Works with backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" on CPU (tests)."""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """(rank, local_rank, world).  Reads RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set by torch.distributed.run."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shard_indices(n: int, rank: int, world: int, drop_last: bool = True) -> range:
+    """Contiguous slice of a (same-seed-shuffled) index list for this rank."""
+    per = n // world if drop_last else -(-n // world)
+    return range(rank * per, min(n, (rank + 1) * per))
+
+
+def loss_weights(local_denoms: Dict[str, float], device) -> Dict[str, float | torch.Tensor]:
+    """For each loss term return world * den_local / sum_ranks(den): scaling the local *mean* loss by it
+    before backward makes all-reduce(sum)/world of the gradients equal the gradient of the
+    global-batch mean.  Uniform shards -> 1.0.  Device tensors, no host sync."""
+    keys = sorted(local_denoms)
+    t = torch.tensor([float(local_denoms[k]) for k in keys], dtype=torch.float32, device=device)
+    if world_size() == 1:
+        return {k: 1.0 for k in keys}
+    tot = t.clone()
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    w = t * world_size() / tot.clamp_min(1e-12)
+    return {k: w[i] for i, k in enumerate(keys)}
+
+
+def allreduce_flat_grads(flat_g: torch.Tensor) -> float:
+    """Sum the flat LoRA gradient buffer over ranks (in place); returns the 1/world grad scale the
+    optimiser applies inside its fused update kernel."""
+    w = world_size()
+    if w > 1:
+        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+    return 1.0 / w
+
+
+def reduce_metrics(nums_dens: torch.Tensor) -> torch.Tensor:
+    """all-reduce(sum) a small vector of [numerators..., denominators...] for logging global means
+    (replaces Lightning's sync_dist=True scalar reduce, train_joint.py:152-159)."""
+    if world_size() > 1:
+        dist.all_reduce(nums_dens, op=dist.ReduceOp.SUM)
+    return nums_dens
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()

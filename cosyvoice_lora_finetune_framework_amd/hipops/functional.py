@@ -18,6 +18,19 @@ from . import binding as cb
 from .binding import ACT, GemmArgs, check, dt, lib, ptr, stream
 
 
+PROFILE = None   # bench.py sets this to a list: every tap-GEMM launch is then bracketed by HIP events
+
+
+def _gemm_kernel_name(M: int, N: int, dtype: torch.dtype) -> str:
+    """Mirror of the tile selection in csrc/gemm.hip::gemm_launch."""
+    t = "bf16" if dtype == torch.bfloat16 else "f32"
+    if N <= 32:
+        return f"gemm_kernel<{t},128,32,4,1>"
+    if -(-M // 128) * -(-N // 128) >= 512:
+        return f"gemm_kernel<{t},128,128,2,2>"
+    return f"gemm_kernel<{t},64,64,2,2>"
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -83,6 +96,14 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
         assert residual.shape[0] == out.shape[0]
         a.residual, a.ldr = ptr(residual), residual.stride(0)
     a.C, a.ldc = ptr(out), out.stride(0)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().cvft_gemm(C.byref(a), stream()), "cvft_gemm")
+        e1.record()
+        PROFILE.append({"kernel": _gemm_kernel_name(a.M, N, x.dtype), "start": e0, "end": e1,
+                        "flop": 2.0 * a.M * N * (ntaps * K + (a.R if U is not None else 0))})
+        return out
     check(lib().cvft_gemm(C.byref(a), stream()), "cvft_gemm")
     return out
 

@@ -55,6 +55,17 @@ class JointLLMFlowModel(nn.Module):
             losses['loss'] = losses['flow_loss']
         return losses
 
+    def prepare_batch(self, batch: dict, device) -> dict:
+        """Move a collated batch to `device` and attach the host-computed LLM index maps, so that the
+        training step itself performs no host<->device transfers (hipGraph-capturable)."""
+        out = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        for k in ('speech_token_len', 'speech_feat_len', 'text_token_len'):
+            if k in out:
+                out[k] = out[k].to(torch.int32)
+        if self.training_mode in ('joint', 'llm_only') and hasattr(self.llm, 'prepare_batch'):
+            out.update(self.llm.prepare_batch(batch, device))
+        return out
+
     def _forward_llm(self, batch: dict, device) -> Dict[str, Any]:
         return self.llm.forward_no_prompt(batch, device)
 

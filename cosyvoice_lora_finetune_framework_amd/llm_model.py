@@ -82,9 +82,12 @@ class TransformerLM(nn.Module):
         B, Lx = text.shape
         sp = batch['speech_token']
         Lt = sp.shape[1]
-        idx, tgt, lm_len, L = self.build_index_maps(batch['text_token_len'].cpu(), batch['speech_token_len'].cpu(),
-                                                    sp.cpu(), B, Lx, Lt, self.speech_token_size)
-        idx, tgt, lm_len = idx.to(device), tgt.to(device), lm_len.to(device)
+        if '_lm_maps' in batch:                       # prepared once on the host (prepare_batch): no sync, graph-safe
+            idx, tgt, lm_len, L = batch['_lm_maps']
+        else:
+            idx, tgt, lm_len, L = self.build_index_maps(batch['text_token_len'].cpu(), batch['speech_token_len'].cpu(),
+                                                        sp.cpu(), B, Lx, Lt, self.speech_token_size)
+            idx, tgt, lm_len = idx.to(device), tgt.to(device), lm_len.to(device)
         text_len = to_len(batch['text_token_len'], device)
         with torch.no_grad():
             temb = HF.embed_gather(text.to(device), self._table(self.text_embedding, dt))
@@ -102,6 +105,15 @@ class TransformerLM(nn.Module):
 
     def forward(self, batch: dict, device) -> Dict[str, Any]:
         return self.forward_no_prompt(batch, device)
+
+    def prepare_batch(self, batch: dict, device) -> dict:
+        """Host-side preparation of one batch: index maps + H2D copies, done once per batch outside the
+        (graph-capturable) step."""
+        B, Lx = batch['text_token'].shape
+        Lt = batch['speech_token'].shape[1]
+        idx, tgt, lm_len, L = self.build_index_maps(batch['text_token_len'].cpu(), batch['speech_token_len'].cpu(),
+                                                    batch['speech_token'].cpu(), B, Lx, Lt, self.speech_token_size)
+        return {'_lm_maps': (idx.to(device), tgt.to(device), lm_len.to(device), L)}
 
 
 def build_llm_model(pretrained_path: Optional[str] = None, device: str = 'cuda', numerics: Optional[Numerics] = None,

@@ -1,0 +1,82 @@
+"""Flat-buffer AdamW + warmup-cosine LR schedule (reference train_joint.py:198-226, 349-360).
+
+MI355X-first: all trainable (LoRA) parameters live in ONE contiguous fp32 buffer and their
+gradients in another, so that (a) the data-parallel exchange is a single RCCL all-reduce of one
+buffer, (b) grad-norm clipping is one reduction kernel and (c) the AdamW update is one fused
+kernel whose learning rate / step / clip coefficient are read from device memory (no host
+sync, hipGraph-replayable).  Arithmetic == torch.optim.AdamW(betas .9/.999, eps 1e-8) preceded
+by torch.nn.utils.clip_grad_norm_ (checked in tests/test_ops_gpu.py::test_adamw_flat_matches_torch)."""
+from __future__ import annotations
+
+import math
+from typing import Iterable, List, Optional
+
+import torch
+
+from .hipops import binding as cb
+
+
+def lr_lambda(step: int, warmup_steps: int, total_steps: int, min_lr: float, base_lr: float) -> float:
+    """train_joint.py:211-216 (note the reference's pi = 3.14159 and fp32 cosine)."""
+    if step < warmup_steps:
+        return step / max(1, warmup_steps)
+    progress = (step - warmup_steps) / max(1, total_steps - warmup_steps)
+    return max(min_lr / base_lr, 0.5 * (1 + torch.cos(torch.tensor(progress * 3.14159)).item()))
+
+
+class FlatAdamW:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 5e-5, weight_decay: float = 0.01,
+                 betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float = 1.0):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev = self.params[0].device
+        assert dev.type == "cuda", "FlatAdamW runs on the HIP path only"
+        n = sum(p.numel() for p in self.params)
+        self.n = n
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            assert p.dtype == torch.float32
+            self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + k].view(p.shape)
+            p.grad = self.flat_g[off:off + k].view(p.shape)
+            off += k
+        self.base_lr, self.wd, self.betas, self.eps, self.max_grad_norm = lr, weight_decay, betas, eps, max_grad_norm
+        self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def set_lr(self, lr: float):
+        self.lr_dev.fill_(lr)
+
+    def grad_norm(self, grad_scale: float = 1.0) -> torch.Tensor:
+        """L2 norm of (grad_scale * grads) as a device scalar (reads the last step()'s reduction)."""
+        return self.gnorm_sq.sqrt() * abs(grad_scale)
+
+    def step(self, grad_scale: float = 1.0):
+        """clip_grad_norm_(max_grad_norm) on grad_scale*g, then AdamW -- two kernels, no host sync."""
+        self.step_count += 1
+        self.step_dev.add_(1.0)
+        self.gnorm_sq.zero_()
+        L = cb.lib()
+        cb.check(L.cvft_sumsq(self.n, cb.ptr(self.flat_g), cb.ptr(self.gnorm_sq), cb.stream()), "cvft_sumsq")
+        cb.check(L.cvft_adamw_flat(self.n, cb.ptr(self.flat_p), cb.ptr(self.flat_g), cb.ptr(self.m), cb.ptr(self.v),
+                                   cb.ptr(self.lr_dev), self.betas[0], self.betas[1], self.eps, self.wd,
+                                   cb.ptr(self.step_dev), cb.ptr(self.gnorm_sq), float(self.max_grad_norm or 0.0),
+                                   float(grad_scale), cb.stream()), "cvft_adamw_flat")
+
+    def state_dict(self):
+        return {"m": self.m.cpu(), "v": self.v.cpu(), "step": self.step_count, "flat_p": self.flat_p.cpu()}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.flat_p.copy_(sd["flat_p"])
+        self.step_count = int(sd["step"])
+        self.step_dev.fill_(float(self.step_count))
