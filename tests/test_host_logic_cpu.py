@@ -1,0 +1,135 @@
+"""Host-side logic that needs no GPU: LR schedule, LM index maps / targets, LoRA injection + export
+key contract, data-parallel reductions over gloo (world size 2)."""
+import math
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from conftest import load_json
+
+
+def test_lr_schedule_matches_reference_run():
+    """train_joint.py:211-216 arithmetic vs the LambdaLR values recorded from the reference run."""
+    from cosyvoice_lora_finetune_framework_amd.optim import lr_lambda
+    log = load_json("train_tiny_log.json")
+    hp = log["hp"]
+    steps = [r for r in log["log"] if "lr" in r]
+    for i, r in enumerate(steps):
+        lr = hp["lr"] * lr_lambda(i, hp["warmup"], log["total_steps"], hp["min_lr"], hp["lr"])
+        assert abs(lr - r["lr"]) <= 1e-12 + 1e-7 * r["lr"], (i, lr, r["lr"])
+    assert lr_lambda(0, 50, 1000, 1e-6, 2e-4) == 0.0
+    assert lr_lambda(10 ** 6, 50, 1000, 1e-6, 2e-4) >= 1e-6 / 2e-4
+
+
+def test_lm_index_maps_match_oracle_layout():
+    """llm.py:88-95 + llm_flow_model.py:129-139 as one host-built gather map."""
+    from oracle import ref_math as R
+    from cosyvoice_lora_finetune_framework_amd.llm_model import TransformerLM
+    B, Lx, Lt = 3, 6, 9
+    text_len, sp_len = torch.tensor([6, 2, 4]), torch.tensor([9, 5, 1])
+    sp = torch.randint(0, 50, (B, Lt))
+    idx, tgt, lens, L = TransformerLM.build_index_maps(text_len, sp_len, sp, B, Lx, Lt, eos=50)
+    ref_t = R.build_lm_target(text_len, sp, sp_len, 50)
+    assert L == ref_t.shape[1] and torch.equal(tgt.view(B, L).long(), ref_t)
+    assert lens.tolist() == [3 + 6 + 9, 3 + 2 + 5, 3 + 4 + 1]
+    # emulate the gather on the host and compare with the oracle's ragged concat
+    d = 4
+    special, spk, enc, semb = torch.randn(2, d), torch.randn(B, d), torch.randn(B * Lx, d), torch.randn(B * Lt, d)
+    src = torch.cat([special, spk, enc, semb])
+    got = torch.where(idx.view(-1, 1) >= 0, src[idx.clamp(min=0).long()], torch.tensor(-1.0)).view(B, L, d)
+    for i in range(B):
+        a, b = int(text_len[i]), int(sp_len[i])
+        exp = torch.cat([special[0:1], spk[i:i + 1], enc[i * Lx:i * Lx + a], special[1:2], semb[i * Lt:i * Lt + b]])
+        assert torch.equal(got[i, :3 + a + b], exp)
+        assert bool((got[i, 3 + a + b:] == -1).all())
+
+
+def test_lora_injection_and_export_contract(tiny_meta):
+    """apply_lora_to_model stats / freezing (lora.py:134-227) and merged-key contract (lora.py:284-323) on CPU
+    parameter containers (no compute)."""
+    from cosyvoice_lora_finetune_framework_amd.flow_model import build_flow_model
+    from cosyvoice_lora_finetune_framework_amd import lora
+    fm = tiny_meta["flow"]
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in fm["build"].items()}
+    m = build_flow_model(None, 'cpu', **kw)
+    assert sorted(m.state_dict().keys()) == fm["base_keys"]
+    st = lora.apply_lora_to_model(m, r=4, lora_alpha=8, lora_dropout=0.0, target_modules=fm["lora"]["targets"])
+    assert st == fm["stats"]
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == {k: s for k, s in fm["spec"]}
+    assert all(('lora_' in n) == p.requires_grad for n, p in m.named_parameters())
+    wrapped = m.decoder.estimator.mid_blocks[0][1][0].attn1.to_q
+    assert isinstance(wrapped, lora.LoRALinear) and wrapped.scaling == 2.0
+    assert float(wrapped.lora_B.abs().sum()) > 0          # normal(0, .01), not zeros (lora.py:60-62)
+    w0 = wrapped.original_layer.weight.clone()
+    merged = lora.get_merged_state_dict(m)
+    assert sorted(merged.keys()) == fm["base_keys"]
+    delta = wrapped.lora_B @ wrapped.lora_A * 2.0
+    assert torch.allclose(merged["decoder.estimator.mid_blocks.0.1.0.attn1.to_q.weight"], w0 + delta, atol=1e-6)
+    sd = lora.get_lora_state_dict(m)
+    assert len(sd) == 2 * st["replaced_layers"]
+
+
+def test_lora_conv1d_wrapper_keys():
+    from cosyvoice_lora_finetune_framework_amd import lora
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.to_q = nn.Conv1d(8, 12, 1)
+            self.other = nn.Conv1d(8, 8, 3, padding=1)
+    net = Net()
+    st = lora.apply_lora_to_model(net, r=2, lora_alpha=4, target_modules=['to_q'])
+    assert st["replaced_layers"] == 1 and isinstance(net.to_q, lora.LoRAConv1d)
+    assert {"to_q.lora_A.weight", "to_q.lora_B.weight", "to_q.original_layer.weight"} <= set(net.state_dict())
+    merged = lora.get_merged_state_dict(net)
+    assert set(merged) == {"to_q.weight", "to_q.bias", "other.weight", "other.bias"}
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from cosyvoice_lora_finetune_framework_amd import dp
+    r, _, w = dp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    theta = torch.randn(5, requires_grad=True)          # "LoRA parameters", identical on all ranks
+    # ragged global batch of 4 samples with different denominators; rank r owns samples 2r, 2r+1
+    xs = torch.arange(20, dtype=torch.float32).view(4, 5) / 10.0
+    dens = torch.tensor([3.0, 7.0, 2.0, 5.0])
+    mine = list(dp.shard_indices(4, rank, world))
+    num_local = sum(((xs[i] * theta).sum() ** 2) * dens[i] for i in mine)        # sum over "frames"
+    den_local = sum(dens[i] for i in mine)
+    local_mean = num_local / den_local
+    wts = dp.loss_weights({"flow": float(den_local)}, torch.device("cpu"))
+    (local_mean * wts["flow"]).backward()
+    flat_g = theta.grad.clone()
+    scale = dp.allreduce_flat_grads(flat_g)
+    g_dp = flat_g * scale
+    th2 = theta.detach().clone().requires_grad_(True)
+    glob = sum(((xs[i] * th2).sum() ** 2) * dens[i] for i in range(4)) / dens.sum()
+    glob.backward()
+    m = dp.reduce_metrics(torch.tensor([float(num_local), float(den_local)]))
+    ok = torch.allclose(g_dp, th2.grad, rtol=1e-5, atol=1e-6) and abs(float(m[0] / m[1]) - float(glob)) < 1e-5
+    q.put((rank, bool(ok)))
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_equals_global_batch_gloo_world2():
+    """DP with ragged shards: weighted local means + all-reduce(sum)/world == gradient of the global-batch
+    mean (the reference's single-process loss), and the flat-bucket all-reduce plumbing."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 200
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
