@@ -218,7 +218,7 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
 
     auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     if (p.N <= 32) {
-        hipLaunchKernelGGL((gemm_kernel<T, 128, 32, 4, 1>), dim3((unsigned)tiles(128, 32)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemm_kernel<T, 32, 32, 2, 1>), dim3((unsigned)tiles(32, 32)), dim3(128), 0, st, p);
     } else if (tiles(128, 128) >= 512) {
         hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, st, p);
     } else {
@@ -332,5 +332,128 @@ extern "C" int cvft_tn_accum(int dtype, int M, int P, int Q, const void* Pm, int
         hipLaunchKernelGGL((tn_accum_kernel<bf16_t>), grid, dim3(256), 0, st, M, P, Q, (const bf16_t*)Pm, ldp,
                            (const bf16_t*)Qm, ldq, G, ldg, mpb);
     CVFT_LAUNCH_CHECK("cvft_tn_accum");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// LoRA adapter gradients, rank side r <= 64, VALU (HBM-bound: the wide operand is read once):
+//   out[j, c] (+)= sum_m Rk[m, j] * Wd[m, c]      (transpose_out = 0 :  dA[r,K] = V^T X)
+//   out[c, j] (+)= sum_m Rk[m, j] * Wd[m, c]      (transpose_out = 1 :  dB[N,r] = dY^T U)
+// Block = 64 columns x 4 rank slices (one wavefront each); the [rows x r] rank chunk is staged in
+// LDS as fp32 and read as broadcast ds_read; fp32 atomics combine the M-splits.
+// ------------------------------------------------------------------------------
+template <typename T, int RS>   // RS = rank values per thread (r = 4*RS)
+__global__ void __launch_bounds__(256) lora_rank_accum_kernel(int M, int Cn, int r, const T* __restrict__ Wd, int ldw,
+                                                               const T* __restrict__ Rk, int ldr, float* __restrict__ out,
+                                                               int ldo, int transpose_out, int rows_per_block) {
+    extern __shared__ float rk_s[];            // [CH][r]
+    constexpr int CH = 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int mb = blockIdx.y * rows_per_block;
+    const int me = min(M, mb + rows_per_block);
+    float acc[RS];
+#pragma unroll
+    for (int j = 0; j < RS; ++j) acc[j] = 0.f;
+    for (int m0 = mb; m0 < me; m0 += CH) {
+        const int nrow = min(CH, me - m0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nrow * r; e += 256) rk_s[e] = to_f32(Rk[(size_t)(m0 + e / r) * ldr + (e % r)]);
+        __syncthreads();
+        if (c < Cn) {
+            for (int mm = 0; mm < nrow; ++mm) {
+                const float wv = to_f32(Wd[(size_t)(m0 + mm) * ldw + c]);
+                const float* rp = rk_s + mm * r + w * RS;
+#pragma unroll
+                for (int j = 0; j < RS; ++j) acc[j] += wv * rp[j];
+            }
+        }
+    }
+    if (c < Cn) {
+#pragma unroll
+        for (int j = 0; j < RS; ++j) {
+            const int jj = w * RS + j;
+            float* dst = transpose_out ? &out[(size_t)c * ldo + jj] : &out[(size_t)jj * ldo + c];
+            atomicAdd(dst, acc[j]);
+        }
+    }
+}
+
+template <typename T>
+static int rank_accum_launch(int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, float* out, int ldo,
+                             int transpose_out, hipStream_t st) {
+    int colblocks = (Cn + 63) / 64;
+    int splits = (768 + colblocks - 1) / colblocks;
+    int rpb = (M + splits - 1) / splits;
+    rpb = ((rpb + 63) / 64) * 64;
+    if (rpb < 64) rpb = 64;
+    splits = (M + rpb - 1) / rpb;
+    dim3 grid(colblocks, splits);
+    size_t sm = (size_t)64 * r * sizeof(float);
+#define RA_LAUNCH(RS) hipLaunchKernelGGL((lora_rank_accum_kernel<T, RS>), grid, dim3(256), sm, st, M, Cn, r, (const T*)Wd, ldw, \
+                                         (const T*)Rk, ldr, out, ldo, transpose_out, rpb)
+    switch (r / 4) {
+        case 1: RA_LAUNCH(1); break;
+        case 2: RA_LAUNCH(2); break;
+        case 4: RA_LAUNCH(4); break;
+        case 8: RA_LAUNCH(8); break;
+        case 16: RA_LAUNCH(16); break;
+        default: return 1;
+    }
+#undef RA_LAUNCH
+    return 0;
+}
+
+extern "C" int cvft_lora_rank_accum(int dtype, int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr,
+                                    float* out, int ldo, int transpose_out, void* stream) {
+    CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_lora_rank_accum: bad dtype");
+    CVFT_CHECK_ARG(M >= 0 && Cn > 0 && r > 0 && ldw >= Cn && ldr >= r && Wd && Rk && out, "cvft_lora_rank_accum: bad args");
+    CVFT_CHECK_ARG(ldo >= (transpose_out ? r : Cn), "cvft_lora_rank_accum: bad ldo");
+    if (M == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = 1;
+    if (r % 4 == 0 && r <= 64) rc = dtype == CVFT_F32 ? rank_accum_launch<float>(M, Cn, r, Wd, ldw, Rk, ldr, out, ldo, transpose_out, st)
+                                                      : rank_accum_launch<bf16_t>(M, Cn, r, Wd, ldw, Rk, ldr, out, ldo, transpose_out, st);
+    if (rc == 1) {   // odd ranks: generic MFMA path  out = Rk^T Wd  or  Wd^T Rk
+        return transpose_out ? cvft_tn_accum(dtype, M, Cn, r, Wd, ldw, Rk, ldr, out, ldo, stream)
+                             : cvft_tn_accum(dtype, M, r, Cn, Rk, ldr, Wd, ldw, out, ldo, stream);
+    }
+    CVFT_LAUNCH_CHECK("cvft_lora_rank_accum");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// LoRA shadows: for every [rows x cols] fp32 master in the flat parameter buffer write a compute-dtype
+// (bf16) copy at the same offset of `flat_c` and a TRANSPOSED copy ([cols x rows]) at the same offset
+// of `flat_t` -- one launch per optimiser step for all adapters (32x32 LDS tiles).
+//   tiles[t] = {param offset, rows, cols, tile_row * 65536 + tile_col}
+// ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lora_shadow_kernel(const int4* __restrict__ tiles, const float* __restrict__ flat_p,
+                                                           bf16_t* __restrict__ flat_c, bf16_t* __restrict__ flat_t) {
+    __shared__ float tl[32][33];
+    const int4 d = tiles[blockIdx.x];
+    const int off = d.x, rows = d.y, cols = d.z, tr = (d.w >> 16) * 32, tc = (d.w & 0xffff) * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;     // 32 x 8
+    for (int i = ly; i < 32; i += 8) {
+        int rr = tr + i, cc = tc + lx;
+        float v = 0.f;
+        if (rr < rows && cc < cols) {
+            v = flat_p[(size_t)off + (size_t)rr * cols + cc];
+            flat_c[(size_t)off + (size_t)rr * cols + cc] = (bf16_t)v;
+        }
+        tl[i][lx] = v;
+    }
+    __syncthreads();
+    for (int i = ly; i < 32; i += 8) {
+        int cc = tc + i, rr = tr + lx;
+        if (rr < rows && cc < cols) flat_t[(size_t)off + (size_t)cc * rows + rr] = (bf16_t)tl[lx][i];
+    }
+}
+extern "C" int cvft_lora_shadow(int ntiles, const void* tiles, const float* flat_p, void* flat_c, void* flat_t, void* stream) {
+    CVFT_CHECK_ARG(ntiles >= 0 && tiles && flat_p && flat_c && flat_t, "cvft_lora_shadow: bad args");
+    if (ntiles == 0) return 0;
+    hipLaunchKernelGGL(lora_shadow_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, (const int4*)tiles, flat_p,
+                       (bf16_t*)flat_c, (bf16_t*)flat_t);
+    CVFT_LAUNCH_CHECK("cvft_lora_shadow");
     return 0;
 }

@@ -25,7 +25,7 @@ def _gemm_kernel_name(M: int, N: int, dtype: torch.dtype) -> str:
     """Mirror of the tile selection in csrc/gemm.hip::gemm_launch."""
     t = "bf16" if dtype == torch.bfloat16 else "f32"
     if N <= 32:
-        return f"gemm_kernel<{t},128,32,4,1>"
+        return f"gemm_kernel<{t},32,32,2,1>"
     if -(-M // 128) * -(-N // 128) >= 512:
         return f"gemm_kernel<{t},128,128,2,2>"
     return f"gemm_kernel<{t},64,64,2,2>"
@@ -161,41 +161,74 @@ class LinearPack:
         return self._Wb
 
 
+def rank_accum(Wd: torch.Tensor, Rk: torch.Tensor, out: torch.Tensor, transpose_out: bool) -> None:
+    """out[r,C] += Rk^T Wd (transpose_out=False) or out[C,r] += Wd^T Rk (True); out fp32, accumulated in place."""
+    assert Wd.shape[0] == Rk.shape[0] and out.dtype == torch.float32 and out.is_contiguous()
+    Cn, r = Wd.shape[1], Rk.shape[1]
+    assert tuple(out.shape[:2]) == ((Cn, r) if transpose_out else (r, Cn))
+    check(lib().cvft_lora_rank_accum(dt(Wd), Wd.shape[0], Cn, r, ptr(Wd), Wd.stride(0), ptr(Rk), Rk.stride(0), ptr(out),
+                                     r if transpose_out else Cn, int(transpose_out), stream()), "cvft_lora_rank_accum")
+
+
+def _lora_operands(P: torch.Tensor, dtype):
+    """(compute-dtype copy, transposed copy) of a LoRA master; uses the per-step shadows maintained by
+    optim.FlatAdamW when present (one kernel per step for all adapters), else casts on the fly."""
+    sh = getattr(P, "_cvft_shadow", None)
+    if sh is not None and dtype == torch.bfloat16 and getattr(P, "_cvft_shadow_ver", -1) == P._version:
+        return sh
+    Pc = P.detach().to(dtype)
+    return _c(Pc), Pc.t().contiguous()
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b + scale * (x A^T) B^T) (+ residual): reference lora.py:64-76 as ONE
-    GEMM launch plus a rank-r pre-GEMM; backward = dgrad (+ rank-r side path) and dA/dB."""
+    GEMM launch plus a rank-r pre-GEMM; backward = dgrad (+ rank-r side path) and dA/dB, the latter
+    accumulated straight into the parameters' (flat) .grad buffers when those exist."""
 
     @staticmethod
     def forward(ctx, x, A, B, residual, pack: LinearPack, scale: float, act: Optional[str]):
         x = _c(x)
         has_lora = A is not None
         need_grad = any(ctx.needs_input_grad[:3])
-        U = Ac = Bc = None
+        U = None
+        ops = None
         if has_lora:
-            Ac, Bc = A.detach().to(x.dtype), B.detach().to(x.dtype)
-            U = gemm(x, _c(Ac), alpha=scale)
+            Ac, At = _lora_operands(A, x.dtype)
+            Bc, Bt = _lora_operands(B, x.dtype)
+            ops = (Ac, At, Bc, Bt)
+            U = gemm(x, Ac, alpha=scale)
         z = torch.empty((x.shape[0], pack.N), dtype=x.dtype, device=x.device) if (act and need_grad) else None
-        y = gemm(x, pack.Wf, bias=pack.bias, U=U, Bl=Bc, act=act, preact=z, residual=None if residual is None else _c(residual))
+        y = gemm(x, pack.Wf, bias=pack.bias, U=U, Bl=None if ops is None else ops[2], act=act, preact=z,
+                 residual=None if residual is None else _c(residual))
         ctx.pack, ctx.scale, ctx.act, ctx.has_lora = pack, scale, act, has_lora
-        ctx.save_for_backward(x, U, z, Ac, Bc)
+        ctx.ops, ctx.A_ref, ctx.B_ref = ops, A, B
+        ctx.save_for_backward(x, U, z)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, U, z, Ac, Bc = ctx.saved_tensors
+        x, U, z = ctx.saved_tensors
         dy = _c(dy)
         dz = act_bwd(z, dy, ctx.act) if ctx.act else dy
         dx = dA = dB = None
         V = None
         if ctx.has_lora:
-            V = gemm(dz, Bc.t().contiguous(), alpha=ctx.scale)          # [M, r] = s * dz B
+            Ac, At, Bc, Bt = ctx.ops
+            V = gemm(dz, Bt, alpha=ctx.scale)                             # [M, r] = s * dz B
         if ctx.needs_input_grad[0]:
-            dx = gemm(dz, ctx.pack.Wb, U=V, Bl=None if V is None else Ac.t().contiguous())
-        if ctx.has_lora:
-            dA = torch.zeros(Ac.shape, dtype=torch.float32, device=x.device)
-            dB = torch.zeros(Bc.shape, dtype=torch.float32, device=x.device)
-            tn_accum(V, x, dA)
-            tn_accum(dz, U, dB)
+            dx = gemm(dz, ctx.pack.Wb, U=V, Bl=None if V is None else At)
+        if ctx.has_lora and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            A, B = ctx.A_ref, ctx.B_ref
+            gA, gB = A.grad, B.grad
+            direct = gA is not None and gB is not None and gA.dtype == torch.float32 and gA.is_contiguous() \
+                and gB.is_contiguous() and gA.dim() == 2 and gB.dim() == 2
+            if not direct:
+                gA = torch.zeros(Ac.shape, dtype=torch.float32, device=x.device)
+                gB = torch.zeros(Bc.shape, dtype=torch.float32, device=x.device)
+            rank_accum(x, V, gA, False)                                   # dA[r,K] += V^T x
+            rank_accum(dz, U, gB, True)                                   # dB[N,r] += dz^T U
+            if not direct:
+                dA, dB = gA, gB
         dres = dy if ctx.needs_input_grad[3] else None
         return dx, dA, dB, dres, None, None, None
 

@@ -45,11 +45,35 @@ class FlatAdamW:
             p.data = self.flat_p[off:off + k].view(p.shape)
             p.grad = self.flat_g[off:off + k].view(p.shape)
             off += k
+        # compute-dtype shadows (bf16 copy + transposed bf16 copy) of every adapter, refreshed by ONE kernel per
+        # optimiser step; LinearFn picks them up through P._cvft_shadow
+        self.flat_c = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        self.flat_t = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        tiles = []
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            rows = p.shape[0]
+            cols = k // rows
+            if p.dim() == 2:
+                p._cvft_shadow = (self.flat_c[off:off + k].view(rows, cols), self.flat_t[off:off + k].view(cols, rows))
+            for tr in range(-(-rows // 32)):
+                for tc in range(-(-cols // 32)):
+                    tiles.append((off, rows, cols, (tr << 16) | tc))
+            off += k
+        self.tiles = torch.tensor(tiles, dtype=torch.int32, device=dev).contiguous()
         self.base_lr, self.wd, self.betas, self.eps, self.max_grad_norm = lr, weight_decay, betas, eps, max_grad_norm
         self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self.refresh_shadows()
+
+    def refresh_shadows(self):
+        cb.check(cb.lib().cvft_lora_shadow(self.tiles.shape[0], cb.ptr(self.tiles), cb.ptr(self.flat_p), cb.ptr(self.flat_c),
+                                           cb.ptr(self.flat_t), cb.stream()), "cvft_lora_shadow")
+        for p in self.params:            # in-place edits of a master (load_lora_weights, ...) bump _version => on-the-fly cast
+            p._cvft_shadow_ver = p._version
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -72,6 +96,7 @@ class FlatAdamW:
                                    cb.ptr(self.lr_dev), self.betas[0], self.betas[1], self.eps, self.wd,
                                    cb.ptr(self.step_dev), cb.ptr(self.gnorm_sq), float(self.max_grad_norm or 0.0),
                                    float(grad_scale), cb.stream()), "cvft_adamw_flat")
+        self.refresh_shadows()
 
     def state_dict(self):
         return {"m": self.m.cpu(), "v": self.v.cpu(), "step": self.step_count, "flat_p": self.flat_p.cpu()}
@@ -80,3 +105,4 @@ class FlatAdamW:
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.flat_p.copy_(sd["flat_p"])
         self.step_count = int(sd["step"])
         self.step_dev.fill_(float(self.step_count))
+        self.refresh_shadows()

@@ -86,6 +86,15 @@ int cvft_gemm(const cvft_gemm_args* a, void* stream);
 int cvft_tn_accum(int dtype, int M, int P, int Q, const void* Pm, int ldp, const void* Qm, int ldq,
                   float* G, int ldg, void* stream);
 
+/* Same gradients with the rank side r (multiple of 4, <= 64) on a VALU kernel that reads the wide operand
+ * once:  transpose_out = 0: out[r][C] += Rk^T Wd   (dA = V^T X);   transpose_out = 1: out[C][r] += Wd^T Rk
+ * (dB = dY^T U).  Wd [M][C], Rk [M][r]; out fp32 (atomics). Other ranks fall back to cvft_tn_accum. */
+int cvft_lora_rank_accum(int dtype, int M, int C, int r, const void* Wd, int ldw, const void* Rk, int ldr,
+                         float* out, int ldo, int transpose_out, void* stream);
+/* One launch per optimiser step: bf16 copy (flat_c) and transposed bf16 copy (flat_t) of every LoRA master in
+ * the flat fp32 buffer.  tiles: int32[ntiles][4] = {offset, rows, cols, tile_row<<16 | tile_col} (32x32 tiles). */
+int cvft_lora_shadow(int ntiles, const void* tiles, const float* flat_p, void* flat_c, void* flat_t, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * LayerNorm over the channel axis (+ optional ReLU, + optional post-scale).
  * Replaces nn.LayerNorm (+ReLU, + x*sqrt(d)) in encoder_layer.py:90-106,

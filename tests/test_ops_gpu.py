@@ -369,3 +369,45 @@ def test_adamw_flat_matches_torch():
         cb.check(cb.lib().cvft_adamw_flat(n, cb.ptr(p), cb.ptr(gd), cb.ptr(m), cb.ptr(v), cb.ptr(lr), 0.9, 0.999, 1e-8,
                                           0.01, cb.ptr(st), cb.ptr(ss), 1.0, 1.0, cb.stream()))
         assert rel(p, pr.data) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("r", [4, 16, 64, 6])
+def test_lora_rank_accum(dtype, r):
+    """dA = V^T X and dB = dY^T U on the VALU rank kernel (r % 4 == 0) / MFMA fallback (r = 6)."""
+    HF = HFmod()
+    M, Cn = 1237, 200
+    wd, rk = q(rnd(M, Cn, seed=1), dtype), q(rnd(M, r, seed=2), dtype)
+    ref = rk.double().t() @ wd.double()
+    out = torch.ones(r, Cn, device=DEV)
+    HF.rank_accum(wd.to(DEV, dtype), rk.to(DEV, dtype), out, False)
+    assert rel(out - 1.0, ref) < 1e-5
+    out_t = torch.zeros(Cn, r, device=DEV)
+    HF.rank_accum(wd.to(DEV, dtype), rk.to(DEV, dtype), out_t, True)
+    assert rel(out_t, ref.t()) < 1e-5
+
+
+def test_flat_adamw_shadows_and_direct_grads():
+    """FlatAdamW: flat views, bf16 + transposed shadows refreshed per step, LoRA grads accumulated in place."""
+    from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
+    HF = HFmod()
+    lin = torch.nn.Linear(96, 160).to(DEV)
+    A = torch.nn.Parameter(rnd(8, 96, seed=1).to(DEV) * 0.1)
+    Bm = torch.nn.Parameter(rnd(160, 8, seed=2).to(DEV) * 0.1)
+    opt = FlatAdamW([A, Bm], lr=1e-2)
+    assert A.data_ptr() == opt.flat_p.data_ptr() and A.grad.data_ptr() == opt.flat_g.data_ptr()
+    assert rel(A._cvft_shadow[0], A) < 4e-3 and rel(A._cvft_shadow[1], A.t()) < 4e-3
+    assert rel(Bm._cvft_shadow[1], Bm.t()) < 4e-3
+    pack = HF.LinearPack(lin.weight, lin.bias, torch.bfloat16)
+    x = rnd(300, 96, seed=3).to(DEV, torch.bfloat16).requires_grad_(True)
+    for it in range(2):
+        y = HF.lora_linear(x, pack, A, Bm, 2.0)
+        y.float().pow(2).mean().backward()
+        g0 = opt.flat_g.clone()
+        assert float(g0.abs().sum()) > 0
+        a_before = A.detach().clone()
+        opt.step()
+        opt.zero_grad()
+        assert float((A.detach() - a_before).abs().sum()) > 0
+        assert rel(A._cvft_shadow[0], A) < 4e-3 and rel(Bm._cvft_shadow[1], Bm.t()) < 4e-3
+        assert float(opt.flat_g.abs().sum()) == 0.0
