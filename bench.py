@@ -130,7 +130,8 @@ def main():
 
     def fwd_bwd():
         out = jm(batch, dev)
-        out['loss'].backward()
+        with HF.LoraGradSink():
+            out['loss'].backward()
         return out['loss'].detach()
 
     graph = None

@@ -6,6 +6,16 @@
 // modules.py:60-120 & matcha/models/components/decoder.py:35-158, and their dgrad.
 #include "common.cuh"
 
+#include <utility>
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 template <typename T>
 struct GP {
     int M, N, K, Tm, Tin, Tout, in_stride, out_stride, out_off, ntaps;
@@ -24,21 +34,21 @@ struct GP {
     const T* residual; int ldr;
     T* C; int ldc;
     int vecA, vecW, vecU, vecB;   // 16-byte vector loads legal for that operand
+    unsigned bytesA, bytesW, bytesU, bytesB;   // buffer extents for the hardware range check
 };
 
-template <typename T>
-__device__ __forceinline__ uint4 load_chunk(const T* base, int kk, int klim, bool rowok, bool vec) {
-    constexpr int VEC = 16 / sizeof(T);
-    uint4 r = make_uint4(0, 0, 0, 0);
-    if (!rowok || kk >= klim) return r;
-    if (vec) return *reinterpret_cast<const uint4*>(base + kk);
-    T tmp[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) tmp[e] = (kk + e < klim) ? base[kk + e] : from_f32<T>(0.f);
-    return *reinterpret_cast<uint4*>(tmp);
-}
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#define CVFT_OOB 0x80000000u      // byte offset past every buffer (< 2 GiB each, host-checked): the load returns 0
 
-template <typename T, int BM, int BN, int WM, int WN>
+// Main loop: the K extent (all taps, then the rank-r LoRA segment) is cut into BK-wide tiles.  D tiles
+// are kept in flight in registers (these GEMMs are small and latency-bound: the lever is bytes in
+// flight), LDS is double-buffered with ONE barrier per tile.  AL = every operand 16-byte aligned and
+// K % VEC == 0: operand chunks are raw buffer loads (hardware range check => no predication branches,
+// 32-bit offsets, and a statically known number of outstanding loads so hipcc emits counted vmcnt waits:
+// loads past the last tile are issued anyway and return zeros).  !AL: guarded element loads.
+// Epilogue: accumulators -> LDS (fp32) -> 16-byte coalesced row segments with the whole
+// bias/act/act'/residual/mask chain applied on the vectors.
+template <typename T, int BM, int BN, int WM, int WN, int D, bool AL>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
     constexpr int NT = WM * WN * 64;
     constexpr int VEC = 16 / sizeof(T);
@@ -49,18 +59,29 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
     constexpr int MI = TM / 16, NI = TN / 16;
     constexpr int A_IT = (BM * CPR + NT - 1) / NT;
     constexpr int W_IT = (BN * CPR + NT - 1) / NT;
+    constexpr bool A_FULL = (BM * CPR) % NT == 0, W_FULL = (BN * CPR) % NT == 0;
+    constexpr int CLD = BN + 4;
     typedef Mma<T> MM;
 
-    __shared__ __attribute__((aligned(16))) T As[BM * LD];
-    __shared__ __attribute__((aligned(16))) T Ws[BN * LD];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* As = reinterpret_cast<T*>(smem_raw);                 // [2][BM*LD]
+    T* Ws = As + 2 * BM * LD;                               // [2][BN*LD]
+    float* Cs = reinterpret_cast<float*>(smem_raw);         // [BM][CLD] (aliases the operand ring after the loop)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM;
-    const int n0 = (blockIdx.x % tiles_n) * BN;
+    // XCD-aware remap (blocks are dealt round-robin over the 8 XCDs): give each XCD a contiguous range of
+    // tile ids, n fastest, so the n-tiles that share an A row panel -- and the W panel they all read --
+    // hit the same 4 MiB L2.  Bijective for any grid size (speed only, never correctness).
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rm = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+    }
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
 
-    // per-thread staging slots: row decode is loop invariant
     int a_row[A_IT], a_cc[A_IT], a_b[A_IT], a_t[A_IT], a_len[A_IT];
     bool a_ok[A_IT];
 #pragma unroll
@@ -69,7 +90,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
         a_row[i] = c / CPR;
         a_cc[i] = c % CPR;
         int m = m0 + a_row[i];
-        a_ok[i] = (c < BM * CPR) && (m < p.M);
+        a_ok[i] = (A_FULL || c < BM * CPR) && (m < p.M);
         int b = a_ok[i] ? m / p.Tm : 0;
         a_b[i] = b;
         a_t[i] = a_ok[i] ? m - b * p.Tm : 0;
@@ -82,7 +103,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
         int c = tid + i * NT;
         w_row[i] = c / CPR;
         w_cc[i] = c % CPR;
-        w_ok[i] = (c < BN * CPR) && (n0 + w_row[i] < p.N);
+        w_ok[i] = (W_FULL || c < BN * CPR) && (n0 + w_row[i] < p.N);
     }
 
     f32x4 acc[MI][NI];
@@ -95,101 +116,236 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
     const int nk_lora = (p.R > 0) ? (p.R + BK - 1) / BK : 0;
     const int n_it = p.ntaps * nk_main + nk_lora;
 
-    uint4 ra[A_IT], rw[W_IT];
+    uint4 ra[D][A_IT], rw[D][W_IT];
 
-    auto gload = [&](int it) {
-        if (it < p.ntaps * nk_main) {
-            const int seg = it / nk_main;
-            const int k0 = (it - seg * nk_main) * BK;
+    // Loader state machine (tiles are requested strictly in order): per-slot offsets are set up once per
+    // segment (tap / LoRA), only the k offset advances per tile.
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.A), 0, p.bytesA, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.W), 0, p.bytesW, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.U), 0, p.bytesU, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.Bl), 0, p.bytesB, 0x00020000);
+    unsigned oa[A_IT], ow[W_IT];          // AL: byte offsets (CVFT_OOB = invalid row)
+    const T* pa[A_IT];                    // !AL: row pointers
+    const T* pw[W_IT];
+    bool va[A_IT], vw[W_IT];
+    int ld_seg = -1, ld_kt = 0, ld_nk = 0, ld_klim = 0;
+    auto seg_setup = [&](int seg) __attribute__((always_inline)) {
+        if (seg < p.ntaps) {
             const int toff = p.tap_off[seg];
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 int ti = a_t[i] * p.in_stride + toff;
-                bool ok = a_ok[i] && ti >= 0 && ti < p.Tin && ti < a_len[i];
-                const T* base = p.A + (size_t)(a_b[i] * p.Tin + (ok ? ti : 0)) * p.lda;
-                ra[i] = load_chunk<T>(base, k0 + a_cc[i] * VEC, p.K, ok, p.vecA);
+                va[i] = a_ok[i] && ti >= 0 && ti < p.Tin && ti < a_len[i];
+                const size_t e = (size_t)(a_b[i] * p.Tin + (va[i] ? ti : 0)) * p.lda + a_cc[i] * VEC;
+                oa[i] = va[i] ? (unsigned)(e * sizeof(T)) : CVFT_OOB;
+                pa[i] = p.A + e;
             }
 #pragma unroll
             for (int i = 0; i < W_IT; ++i) {
-                const T* base = p.W + (size_t)(w_ok[i] ? n0 + w_row[i] : 0) * p.ldw + (size_t)seg * p.K;
-                rw[i] = load_chunk<T>(base, k0 + w_cc[i] * VEC, p.K, w_ok[i], p.vecW);
+                vw[i] = w_ok[i];
+                const size_t e = (size_t)(w_ok[i] ? n0 + w_row[i] : 0) * p.ldw + (size_t)seg * p.K + w_cc[i] * VEC;
+                ow[i] = vw[i] ? (unsigned)(e * sizeof(T)) : CVFT_OOB;
+                pw[i] = p.W + e;
             }
+            ld_klim = p.K;
+            ld_nk = nk_main;
         } else {
-            const int k0 = (it - p.ntaps * nk_main) * BK;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                int m = m0 + a_row[i];
-                const T* base = p.U + (size_t)(a_ok[i] ? m : 0) * p.ldu;
-                ra[i] = load_chunk<T>(base, k0 + a_cc[i] * VEC, p.R, a_ok[i], p.vecU);
+                va[i] = a_ok[i] && p.R > 0;
+                const size_t e = (size_t)(a_ok[i] ? m0 + a_row[i] : 0) * p.ldu + a_cc[i] * VEC;
+                oa[i] = va[i] ? (unsigned)(e * sizeof(T)) : CVFT_OOB;
+                pa[i] = p.U + e;
             }
 #pragma unroll
             for (int i = 0; i < W_IT; ++i) {
-                const T* base = p.Bl + (size_t)(w_ok[i] ? n0 + w_row[i] : 0) * p.ldbl;
-                rw[i] = load_chunk<T>(base, k0 + w_cc[i] * VEC, p.R, w_ok[i], p.vecB);
+                vw[i] = w_ok[i] && p.R > 0;
+                const size_t e = (size_t)(w_ok[i] ? n0 + w_row[i] : 0) * p.ldbl + w_cc[i] * VEC;
+                ow[i] = vw[i] ? (unsigned)(e * sizeof(T)) : CVFT_OOB;
+                pw[i] = p.Bl + e;
+            }
+            ld_klim = p.R;
+            ld_nk = 0x3fffffff;           // terminal segment: later tiles fall beyond ld_klim and load zeros
+        }
+        ld_seg = seg;
+        ld_kt = 0;
+    };
+    auto gload = [&](uint4 (&ra_)[A_IT], uint4 (&rw_)[W_IT]) __attribute__((always_inline)) {
+        if (ld_kt == ld_nk) seg_setup(ld_seg + 1);
+        const int k0 = ld_kt * BK;
+        const bool lora = ld_seg >= p.ntaps;
+        if (AL) {
+            const __amdgpu_buffer_rsrc_t ra_src = lora ? rsU : rsA;
+            const __amdgpu_buffer_rsrc_t rw_src = lora ? rsB : rsW;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const unsigned off = (k0 + a_cc[i] * VEC < ld_klim) ? oa[i] + (unsigned)(k0 * sizeof(T)) : CVFT_OOB;
+                u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra_src, (int)off, 0, 0);
+                ra_[i] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < W_IT; ++i) {
+                const unsigned off = (k0 + w_cc[i] * VEC < ld_klim) ? ow[i] + (unsigned)(k0 * sizeof(T)) : CVFT_OOB;
+                u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw_src, (int)off, 0, 0);
+                rw_[i] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                T tmp[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int kk = k0 + a_cc[i] * VEC + e;
+                    tmp[e] = (va[i] && kk < ld_klim) ? pa[i][k0 + e] : from_f32<T>(0.f);
+                }
+                ra_[i] = *reinterpret_cast<uint4*>(tmp);
+            }
+#pragma unroll
+            for (int i = 0; i < W_IT; ++i) {
+                T tmp[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int kk = k0 + w_cc[i] * VEC + e;
+                    tmp[e] = (vw[i] && kk < ld_klim) ? pw[i][k0 + e] : from_f32<T>(0.f);
+                }
+                rw_[i] = *reinterpret_cast<uint4*>(tmp);
             }
         }
+        ld_kt += 1;
     };
-    auto sstore = [&]() {
+    auto sstore = [&](int buf, const uint4 (&ra_)[A_IT], const uint4 (&rw_)[W_IT]) __attribute__((always_inline)) {
+        T* Ab = As + buf * BM * LD;
+        T* Wb = Ws + buf * BN * LD;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            if (tid + i * NT < BM * CPR) *reinterpret_cast<uint4*>(&As[a_row[i] * LD + a_cc[i] * VEC]) = ra[i];
+            if (A_FULL || tid + i * NT < BM * CPR) *reinterpret_cast<uint4*>(&Ab[a_row[i] * LD + a_cc[i] * VEC]) = ra_[i];
 #pragma unroll
         for (int i = 0; i < W_IT; ++i)
-            if (tid + i * NT < BN * CPR) *reinterpret_cast<uint4*>(&Ws[w_row[i] * LD + w_cc[i] * VEC]) = rw[i];
+            if (W_FULL || tid + i * NT < BN * CPR) *reinterpret_cast<uint4*>(&Wb[w_row[i] * LD + w_cc[i] * VEC]) = rw_[i];
     };
-
-    gload(0);
-    sstore();
-    __syncthreads();
-    for (int it = 0; it < n_it; ++it) {
-        if (it + 1 < n_it) gload(it + 1);
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const T* Ab = As + buf * BM * LD;
+        const T* Wb = Ws + buf * BN * LD;
 #pragma unroll
         for (int ks = 0; ks < BK; ks += MM::K) {
             typename MM::Frag a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = MM::load(&As[(wm * TM + i * 16 + (lane & 15)) * LD + ks], lane);
+            for (int i = 0; i < MI; ++i) a[i] = MM::load(&Ab[(wm * TM + i * 16 + (lane & 15)) * LD + ks], lane);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = MM::load(&Ws[(wn * TN + j * 16 + (lane & 15)) * LD + ks], lane);
+            for (int j = 0; j < NI; ++j) b[j] = MM::load(&Wb[(wn * TN + j * 16 + (lane & 15)) * LD + ks], lane);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) MM::mma(acc[i][j], a[i], b[j]);
         }
-        __syncthreads();
-        if (it + 1 < n_it) {
-            sstore();
+    };
+
+    seg_setup(0);
+    // prologue: tiles 0..D-1 in flight, tile 0 staged, its register set refilled with tile D
+    static_for<D>([&](auto dc) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        gload(ra[d], rw[d]);
+    });
+    sstore(0, ra[0], rw[0]);
+    gload(ra[0], rw[0]);
+    __syncthreads();
+    // steady state: stage tile it+1 (register set dn) into the other LDS buffer, refill that set with
+    // tile it+1+D, compute tile it.  No data-dependent control flow between the loads and their use.
+    int it0 = 0;
+    for (; it0 + D <= n_it; it0 += D) {
+        static_for<D>([&](auto dc) __attribute__((always_inline)) {
+            constexpr int d = decltype(dc)::value;
+            constexpr int dn = (d + 1) % D;
+            const int it = it0 + d;
+            sstore((it + 1) & 1, ra[dn], rw[dn]);
+            gload(ra[dn], rw[dn]);
+            compute(it & 1);
+            __syncthreads();
+        });
+    }
+    static_for<D>([&](auto dc) __attribute__((always_inline)) {      // remainder (< D tiles), block-uniform
+        constexpr int d = decltype(dc)::value;
+        constexpr int dn = (d + 1) % D;
+        const int it = it0 + d;
+        if (it < n_it) {
+            sstore((it + 1) & 1, ra[dn], rw[dn]);
+            compute(it & 1);
             __syncthreads();
         }
-    }
+    });
 
     // ------------------------------------------------------------- epilogue
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[(wm * TM + i * 16 + (lane >> 4) * 4 + r) * CLD + wn * TN + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
     const bool ident = (p.Tm == p.M) && p.out_stride == 1 && p.out_off == 0;
+    const bool vec_out = (p.N % VEC == 0) && (p.ldc % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                         (!p.preact || ((p.ldp % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.preact) & 15) == 0))) &&
+                         (!p.dact_src || ((p.ldd % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.dact_src) & 15) == 0))) &&
+                         (!p.residual || ((p.ldr % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
+    constexpr int CPRO = BN / VEC;                 // output chunks per tile row
+    for (int c = tid; c < BM * CPRO; c += NT) {
+        const int row = c / CPRO, cc = c % CPRO;
+        const int m = m0 + row;
+        const int nb = n0 + cc * VEC;
+        if (m >= p.M || nb >= p.N) continue;
+        int b = 0, to = m;
+        if (!ident) {
+            b = m / p.Tm;
+            to = (m - b * p.Tm) * p.out_stride + p.out_off;
+            if (to >= p.Tout) continue;
+        }
+        const size_t orow = (size_t)b * p.Tout + to;
+        const bool live = p.out_len ? (to < p.out_len[b]) : true;
+        float v[VEC];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+        for (int e = 0; e < VEC; ++e) {
+            const int n = nb + e;
+            float x = Cs[row * CLD + cc * VEC + e] * p.alpha;
+            if (p.bias && n < p.N) x += p.bias[n];
+            v[e] = x;
+        }
+        if (vec_out) {
+            T tmp[VEC];
+            if (p.preact) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int m = m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r;
-            if (m >= p.M) continue;
-            int b = 0, to = m;
-            if (!ident) {
-                b = m / p.Tm;
-                to = (m - b * p.Tm) * p.out_stride + p.out_off;
-                if (to >= p.Tout) continue;
+                for (int e = 0; e < VEC; ++e) tmp[e] = from_f32<T>(v[e]);
+                *reinterpret_cast<uint4*>(&p.preact[orow * p.ldp + nb]) = *reinterpret_cast<uint4*>(tmp);
             }
-            size_t orow = (size_t)b * p.Tout + to;
-            bool live = p.out_len ? (to < p.out_len[b]) : true;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                int n = n0 + wn * TN + j * 16 + (lane & 15);
+            for (int e = 0; e < VEC; ++e) v[e] = act_apply(p.act, v[e]);
+            if (p.dact_src) {
+                uint4 dv = *reinterpret_cast<const uint4*>(&p.dact_src[orow * p.ldd + nb]);
+                const T* de = reinterpret_cast<const T*>(&dv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] *= act_grad(p.dact, to_f32(de[e]));
+            }
+            if (p.residual) {
+                uint4 rv = *reinterpret_cast<const uint4*>(&p.residual[orow * p.ldr + nb]);
+                const T* re = reinterpret_cast<const T*>(&rv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] += to_f32(re[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tmp[e] = from_f32<T>(live ? v[e] : 0.f);
+            *reinterpret_cast<uint4*>(&p.C[orow * p.ldc + nb]) = *reinterpret_cast<uint4*>(tmp);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int n = nb + e;
                 if (n >= p.N) continue;
-                float v = acc[i][j][r] * p.alpha;
-                if (p.bias) v += p.bias[n];
-                if (p.preact) p.preact[orow * p.ldp + n] = from_f32<T>(v);
-                v = act_apply(p.act, v);
-                if (p.dact_src) v *= act_grad(p.dact, to_f32(p.dact_src[orow * p.ldd + n]));
-                if (p.residual) v += to_f32(p.residual[orow * p.ldr + n]);
-                if (!live) v = 0.f;
-                p.C[orow * p.ldc + n] = from_f32<T>(v);
+                float x = v[e];
+                if (p.preact) p.preact[orow * p.ldp + n] = from_f32<T>(x);
+                x = act_apply(p.act, x);
+                if (p.dact_src) x *= act_grad(p.dact, to_f32(p.dact_src[orow * p.ldd + n]));
+                if (p.residual) x += to_f32(p.residual[orow * p.ldr + n]);
+                if (!live) x = 0.f;
+                p.C[orow * p.ldc + n] = from_f32<T>(x);
             }
         }
     }
@@ -197,6 +353,28 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
 
 template <typename T>
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T, int BM, int BN, int WM, int WN, int D, bool AL>
+static int gemm_launch_cfg(const GP<T>& p, hipStream_t st) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int BK = (sizeof(T) == 2) ? 64 : 16;
+    constexpr int LD = BK + VEC;
+    size_t ring = (size_t)2 * (BM + BN) * LD * sizeof(T);
+    size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
+    size_t sm = ring > cs ? ring : cs;
+    auto kern = gemm_kernel<T, BM, BN, WM, WN, D, AL>;
+    if (sm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            cvft_set_error("cvft_gemm: hipFuncSetAttribute(%zu) failed: %s", sm, hipGetErrorString(e));
+            return -2;
+        }
+    }
+    long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, p);
+    CVFT_LAUNCH_CHECK("cvft_gemm");
+    return 0;
+}
 
 template <typename T>
 static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
@@ -216,16 +394,18 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
     p.vecU = p.R > 0 && (p.R % VEC == 0) && (a->ldu % VEC == 0) && al16<T>(a->U);
     p.vecB = p.R > 0 && (p.R % VEC == 0) && (a->ldbl % VEC == 0) && al16<T>(a->Bl);
 
-    auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-    if (p.N <= 32) {
-        hipLaunchKernelGGL((gemm_kernel<T, 32, 32, 2, 1>), dim3((unsigned)tiles(32, 32)), dim3(128), 0, st, p);
-    } else if (tiles(128, 128) >= 512) {
-        hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2>), dim3((unsigned)tiles(128, 128)), dim3(256), 0, st, p);
-    } else {
-        hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2>), dim3((unsigned)tiles(64, 64)), dim3(256), 0, st, p);
+    const size_t bA = (size_t)(p.M / p.Tm) * p.Tin * p.lda * sizeof(T), bW = (size_t)p.N * p.ldw * sizeof(T);
+    const size_t bU = p.R > 0 ? (size_t)p.M * p.ldu * sizeof(T) : 0, bB = p.R > 0 ? (size_t)p.N * p.ldbl * sizeof(T) : 0;
+    const size_t lim = 0x7fff0000u;
+    p.bytesA = (unsigned)bA; p.bytesW = (unsigned)bW; p.bytesU = (unsigned)bU; p.bytesB = (unsigned)bB;
+    long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const bool al = p.vecA && p.vecW && (p.R == 0 || (p.vecU && p.vecB)) && bA < lim && bW < lim && bU < lim && bB < lim;
+    if (al) {
+        if (p.N <= 32) return gemm_launch_cfg<T, 32, 32, 2, 1, 4, true>(p, st);
+        if (t128 >= 256) return gemm_launch_cfg<T, 128, 128, 2, 2, 3, true>(p, st);
+        return gemm_launch_cfg<T, 64, 64, 2, 2, 4, true>(p, st);
     }
-    CVFT_LAUNCH_CHECK("cvft_gemm");
-    return 0;
+    return gemm_launch_cfg<T, 64, 64, 2, 2, 2, false>(p, st);     // unaligned / odd-K operands: generic element loads
 }
 
 extern "C" int cvft_gemm(const cvft_gemm_args* a, void* stream) {
@@ -379,10 +559,105 @@ __global__ void __launch_bounds__(256) lora_rank_accum_kernel(int M, int Cn, int
     }
 }
 
+// v3 (aligned operands, r == 16 * k): one block = 64 columns x (4 waves x RW rows).  Each wave issues ALL
+// its 16-byte row-segment loads up front (8 lanes cover a 64-column segment of one row, 8 rows per
+// wave-instruction), accumulates every rank for its rows in registers, the 4 waves are combined through
+// LDS and each output element gets ONE fp32 atomic per block, issued as 256-byte-contiguous wave-instructions.
+template <typename T, int RW>
+__global__ void __launch_bounds__(256) lora_rank_accum_vec_kernel(int M, int Cn, int r, const T* __restrict__ Wd, int ldw,
+                                                                   const T* __restrict__ Rk, int ldr,
+                                                                   float* __restrict__ out, int ldo, int transpose_out,
+                                                                   size_t part_stride) {
+    // part_stride != 0: deterministic two-stage mode -- block row y writes its slab to out + y*part_stride with
+    // plain stores (no atomics; cvft_lora_grad_reduce sums the slabs).  part_stride == 0: fp32 atomics into out.
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int CG = 64 / VEC;        // lanes per 64-column row segment
+    constexpr int RG = 64 / CG;         // rows per wave-instruction
+    constexpr int NL = RW / RG;         // load instructions per wave
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane / CG;
+    const int c = blockIdx.x * 64 + (lane % CG) * VEC;
+    const int row0 = blockIdx.y * (4 * RW) + w * RW + g;
+    const bool cok = c < Cn;
+    uint4 wv[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int row = row0 + u * RG;
+        wv[u] = (cok && row < M) ? *reinterpret_cast<const uint4*>(Wd + (size_t)row * ldw + c) : make_uint4(0, 0, 0, 0);
+    }
+    for (int j0 = 0; j0 < r; j0 += 16) {
+        float acc[16][VEC];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[j][e] = 0.f;
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int row = row0 + u * RG;
+            T rk[16];
+            if (row < M) {
+#pragma unroll
+                for (int q = 0; q < 16 / VEC; ++q)
+                    *reinterpret_cast<uint4*>(&rk[q * VEC]) = *reinterpret_cast<const uint4*>(Rk + (size_t)row * ldr + j0 + q * VEC);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) rk[j] = from_f32<T>(0.f);
+            }
+            const T* we = reinterpret_cast<const T*>(&wv[u]);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float rv = to_f32(rk[j]);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[j][e] += rv * to_f32(we[e]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float v = acc[j][e];
+#pragma unroll
+                for (int o = CG; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (g == 0) red[w][j][(lane % CG) * VEC + e] = v;
+            }
+        __syncthreads();
+        const int cl = blockIdx.x * 64 + lane;
+        if (cl < Cn) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = w * 4 + jj;
+                const float v = red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane];
+                float* base = out + (size_t)blockIdx.y * part_stride;
+                float* dst = transpose_out ? &base[(size_t)cl * ldo + j0 + j] : &base[(size_t)(j0 + j) * ldo + cl];
+                if (part_stride) *dst = v; else atomicAdd(dst, v);
+            }
+        }
+    }
+}
+
 template <typename T>
 static int rank_accum_launch(int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, float* out, int ldo,
-                             int transpose_out, hipStream_t st) {
+                             int transpose_out, hipStream_t st, int part_rows = 0) {
+    constexpr int VEC = 16 / sizeof(T);
+    const bool vec = (Cn % VEC == 0) && (ldw % VEC == 0) && ((reinterpret_cast<uintptr_t>(Wd) & 15) == 0) &&
+                     (r % 16 == 0) && (ldr % VEC == 0) && ((reinterpret_cast<uintptr_t>(Rk) & 15) == 0);
     int colblocks = (Cn + 63) / 64;
+    if (part_rows && !vec) return 2;
+    if (vec) {
+        // rows per block 64 / 128 / 256: the largest that still gives >= 512 blocks (or the caller's choice)
+        int RW = 64;
+        while (RW > 16 && (long)colblocks * ((M + 4 * RW - 1) / (4 * RW)) < 512) RW >>= 1;
+        if (part_rows) RW = part_rows / 4;
+        const size_t part_stride = part_rows ? (size_t)r * Cn : 0;
+        dim3 grid(colblocks, (M + 4 * RW - 1) / (4 * RW));
+#define RV_LAUNCH(RWv) hipLaunchKernelGGL((lora_rank_accum_vec_kernel<T, RWv>), grid, dim3(256), 0, st, M, Cn, r, (const T*)Wd, \
+                                          ldw, (const T*)Rk, ldr, out, ldo, transpose_out, part_stride)
+        if (RW == 64) RV_LAUNCH(64); else if (RW == 32) RV_LAUNCH(32); else RV_LAUNCH(16);
+#undef RV_LAUNCH
+        return 0;
+    }
     int splits = (768 + colblocks - 1) / colblocks;
     int rpb = (M + splits - 1) / splits;
     rpb = ((rpb + 63) / 64) * 64;
@@ -419,6 +694,42 @@ extern "C" int cvft_lora_rank_accum(int dtype, int M, int Cn, int r, const void*
                              : cvft_tn_accum(dtype, M, r, Cn, Rk, ldr, Wd, ldw, out, ldo, stream);
     }
     CVFT_LAUNCH_CHECK("cvft_lora_rank_accum");
+    return 0;
+}
+
+// Two-stage (deterministic, atomic-free) form: slabs, then ONE reduce launch for every adapter of the step.
+extern "C" int cvft_lora_rank_partial(int dtype, int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr,
+                                      float* part, int transpose_out, int rows_per_block, void* stream) {
+    CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_lora_rank_partial: bad dtype");
+    CVFT_CHECK_ARG(M > 0 && Cn > 0 && r > 0 && r % 16 == 0 && ldw >= Cn && ldr >= r && Wd && Rk && part, "cvft_lora_rank_partial: bad args");
+    CVFT_CHECK_ARG(rows_per_block == 64 || rows_per_block == 128 || rows_per_block == 256, "cvft_lora_rank_partial: rows_per_block must be 64/128/256");
+    hipStream_t st = (hipStream_t)stream;
+    int ldo = transpose_out ? r : Cn;
+    int rc = dtype == CVFT_F32 ? rank_accum_launch<float>(M, Cn, r, Wd, ldw, Rk, ldr, part, ldo, transpose_out, st, rows_per_block)
+                               : rank_accum_launch<bf16_t>(M, Cn, r, Wd, ldw, Rk, ldr, part, ldo, transpose_out, st, rows_per_block);
+    CVFT_CHECK_ARG(rc == 0, "cvft_lora_rank_partial: operands must be 16-byte aligned with C %% VEC == 0");
+    CVFT_LAUNCH_CHECK("cvft_lora_rank_partial");
+    return 0;
+}
+
+// tasks[t] = {slab base, grad base, numel, nsplit} (int64 x 4):  grad[i] += sum_s slab[s*numel + i], fixed order.
+__global__ void __launch_bounds__(256) lora_grad_reduce_kernel(const long long* __restrict__ tasks) {
+    const long long* t = tasks + (size_t)blockIdx.y * 4;
+    const float* slab = reinterpret_cast<const float*>(t[0]);
+    float* grad = reinterpret_cast<float*>(t[1]);
+    const long long numel = t[2];
+    const int nsplit = (int)t[3];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * numel + i];
+        grad[i] += s;
+    }
+}
+extern "C" int cvft_lora_grad_reduce(int ntasks, const void* tasks, int max_blocks_x, void* stream) {
+    CVFT_CHECK_ARG(ntasks >= 0 && tasks && max_blocks_x > 0, "cvft_lora_grad_reduce: bad args");
+    if (ntasks == 0) return 0;
+    hipLaunchKernelGGL(lora_grad_reduce_kernel, dim3(max_blocks_x, ntasks), dim3(256), 0, (hipStream_t)stream, (const long long*)tasks);
+    CVFT_LAUNCH_CHECK("cvft_lora_grad_reduce");
     return 0;
 }
 

@@ -26,7 +26,7 @@ def _gemm_kernel_name(M: int, N: int, dtype: torch.dtype) -> str:
     t = "bf16" if dtype == torch.bfloat16 else "f32"
     if N <= 32:
         return f"gemm_kernel<{t},32,32,2,1>"
-    if -(-M // 128) * -(-N // 128) >= 512:
+    if -(-M // 128) * -(-N // 128) >= 256:
         return f"gemm_kernel<{t},128,128,2,2>"
     return f"gemm_kernel<{t},64,64,2,2>"
 
@@ -170,6 +170,71 @@ def rank_accum(Wd: torch.Tensor, Rk: torch.Tensor, out: torch.Tensor, transpose_
                                      r if transpose_out else Cn, int(transpose_out), stream()), "cvft_lora_rank_accum")
 
 
+class LoraGradSink:
+    """Deterministic, atomic-free LoRA gradient accumulation for a whole backward pass:
+
+        with LoraGradSink():
+            loss.backward()
+
+    Inside the context every LoRA layer writes per-row-block fp32 slabs of dA / dB into a persistent
+    per-parameter workspace (cvft_lora_rank_partial); on exit ONE kernel (cvft_lora_grad_reduce) adds the
+    slabs of all adapters into their .grad buffers in a fixed order.  Without an active sink the layers use
+    the fp32-atomic kernel directly.  The task table lives on the device and is rebuilt only when the set of
+    (workspace, grad, shape) tuples changes, so a captured hipGraph replays it unchanged."""
+    active = None
+    _cache = {}
+
+    def __init__(self):
+        self.tasks = []
+
+    def __enter__(self):
+        assert LoraGradSink.active is None, "LoraGradSink is not re-entrant"
+        LoraGradSink.active = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        LoraGradSink.active = None
+        if et is None:
+            self.flush()
+        return False
+
+    @staticmethod
+    def plan(M: int, Cn: int):
+        """rows per block (64/128/256) and number of slabs for an [M, Cn] wide operand."""
+        colblocks = -(-Cn // 64)
+        rpb = 256
+        while rpb > 64 and colblocks * (-(-M // rpb)) < 512:
+            rpb //= 2
+        return rpb, -(-M // rpb)
+
+    @staticmethod
+    def workspace(P: torch.Tensor, nsplit: int) -> torch.Tensor:
+        need = nsplit * P.numel()
+        ws = getattr(P, "_cvft_part", None)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.float32, device=P.device)
+            P._cvft_part = ws
+        return ws
+
+    def add(self, part: torch.Tensor, grad: torch.Tensor, numel: int, nsplit: int):
+        self.tasks.append((part.data_ptr(), grad.data_ptr(), numel, nsplit))
+
+    def flush(self):
+        if not self.tasks:
+            return
+        key = tuple(self.tasks)
+        ent = LoraGradSink._cache.get(key)
+        if ent is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            tbl = torch.tensor(self.tasks, dtype=torch.int64).to(dev)
+            ent = (tbl, min(64, max(1, -(-max(t[2] for t in self.tasks) // 1024))))
+            if len(LoraGradSink._cache) > 8:
+                LoraGradSink._cache.clear()
+            LoraGradSink._cache[key] = ent
+        check(lib().cvft_lora_grad_reduce(len(self.tasks), ptr(ent[0]), ent[1], stream()), "cvft_lora_grad_reduce")
+        self.tasks = []
+
+
 def _lora_operands(P: torch.Tensor, dtype):
     """(compute-dtype copy, transposed copy) of a LoRA master; uses the per-step shadows maintained by
     optim.FlatAdamW when present (one kernel per step for all adapters), else casts on the fly."""
@@ -225,8 +290,21 @@ class LinearFn(torch.autograd.Function):
             if not direct:
                 gA = torch.zeros(Ac.shape, dtype=torch.float32, device=x.device)
                 gB = torch.zeros(Bc.shape, dtype=torch.float32, device=x.device)
-            rank_accum(x, V, gA, False)                                   # dA[r,K] += V^T x
-            rank_accum(dz, U, gB, True)                                   # dB[N,r] += dz^T U
+            sink = LoraGradSink.active
+            r = V.shape[1]
+            vec = 8 if x.dtype == torch.bfloat16 else 4
+            if (sink is not None and direct and r % 16 == 0 and x.shape[1] % vec == 0 and dz.shape[1] % vec == 0
+                    and x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0):
+                M = x.shape[0]
+                for Wd, Rk, P, g, tr in ((x, V, A, gA, False), (dz, U, B, gB, True)):
+                    rpb, ns = LoraGradSink.plan(M, Wd.shape[1])
+                    ws = LoraGradSink.workspace(P, ns)
+                    check(lib().cvft_lora_rank_partial(dt(Wd), M, Wd.shape[1], r, ptr(Wd), Wd.stride(0), ptr(Rk), Rk.stride(0),
+                                                       ptr(ws), int(tr), rpb, stream()), "cvft_lora_rank_partial")
+                    sink.add(ws, g, P.numel(), ns)
+            else:
+                rank_accum(x, V, gA, False)                               # dA[r,K] += V^T x
+                rank_accum(dz, U, gB, True)                               # dB[N,r] += dz^T U
             if not direct:
                 dA, dB = gA, gB
         dres = dy if ctx.needs_input_grad[3] else None

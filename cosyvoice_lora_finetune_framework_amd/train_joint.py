@@ -21,6 +21,7 @@ import torch
 
 from . import dp
 from .config import JOINT_TRAINING_CONFIG, MI355X_CONFIG, OUTPUT_DIR, PRETRAINED_MODEL_DIR, TRAIN_CONFIG
+from .hipops.functional import LoraGradSink
 from .modules import Numerics
 from .optim import FlatAdamW, lr_lambda
 
@@ -185,7 +186,8 @@ class Trainer:
                     total = losses['loss']
                 else:
                     total = sum(losses[f"{k}_loss"] * w[k] for k in ("llm", "flow") if f"{k}_loss" in losses)
-                (total / self.accum).backward()
+                with LoraGradSink():
+                    (total / self.accum).backward()
                 ep_sum += torch.stack([losses[k].detach().float() if k in losses else ep_sum.new_zeros(()) for k in keys])
                 ep_cnt += 1
                 rec = None

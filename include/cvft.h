@@ -91,6 +91,13 @@ int cvft_tn_accum(int dtype, int M, int P, int Q, const void* Pm, int ldp, const
  * (dB = dY^T U).  Wd [M][C], Rk [M][r]; out fp32 (atomics). Other ranks fall back to cvft_tn_accum. */
 int cvft_lora_rank_accum(int dtype, int M, int C, int r, const void* Wd, int ldw, const void* Rk, int ldr,
                          float* out, int ldo, int transpose_out, void* stream);
+/* Deterministic two-stage form of the same gradients (no atomics): stage 1 writes one fp32 slab per row block
+ * (part[s][r][C] or part[s][C][r], s < ceil(M / rows_per_block), rows_per_block in {64,128,256}; operands 16-byte
+ * aligned, r % 16 == 0); stage 2 is ONE launch for all adapters: tasks int64[ntasks][4] = {slab ptr, grad ptr,
+ * numel, nsplit}, grad[i] += sum_s slab[s*numel + i] in fixed order. */
+int cvft_lora_rank_partial(int dtype, int M, int C, int r, const void* Wd, int ldw, const void* Rk, int ldr,
+                           float* part, int transpose_out, int rows_per_block, void* stream);
+int cvft_lora_grad_reduce(int ntasks, const void* tasks, int max_blocks_x, void* stream);
 /* One launch per optimiser step: bf16 copy (flat_c) and transposed bf16 copy (flat_t) of every LoRA master in
  * the flat fp32 buffer.  tiles: int32[ntiles][4] = {offset, rows, cols, tile_row<<16 | tile_col} (32x32 tiles). */
 int cvft_lora_shadow(int ntiles, const void* tiles, const float* flat_p, void* flat_c, void* flat_t, void* stream);

@@ -411,3 +411,26 @@ def test_flat_adamw_shadows_and_direct_grads():
         assert float((A.detach() - a_before).abs().sum()) > 0
         assert rel(A._cvft_shadow[0], A) < 4e-3 and rel(Bm._cvft_shadow[1], Bm.t()) < 4e-3
         assert float(opt.flat_g.abs().sum()) == 0.0
+
+
+def test_lora_grad_sink_matches_atomic_path_and_is_deterministic():
+    """two-stage slabs + single reduce launch == atomic kernel (to fp32 rounding), bitwise reproducible."""
+    from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
+    HF = HFmod()
+    lin = torch.nn.Linear(256, 512).to(DEV)
+    A = torch.nn.Parameter(rnd(16, 256, seed=1).to(DEV) * 0.1)
+    Bm = torch.nn.Parameter(rnd(512, 16, seed=2).to(DEV) * 0.1)
+    opt = FlatAdamW([A, Bm], lr=1e-2)
+    pack = HF.LinearPack(lin.weight, lin.bias, torch.bfloat16)
+    x = rnd(1500, 256, seed=3).to(DEV, torch.bfloat16).requires_grad_(True)
+    gy = rnd(1500, 512, seed=4).to(DEV, torch.bfloat16)
+    HF.lora_linear(x, pack, A, Bm, 2.0).backward(gy)
+    g_atomic = opt.flat_g.clone()
+    runs = []
+    for _ in range(2):
+        opt.zero_grad()
+        with HF.LoraGradSink():
+            HF.lora_linear(x, pack, A, Bm, 2.0).backward(gy)
+        runs.append(opt.flat_g.clone())
+    assert torch.equal(runs[0], runs[1])
+    assert rel(runs[0], g_atomic) < 1e-5
