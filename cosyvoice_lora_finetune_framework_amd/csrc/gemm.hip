@@ -4,6 +4,7 @@
 //
 // Replaces (reference): lora.py:64-76, nn.Linear/Conv1d/ConvTranspose1d calls of
 // modules.py:60-120 & matcha/models/components/decoder.py:35-158, and their dgrad.
+#include <stdlib.h>
 #include "common.cuh"
 
 #include <utility>
@@ -401,8 +402,26 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
     long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     const bool al = p.vecA && p.vecW && (p.R == 0 || (p.vecU && p.vecB)) && bA < lim && bW < lim && bU < lim && bB < lim;
     if (al) {
+        if constexpr (sizeof(T) == 2) {          // experiment hook: CVFT_GEMM_CFG selects a tile configuration
+            static const int cfg = getenv("CVFT_GEMM_CFG") ? atoi(getenv("CVFT_GEMM_CFG")) : 0;
+            if (cfg && p.N > 32) {
+                switch (cfg) {
+                    case 1: return gemm_launch_cfg<T, 128, 128, 2, 2, 2, true>(p, st);
+                    case 2: return gemm_launch_cfg<T, 128, 128, 4, 2, 3, true>(p, st);
+                    case 3: return gemm_launch_cfg<T, 256, 128, 4, 2, 2, true>(p, st);
+                    case 4: return gemm_launch_cfg<T, 128, 256, 2, 4, 2, true>(p, st);
+                    case 5: return gemm_launch_cfg<T, 64, 64, 2, 2, 4, true>(p, st);
+                    case 6: return gemm_launch_cfg<T, 128, 64, 2, 2, 4, true>(p, st);
+                    default: break;
+                }
+            }
+        }
         if (p.N <= 32) return gemm_launch_cfg<T, 32, 32, 2, 1, 4, true>(p, st);
-        if (t128 >= 256) return gemm_launch_cfg<T, 128, 128, 2, 2, 3, true>(p, st);
+        // measured on MI355X (tools/bench_kernels.py, CVFT_GEMM_CFG sweep): 64x64 tiles with 4 k-tiles in flight win
+        // on every step shape up to K = 1024; long-K GEMMs (w_2 dgrad / forward, K = 4096) prefer 256x128 x 8 waves.
+        if constexpr (sizeof(T) == 2) {
+            if (p.ntaps * p.K >= 2048 && t128 >= 256) return gemm_launch_cfg<T, 256, 128, 4, 2, 2, true>(p, st);
+        }
         return gemm_launch_cfg<T, 64, 64, 2, 2, 4, true>(p, st);
     }
     return gemm_launch_cfg<T, 64, 64, 2, 2, 2, false>(p, st);     // unaligned / odd-K operands: generic element loads

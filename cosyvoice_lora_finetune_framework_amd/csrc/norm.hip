@@ -108,24 +108,45 @@ extern "C" int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, con
 }
 
 // ------------------------------------------------------------------ GroupNorm + Mish
-// stats: one block per (b, g); elements (t, cc) with cc fastest => Cg-element runs per frame.
-template <typename T>
-__global__ void __launch_bounds__(256) gn_stats_kernel(int T_, int C, int G, const T* __restrict__ x, float eps,
+// stats: one block per (b, g); the group's (T x Cg) slab is walked in 16-byte chunks (Cg % VEC == 0) so that
+// each frame's Cg-channel run is read with full-width loads.
+template <typename T, bool VECP>
+__global__ void __launch_bounds__(512) gn_stats_kernel(int T_, int C, int G, const T* __restrict__ x, float eps,
                                                         float* __restrict__ mean, float* __restrict__ rstd) {
+    constexpr int VEC = VECP ? 16 / sizeof(T) : 1;
     __shared__ float sm[16];
     const int b = blockIdx.x / G, g = blockIdx.x % G;
-    const int Cg = C / G;
+    const int Cg = C / G, CgV = Cg / VEC;
     const T* xb = x + (size_t)b * T_ * C + g * Cg;
-    const int n = T_ * Cg;
+    const int nch = T_ * CgV;
+    const float n = (float)T_ * (float)Cg;
     float s = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) s += to_f32(xb[(size_t)(e / Cg) * C + (e % Cg)]);
-    const float mu = block_sum(s, sm) / (float)n;
-    float v = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) {
-        float d = to_f32(xb[(size_t)(e / Cg) * C + (e % Cg)]) - mu;
-        v += d * d;
+    for (int e = threadIdx.x; e < nch; e += 512) {
+        const T* p = xb + (size_t)(e / CgV) * C + (e % CgV) * VEC;
+        if (VECP) {
+            uint4 v = *reinterpret_cast<const uint4*>(p);
+            const T* ve = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s += to_f32(ve[k]);
+        } else {
+            s += to_f32(*p);
+        }
     }
-    const float var = block_sum(v, sm) / (float)n;
+    const float mu = block_sum(s, sm) / n;
+    float v2 = 0.f;
+    for (int e = threadIdx.x; e < nch; e += 512) {
+        const T* p = xb + (size_t)(e / CgV) * C + (e % CgV) * VEC;
+        if (VECP) {
+            uint4 v = *reinterpret_cast<const uint4*>(p);
+            const T* ve = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { float d = to_f32(ve[k]) - mu; v2 += d * d; }
+        } else {
+            float d = to_f32(*p) - mu;
+            v2 += d * d;
+        }
+    }
+    const float var = block_sum(v2, sm) / n;
     if (threadIdx.x == 0) {
         mean[blockIdx.x] = mu;
         rstd[blockIdx.x] = 1.0f / sqrtf(var + eps);
@@ -155,39 +176,52 @@ __global__ void __launch_bounds__(256) gn_apply_fwd_kernel(int B, int T_, int C,
     }
 }
 
-// backward stats: s1 = sum(gamma*dz), s2 = sum(gamma*dz*xhat) over the group
-template <typename T>
-__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(int T_, int C, int G, const T* __restrict__ x,
+// backward stats: s1 = sum(gamma*dz), s2 = sum(gamma*dz*xhat) over the group (same chunked walk)
+template <typename T, bool VECP>
+__global__ void __launch_bounds__(512) gn_bwd_stats_kernel(int T_, int C, int G, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const int* __restrict__ len,
                                                             int apply_mish, const T* __restrict__ dy,
                                                             float* __restrict__ ws) {
+    constexpr int VEC = VECP ? 16 / sizeof(T) : 1;
     __shared__ float sm[16];
     const int b = blockIdx.x / G, g = blockIdx.x % G;
-    const int Cg = C / G;
+    const int Cg = C / G, CgV = Cg / VEC;
     const size_t off = (size_t)b * T_ * C + g * Cg;
-    const int n = T_ * Cg;
+    const float n = (float)T_ * (float)Cg;
     const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
-    const int lb = len ? len[b] : T_;
+    const int lb = len ? min(len[b], T_) : T_;
+    const int nch = lb * CgV;                   // frames t >= len contribute nothing
     float s1 = 0.f, s2 = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) {
-        int t = e / Cg, cc = e % Cg, c = g * Cg + cc;
-        if (t >= lb) continue;
-        size_t i = off + (size_t)t * C + cc;
-        float xh = (to_f32(x[i]) - mu) * rs;
-        float dz = to_f32(dy[i]);
-        if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c] + beta[c]);
-        dz *= gamma[c];
-        s1 += dz;
-        s2 += dz * xh;
+    for (int e = threadIdx.x; e < nch; e += 512) {
+        const int t = e / CgV, cc = (e % CgV) * VEC;
+        const size_t i = off + (size_t)t * C + cc;
+        T xv[VEC], dv[VEC];
+        if (VECP) {
+            *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + i);
+            *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(dy + i);
+        } else {
+            xv[0] = x[i];
+            dv[0] = dy[i];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = g * Cg + cc + k;
+            float xh = (to_f32(xv[k]) - mu) * rs;
+            float dz = to_f32(dv[k]);
+            if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c] + beta[c]);
+            dz *= gamma[c];
+            s1 += dz;
+            s2 += dz * xh;
+        }
     }
     s1 = block_sum(s1, sm);
     s2 = block_sum(s2, sm);
     if (threadIdx.x == 0) {
-        ws[blockIdx.x * 2 + 0] = s1 / (float)n;
-        ws[blockIdx.x * 2 + 1] = s2 / (float)n;
+        ws[blockIdx.x * 2 + 0] = s1 / n;
+        ws[blockIdx.x * 2 + 1] = s2 / n;
     }
 }
 
@@ -231,12 +265,16 @@ extern "C" int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, co
     CVFT_CHECK_ARG(x && gamma && beta && y && mean && rstd, "cvft_groupnorm_mish_fwd: null operand");
     hipStream_t st = (hipStream_t)stream;
     size_t total = (size_t)B * T * C;
+    const int vec = dtype == CVFT_F32 ? 4 : 8;
+    const bool vp = ((C / G) % vec == 0) && (C % vec == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     if (dtype == CVFT_F32) {
-        hipLaunchKernelGGL((gn_stats_kernel<float>), dim3(B * G), dim3(256), 0, st, T, C, G, (const float*)x, eps, mean, rstd);
+        if (vp) hipLaunchKernelGGL((gn_stats_kernel<float, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, eps, mean, rstd);
+        else hipLaunchKernelGGL((gn_stats_kernel<float, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, eps, mean, rstd);
         hipLaunchKernelGGL((gn_apply_fwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
                            (const float*)x, gamma, beta, mean, rstd, len, (const float*)add, apply_mish, (float*)y);
     } else {
-        hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), dim3(B * G), dim3(256), 0, st, T, C, G, (const bf16_t*)x, eps, mean, rstd);
+        if (vp) hipLaunchKernelGGL((gn_stats_kernel<bf16_t, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, eps, mean, rstd);
+        else hipLaunchKernelGGL((gn_stats_kernel<bf16_t, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, eps, mean, rstd);
         hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
                            (const bf16_t*)x, gamma, beta, mean, rstd, len, (const bf16_t*)add, apply_mish, (bf16_t*)y);
     }
@@ -252,13 +290,19 @@ extern "C" int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, co
     CVFT_CHECK_ARG(x && gamma && beta && mean && rstd && dy && dx && ws, "cvft_groupnorm_mish_bwd: null operand");
     hipStream_t st = (hipStream_t)stream;
     size_t total = (size_t)B * T * C;
+    const int vec = dtype == CVFT_F32 ? 4 : 8;
+    const bool vp = ((C / G) % vec == 0) && (C % vec == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0);
     if (dtype == CVFT_F32) {
-        hipLaunchKernelGGL((gn_bwd_stats_kernel<float>), dim3(B * G), dim3(256), 0, st, T, C, G, (const float*)x, gamma,
+        if (vp) hipLaunchKernelGGL((gn_bwd_stats_kernel<float, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, gamma,
+                                   beta, mean, rstd, len, apply_mish, (const float*)dy, ws);
+        else hipLaunchKernelGGL((gn_bwd_stats_kernel<float, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, gamma,
                            beta, mean, rstd, len, apply_mish, (const float*)dy, ws);
         hipLaunchKernelGGL((gn_apply_bwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
                            (const float*)x, gamma, beta, mean, rstd, len, apply_mish, (const float*)dy, ws, (float*)dx);
     } else {
-        hipLaunchKernelGGL((gn_bwd_stats_kernel<bf16_t>), dim3(B * G), dim3(256), 0, st, T, C, G, (const bf16_t*)x, gamma,
+        if (vp) hipLaunchKernelGGL((gn_bwd_stats_kernel<bf16_t, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, gamma,
+                                   beta, mean, rstd, len, apply_mish, (const bf16_t*)dy, ws);
+        else hipLaunchKernelGGL((gn_bwd_stats_kernel<bf16_t, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, gamma,
                            beta, mean, rstd, len, apply_mish, (const bf16_t*)dy, ws);
         hipLaunchKernelGGL((gn_apply_bwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
                            (const bf16_t*)x, gamma, beta, mean, rstd, len, apply_mish, (const bf16_t*)dy, ws, (bf16_t*)dx);

@@ -8,6 +8,7 @@ only: every other parameter is frozen by ``lora.apply_lora_to_model``
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
@@ -21,18 +22,26 @@ from .binding import ACT, GemmArgs, check, dt, lib, ptr, stream
 PROFILE = None   # bench.py sets this to a list: every tap-GEMM launch is then bracketed by HIP events
 
 
-def _gemm_kernel_name(M: int, N: int, dtype: torch.dtype) -> str:
+def _gemm_kernel_name(M: int, N: int, dtype: torch.dtype, Ktot: int = 0) -> str:
     """Mirror of the tile selection in csrc/gemm.hip::gemm_launch."""
     t = "bf16" if dtype == torch.bfloat16 else "f32"
     if N <= 32:
         return f"gemm_kernel<{t},32,32,2,1>"
-    if -(-M // 128) * -(-N // 128) >= 256:
-        return f"gemm_kernel<{t},128,128,2,2>"
+    if dtype == torch.bfloat16 and Ktot >= 2048 and -(-M // 128) * -(-N // 128) >= 256:
+        return f"gemm_kernel<{t},256,128,4,2>"
     return f"gemm_kernel<{t},64,64,2,2>"
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _rowc(t: torch.Tensor) -> torch.Tensor:
+    """Row-contiguous 2-D view with a 16-byte aligned pitch is enough for the GEMM-family kernels (they take a
+    leading dimension): column slices of a fused buffer (dq|dk|dv) are consumed in place, no copy."""
+    if t.dim() == 2 and t.stride(1) == 1 and (t.stride(0) * t.element_size()) % 16 == 0 and t.data_ptr() % 16 == 0:
+        return t
+    return t.contiguous()
 
 
 # ---------------------------------------------------------------------------------
@@ -101,7 +110,7 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
         e0.record()
         check(lib().cvft_gemm(C.byref(a), stream()), "cvft_gemm")
         e1.record()
-        PROFILE.append({"kernel": _gemm_kernel_name(a.M, N, x.dtype), "start": e0, "end": e1,
+        PROFILE.append({"kernel": _gemm_kernel_name(a.M, N, x.dtype, ntaps * K), "start": e0, "end": e1,
                         "flop": 2.0 * a.M * N * (ntaps * K + (a.R if U is not None else 0))})
         return out
     check(lib().cvft_gemm(C.byref(a), stream()), "cvft_gemm")
@@ -183,9 +192,16 @@ class LoraGradSink:
     (workspace, grad, shape) tuples changes, so a captured hipGraph replays it unchanged."""
     active = None
     _cache = {}
+    _side = None
 
-    def __init__(self):
+    def __init__(self, side_stream: bool = True):
         self.tasks = []
+        self.keep = []                    # operands of side-stream launches stay alive until the join
+        self.side = None
+        if side_stream:
+            if LoraGradSink._side is None:
+                LoraGradSink._side = torch.cuda.Stream()
+            self.side = LoraGradSink._side
 
     def __enter__(self):
         assert LoraGradSink.active is None, "LoraGradSink is not re-entrant"
@@ -222,6 +238,9 @@ class LoraGradSink:
     def flush(self):
         if not self.tasks:
             return
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.keep = []
         key = tuple(self.tasks)
         ent = LoraGradSink._cache.get(key)
         if ent is None:
@@ -273,7 +292,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, U, z = ctx.saved_tensors
-        dy = _c(dy)
+        dy = _c(dy) if ctx.act else _rowc(dy)
         dz = act_bwd(z, dy, ctx.act) if ctx.act else dy
         dx = dA = dB = None
         V = None
@@ -296,12 +315,20 @@ class LinearFn(torch.autograd.Function):
             if (sink is not None and direct and r % 16 == 0 and x.shape[1] % vec == 0 and dz.shape[1] % vec == 0
                     and x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0):
                 M = x.shape[0]
-                for Wd, Rk, P, g, tr in ((x, V, A, gA, False), (dz, U, B, gB, True)):
-                    rpb, ns = LoraGradSink.plan(M, Wd.shape[1])
-                    ws = LoraGradSink.workspace(P, ns)
-                    check(lib().cvft_lora_rank_partial(dt(Wd), M, Wd.shape[1], r, ptr(Wd), Wd.stride(0), ptr(Rk), Rk.stride(0),
-                                                       ptr(ws), int(tr), rpb, stream()), "cvft_lora_rank_partial")
-                    sink.add(ws, g, P.numel(), ns)
+                # the slab kernels are off the critical path (nothing downstream in backward reads them): launch them
+                # on the sink's side stream so they overlap the latency-bound dgrad chain; joined in sink.flush()
+                cur = torch.cuda.current_stream()
+                ctxm = torch.cuda.stream(sink.side) if sink.side is not None else contextlib.nullcontext()
+                if sink.side is not None:
+                    sink.side.wait_stream(cur)
+                    sink.keep.append((x, V, dz, U))
+                with ctxm:
+                    for Wd, Rk, P, g, tr in ((x, V, A, gA, False), (dz, U, B, gB, True)):
+                        rpb, ns = LoraGradSink.plan(M, Wd.shape[1])
+                        ws = LoraGradSink.workspace(P, ns)
+                        check(lib().cvft_lora_rank_partial(dt(Wd), M, Wd.shape[1], r, ptr(Wd), Wd.stride(0), ptr(Rk),
+                                                           Rk.stride(0), ptr(ws), int(tr), rpb, stream()), "cvft_lora_rank_partial")
+                        sink.add(ws, g, P.numel(), ns)
             else:
                 rank_accum(x, V, gA, False)                               # dA[r,K] += V^T x
                 rank_accum(dz, U, gB, True)                               # dB[N,r] += dz^T U

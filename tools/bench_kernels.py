@@ -45,7 +45,9 @@ for M, N, K in shapes:
     t = timeit(lambda: HF.gemm(x, w, bias=b, U=u, Bl=bl, out=out))
     t2 = timeit(lambda: torch.nn.functional.linear(x, w))
     fl = 2 * M * N * (K + 16)
-    print(f"  M{M:5d} N{N:5d} K{K:5d}: {t:7.1f} us  {fl / t / 1e6:7.1f} TF/s   [{HF._gemm_kernel_name(M, N, dt)}]   hipBLASLt {t2:7.1f} us {2*M*N*K/t2/1e6:7.1f} TF/s")
+    print(f"  M{M:5d} N{N:5d} K{K:5d}: {t:7.1f} us  {fl / t / 1e6:7.1f} TF/s   [{HF._gemm_kernel_name(M, N, dt, K)}]   hipBLASLt {t2:7.1f} us {2*M*N*K/t2/1e6:7.1f} TF/s")
+if os.environ.get("ONLY_MAIN"):
+    sys.exit(0)
 print("skinny (U = s x A^T):")
 for M, K in [(4000, 256), (8000, 256), (4640, 512), (5328, 1024), (5328, 4096)]:
     x = torch.randn(M, K, device=dev, dtype=dt)
