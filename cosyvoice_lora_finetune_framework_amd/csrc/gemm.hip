@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(256) lora_rank_accum_vec_kernel(int M, int Cn,
     constexpr int CG = 64 / VEC;        // lanes per 64-column row segment
     constexpr int RG = 64 / CG;         // rows per wave-instruction
     constexpr int NL = RW / RG;         // load instructions per wave
-    __shared__ float red[4][16][64];
+    extern __shared__ float red[];      // [4 waves][RG row groups][16][64]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane / CG;
     const int c = blockIdx.x * 64 + (lane % CG) * VEC;
@@ -631,27 +631,26 @@ __global__ void __launch_bounds__(256) lora_rank_accum_vec_kernel(int M, int Cn,
                 for (int e = 0; e < VEC; ++e) acc[j][e] += rv * to_f32(we[e]);
             }
         }
+        // combine the RG row groups x 4 waves through LDS (wide ds_write, conflict-free column reads); a register
+        // xor-shuffle tree here cost ~18 us of exposed ds_bpermute latency per launch
         __syncthreads();
+        float* mine = red + (size_t)((w * RG + g) * 16) * 64 + (lane % CG) * VEC;
 #pragma unroll
         for (int j = 0; j < 16; ++j)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                float v = acc[j][e];
-#pragma unroll
-                for (int o = CG; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-                if (g == 0) red[w][j][(lane % CG) * VEC + e] = v;
-            }
+            for (int q = 0; q < VEC / 4; ++q)
+                *reinterpret_cast<float4*>(mine + j * 64 + q * 4) = make_float4(acc[j][q * 4], acc[j][q * 4 + 1], acc[j][q * 4 + 2], acc[j][q * 4 + 3]);
         __syncthreads();
-        const int cl = blockIdx.x * 64 + lane;
-        if (cl < Cn) {
+        for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+            const int j = idx >> 6, col = idx & 63;
+            const int cl = blockIdx.x * 64 + col;
+            if (cl >= Cn) continue;
+            float v = 0.f;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = w * 4 + jj;
-                const float v = red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane];
-                float* base = out + (size_t)blockIdx.y * part_stride;
-                float* dst = transpose_out ? &base[(size_t)cl * ldo + j0 + j] : &base[(size_t)(j0 + j) * ldo + cl];
-                if (part_stride) *dst = v; else atomicAdd(dst, v);
-            }
+            for (int s2 = 0; s2 < 4 * RG; ++s2) v += red[(size_t)(s2 * 16 + j) * 64 + col];
+            float* base = out + (size_t)blockIdx.y * part_stride;
+            float* dst = transpose_out ? &base[(size_t)cl * ldo + j0 + j] : &base[(size_t)(j0 + j) * ldo + cl];
+            if (part_stride) *dst = v; else atomicAdd(dst, v);
         }
     }
 }
@@ -671,8 +670,14 @@ static int rank_accum_launch(int M, int Cn, int r, const void* Wd, int ldw, cons
         if (part_rows) RW = part_rows / 4;
         const size_t part_stride = part_rows ? (size_t)r * Cn : 0;
         dim3 grid(colblocks, (M + 4 * RW - 1) / (4 * RW));
-#define RV_LAUNCH(RWv) hipLaunchKernelGGL((lora_rank_accum_vec_kernel<T, RWv>), grid, dim3(256), 0, st, M, Cn, r, (const T*)Wd, \
-                                          ldw, (const T*)Rk, ldr, out, ldo, transpose_out, part_stride)
+        const size_t smr = (size_t)4 * (64 / (64 / VEC)) * 16 * 64 * sizeof(float);       // 4 waves x RG groups x 16 x 64
+#define RV_LAUNCH(RWv)                                                                                                    \
+    do {                                                                                                                  \
+        auto kern = lora_rank_accum_vec_kernel<T, RWv>;                                                                   \
+        if (smr > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), smr, st, M, Cn, r, (const T*)Wd, ldw, (const T*)Rk, ldr, out, ldo,       \
+                           transpose_out, part_stride);                                                                  \
+    } while (0)
         if (RW == 64) RV_LAUNCH(64); else if (RW == 32) RV_LAUNCH(32); else RV_LAUNCH(16);
 #undef RV_LAUNCH
         return 0;
