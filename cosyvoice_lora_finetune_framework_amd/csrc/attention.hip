@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
     typedef Mma<T> MM;
     typedef typename MM::Frag Frag;
     constexpr int LDK = A::LDK, NK = A::NK, LDG = 84;
+    constexpr bool TR = sizeof(T) == 2;      // bf16: k-major operands are staged transposed (one 16-byte read per fragment)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* Ks = reinterpret_cast<T*>(smem);
     T* Vs = Ks + A::TILE;
@@ -78,7 +79,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
 
     for (int j0 = 0; j0 < jmax; j0 += 64) {
         stage64(kg, p.ld, j0, L, Ks, tid);
-        stage64(vg, p.ld, j0, L, Vs, tid);
+        if (TR) stage64_tr<T>(vg, p.ld, j0, L, nullptr, Vs, LDK, 0, tid);      // bf16: V only ever read k(=kv)-major => keep V^T
+        else stage64(vg, p.ld, j0, L, Vs, tid);
         if (REL) {
             const int mb = (L - 1) - (q0 + 63) + j0;
             stage64(pg, p.ldp, mb, 2 * L - 1, Pb, tid);
@@ -150,7 +152,9 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
         for (int ks = 0; ks < NK; ++ks) {
             Frag a = FragLd<T, T>::kc(Pw, LDK, 0, ks * MM::K, lane);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) MM::mma(oacc[dt], a, FragLd<T, T>::km(Vs, LDK, dt * 16, ks * MM::K, lane));
+            for (int dt = 0; dt < 4; ++dt)
+                MM::mma(oacc[dt], a, TR ? FragLd<T, T>::kc(Vs, LDK, dt * 16, ks * MM::K, lane)
+                                        : FragLd<T, T>::km(Vs, LDK, dt * 16, ks * MM::K, lane));
         }
         __syncthreads();
     }
@@ -174,13 +178,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
     typedef Mma<T> MM;
     typedef typename MM::Frag Frag;
     constexpr int LDK = A::LDK, NK = A::NK, LDG = 100;
+    constexpr bool TR = sizeof(T) == 2;
     constexpr int KB = (sizeof(T) == 2) ? 96 : 80;     // skewed dS width, padded to the MFMA k-step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* Ks = reinterpret_cast<T*>(smem);
     T* Vs = Ks + A::TILE;
     T* Ds = Vs + A::TILE;                 // 4 x 16 x LDK
     T* Pb = Ds + 4 * 16 * LDK;            // REL: 192 x LDK
-    float* Gs = reinterpret_cast<float*>(Pb + 192 * LDK);   // REL: 4 x 16 x LDG
+    float* Gs = reinterpret_cast<float*>(Pb + (REL ? 192 * LDK : 0));   // REL: 4 x 16 x LDG
+    T* Kt = reinterpret_cast<T*>(Gs + (REL ? 4 * 16 * LDG : 0));        // TR: K^T tile [d][kv]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
@@ -230,10 +236,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
     float* Gw = Gs + w * 16 * LDG;
 
     for (int j0 = 0; j0 < jmax; j0 += 64) {
-        stage64(kg, p.ld, j0, L, Ks, tid);
+        if (TR) stage64_tr<T>(kg, p.ld, j0, L, Ks, Kt, LDK, 0, tid);
+        else stage64(kg, p.ld, j0, L, Ks, tid);
         stage64(vg, p.ld, j0, L, Vs, tid);
         if (REL) {
             const int mb = (L - 1) - (q0 + 63) + j0;
+            // (a transposed copy of the band was measured slower than strided reads here: 3 scatter passes per tile)
             stage64(pg, p.ldp, mb, 2 * L - 1, Pb, tid);
             stage64(pg, p.ldp, mb + 64, 2 * L - 1, Pb + 64 * LDK, tid);
             stage64(pg, p.ldp, mb + 128, 2 * L - 1, Pb + 128 * LDK, tid);
@@ -291,7 +299,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
         for (int ks = 0; ks < NK; ++ks) {
             Frag a = FragLd<T, T>::kc(Dw, LDK, 0, ks * MM::K, lane);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) MM::mma(dqacc[dt], a, FragLd<T, T>::km(Ks, LDK, dt * 16, ks * MM::K, lane));
+            for (int dt = 0; dt < 4; ++dt)
+                MM::mma(dqacc[dt], a, TR ? FragLd<T, T>::kc(Kt, LDK, dt * 16, ks * MM::K, lane)
+                                         : FragLd<T, T>::km(Ks, LDK, dt * 16, ks * MM::K, lane));
         }
         if (REL) {
 #pragma unroll
@@ -321,6 +331,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) {
     typedef Mma<T> MM;
     typedef typename MM::Frag Frag;
     constexpr int LDK = A::LDK, NK = A::NK, LDG = 36;
+    constexpr bool TR = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* Ks = reinterpret_cast<T*>(smem);
     T* Vs = Ks + A::TILE;
@@ -331,7 +342,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) {
     float* lse_s = reinterpret_cast<float*>(Dt + 4 * 16 * LDK);   // 64
     float* del_s = lse_s + 64;                                     // 64
     T* Pb = reinterpret_cast<T*>(del_s + 64);                      // REL: 128 x LDK
-    float* Gs = reinterpret_cast<float*>(Pb + 128 * LDK);          // REL: 4 x 16 x LDG
+    float* Gs = reinterpret_cast<float*>(Pb + (REL ? 128 * LDK : 0));          // REL: 4 x 16 x LDG
+    T* Qt = reinterpret_cast<T*>(Gs + (REL ? 4 * 16 * LDG : 0));   // TR: Q^T  [d][i]
+    T* Ot = Qt + A::TILE;                                          // TR: dO^T [d][i]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
@@ -366,8 +379,13 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) {
         float* Gw = Gs + w * 16 * LDG;
         const int ibeg = (REL && p.causal) ? j0 : 0;
         for (int i0 = ibeg; i0 < L; i0 += 64) {
-            stage64(qg, p.ld, i0, L, Qs, tid);
-            stage64(dog, p.ldo, i0, L, Os, tid);
+            if (TR) {
+                stage64_tr<T>(qg, p.ld, i0, L, Qs, Qt, LDK, 0, tid);
+                stage64_tr<T>(dog, p.ldo, i0, L, Os, Ot, LDK, 0, tid);
+            } else {
+                stage64(qg, p.ld, i0, L, Qs, tid);
+                stage64(dog, p.ldo, i0, L, Os, tid);
+            }
             if (tid < 64) {
                 int i = i0 + tid;
                 lse_s[tid] = (i < L) ? p.lse[((size_t)b * p.H + h) * L + i] : __builtin_inff();
@@ -442,8 +460,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) {
                 Frag ads = FragLd<T, T>::kc(Dw, LDK, 0, ks * MM::K, lane);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    MM::mma(dvacc[dt], ap, FragLd<T, T>::km(Os, LDK, dt * 16, ks * MM::K, lane));
-                    MM::mma(dkacc[dt], ads, FragLd<T, T>::km(Qs, LDK, dt * 16, ks * MM::K, lane));
+                    MM::mma(dvacc[dt], ap, TR ? FragLd<T, T>::kc(Ot, LDK, dt * 16, ks * MM::K, lane)
+                                              : FragLd<T, T>::km(Os, LDK, dt * 16, ks * MM::K, lane));
+                    MM::mma(dkacc[dt], ads, TR ? FragLd<T, T>::kc(Qt, LDK, dt * 16, ks * MM::K, lane)
+                                               : FragLd<T, T>::km(Qs, LDK, dt * 16, ks * MM::K, lane));
                 }
             }
             __syncthreads();
@@ -483,12 +503,14 @@ template <typename T> static size_t smem_dq(bool rel) {
     typedef AttnCfg<T> A;
     size_t s = (size_t)(2 * A::TILE + 4 * 16 * A::LDK) * sizeof(T);
     if (rel) s += (size_t)192 * A::LDK * sizeof(T) + 4 * 16 * 100 * sizeof(float);
+    if (sizeof(T) == 2) s += (size_t)A::TILE * sizeof(T);                                               // K^T
     return s;
 }
 template <typename T> static size_t smem_dkv(bool rel) {
     typedef AttnCfg<T> A;
     size_t s = (size_t)(4 * A::TILE + 2 * 4 * 16 * A::LDK) * sizeof(T) + 128 * sizeof(float);
     if (rel) s += (size_t)128 * A::LDK * sizeof(T) + 4 * 16 * 36 * sizeof(float);
+    if (sizeof(T) == 2) s += (size_t)2 * A::TILE * sizeof(T);                                           // Q^T, dO^T
     return s;
 }
 

@@ -27,6 +27,22 @@ __device__ __forceinline__ void stage64(const T* __restrict__ g, int ld, int r0,
     }
 }
 
+// transposed staging: global rows r0..r0+63 -> LDS St[c][coff + r] (row stride ldt); optional straight copy S[r][c]
+template <typename T>
+__device__ __forceinline__ void stage64_tr(const T* __restrict__ g, int ld, int r0, int rlim, T* S, T* St, int ldt, int coff,
+                                           int tid) {
+    typedef AttnCfg<T> A;
+    for (int c = tid; c < 64 * A::CPR; c += 256) {
+        int r = c / A::CPR, cc = c % A::CPR;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < rlim && r0 + r >= 0) v = *reinterpret_cast<const uint4*>(g + (size_t)(r0 + r) * ld + cc * A::VEC);
+        if (S) *reinterpret_cast<uint4*>(&S[r * A::LDK + cc * A::VEC]) = v;
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int j = 0; j < A::VEC; ++j) St[(cc * A::VEC + j) * ldt + coff + r] = e[j];
+    }
+}
+
 // ---- operand loaders -------------------------------------------------------------
 template <typename T, typename S> struct FragLd;
 template <> struct FragLd<bf16_t, bf16_t> {

@@ -36,6 +36,9 @@ struct GP {
     T* C; int ldc;
     int vecA, vecW, vecU, vecB;   // 16-byte vector loads legal for that operand
     unsigned bytesA, bytesW, bytesU, bytesB;   // buffer extents for the hardware range check
+    // fused side path: U = lora_scale * A_tile . La^T is computed inside this launch (La [R][K], R <= 16),
+    // fed to the rank-R extension step and written to Uout [M][ldu] by the n-tile-0 blocks
+    const T* La; int ldla; unsigned bytesL; float lora_scale; T* Uout; int fuse;
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -49,7 +52,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // loads past the last tile are issued anyway and return zeros).  !AL: guarded element loads.
 // Epilogue: accumulators -> LDS (fp32) -> 16-byte coalesced row segments with the whole
 // bias/act/act'/residual/mask chain applied on the vectors.
-template <typename T, int BM, int BN, int WM, int WN, int D, bool AL>
+template <typename T, int BM, int BN, int WM, int WN, int D, bool AL, bool FU>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
     constexpr int NT = WM * WN * 64;
     constexpr int VEC = 16 / sizeof(T);
@@ -67,6 +70,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* As = reinterpret_cast<T*>(smem_raw);                 // [2][BM*LD]
     T* Ws = As + 2 * BM * LD;                               // [2][BN*LD]
+    T* Ls = Ws + 2 * BN * LD;                               // FU: [2][16*LD] LoRA-A tile
     float* Cs = reinterpret_cast<float*>(smem_raw);         // [BM][CLD] (aliases the operand ring after the loop)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -114,10 +118,18 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk_main = (p.K + BK - 1) / BK;
-    const int nk_lora = (p.R > 0) ? (p.R + BK - 1) / BK : 0;
+    const int nk_lora = (p.R > 0 && !FU) ? (p.R + BK - 1) / BK : 0;
     const int n_it = p.ntaps * nk_main + nk_lora;
 
     uint4 ra[D][A_IT], rw[D][W_IT];
+    uint4 rl[D];                          // FU: LoRA-A tile chunk (threads < 16*CPR)
+    f32x4 uacc[MI];                       // FU: x_tile . La^T (waves with wn == 0)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) uacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l_row = tid / CPR, l_cc = tid % CPR;
+    const bool l_ok = FU && tid < 16 * CPR && l_row < p.R;
+    __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(FU ? p.La : p.W), 0, FU ? p.bytesL : 0u, 0x00020000);
+    const unsigned ol = l_ok ? (unsigned)(((size_t)l_row * p.ldla + l_cc * VEC) * sizeof(T)) : CVFT_OOB;
 
     // Loader state machine (tiles are requested strictly in order): per-slot offsets are set up once per
     // segment (tap / LoRA), only the k offset advances per tile.
@@ -153,14 +165,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
         } else {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                va[i] = a_ok[i] && p.R > 0;
+                va[i] = a_ok[i] && p.R > 0 && !FU;
                 const size_t e = (size_t)(a_ok[i] ? m0 + a_row[i] : 0) * p.ldu + a_cc[i] * VEC;
                 oa[i] = va[i] ? (unsigned)(e * sizeof(T)) : CVFT_OOB;
                 pa[i] = p.U + e;
             }
 #pragma unroll
             for (int i = 0; i < W_IT; ++i) {
-                vw[i] = w_ok[i] && p.R > 0;
+                vw[i] = w_ok[i] && p.R > 0 && !FU;
                 const size_t e = (size_t)(w_ok[i] ? n0 + w_row[i] : 0) * p.ldbl + w_cc[i] * VEC;
                 ow[i] = vw[i] ? (unsigned)(e * sizeof(T)) : CVFT_OOB;
                 pw[i] = p.Bl + e;
@@ -171,10 +183,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
         ld_seg = seg;
         ld_kt = 0;
     };
-    auto gload = [&](uint4 (&ra_)[A_IT], uint4 (&rw_)[W_IT]) __attribute__((always_inline)) {
+    auto gload = [&](uint4 (&ra_)[A_IT], uint4 (&rw_)[W_IT], uint4& rl_) __attribute__((always_inline)) {
         if (ld_kt == ld_nk) seg_setup(ld_seg + 1);
         const int k0 = ld_kt * BK;
         const bool lora = ld_seg >= p.ntaps;
+        if (FU && AL) {
+            const unsigned off = (!lora && k0 + l_cc * VEC < p.K) ? ol + (unsigned)(k0 * sizeof(T)) : CVFT_OOB;
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsL, (int)off, 0, 0);
+            rl_ = make_uint4(v[0], v[1], v[2], v[3]);
+        }
         if (AL) {
             const __amdgpu_buffer_rsrc_t ra_src = lora ? rsU : rsA;
             const __amdgpu_buffer_rsrc_t rw_src = lora ? rsB : rsW;
@@ -214,9 +231,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
         }
         ld_kt += 1;
     };
-    auto sstore = [&](int buf, const uint4 (&ra_)[A_IT], const uint4 (&rw_)[W_IT]) __attribute__((always_inline)) {
+    auto sstore = [&](int buf, const uint4 (&ra_)[A_IT], const uint4 (&rw_)[W_IT], const uint4& rl_) __attribute__((always_inline)) {
         T* Ab = As + buf * BM * LD;
         T* Wb = Ws + buf * BN * LD;
+        if (FU && tid < 16 * CPR) *reinterpret_cast<uint4*>(&Ls[buf * 16 * LD + l_row * LD + l_cc * VEC]) = rl_;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
             if (A_FULL || tid + i * NT < BM * CPR) *reinterpret_cast<uint4*>(&Ab[a_row[i] * LD + a_cc[i] * VEC]) = ra_[i];
@@ -238,6 +256,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) MM::mma(acc[i][j], a[i], b[j]);
+            if (FU && wn == 0) {          // wave-uniform: side-path product on the A fragments already in registers
+                typename MM::Frag bl = MM::load(&Ls[buf * 16 * LD + (lane & 15) * LD + ks], lane);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) MM::mma(uacc[i], a[i], bl);
+            }
         }
     };
 
@@ -245,10 +268,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
     // prologue: tiles 0..D-1 in flight, tile 0 staged, its register set refilled with tile D
     static_for<D>([&](auto dc) __attribute__((always_inline)) {
         constexpr int d = decltype(dc)::value;
-        gload(ra[d], rw[d]);
+        gload(ra[d], rw[d], rl[d]);
     });
-    sstore(0, ra[0], rw[0]);
-    gload(ra[0], rw[0]);
+    sstore(0, ra[0], rw[0], rl[0]);
+    gload(ra[0], rw[0], rl[0]);
     __syncthreads();
     // steady state: stage tile it+1 (register set dn) into the other LDS buffer, refill that set with
     // tile it+1+D, compute tile it.  No data-dependent control flow between the loads and their use.
@@ -258,8 +281,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
             constexpr int d = decltype(dc)::value;
             constexpr int dn = (d + 1) % D;
             const int it = it0 + d;
-            sstore((it + 1) & 1, ra[dn], rw[dn]);
-            gload(ra[dn], rw[dn]);
+            sstore((it + 1) & 1, ra[dn], rw[dn], rl[dn]);
+            gload(ra[dn], rw[dn], rl[dn]);
             compute(it & 1);
             __syncthreads();
         });
@@ -269,11 +292,46 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
         constexpr int dn = (d + 1) % D;
         const int it = it0 + d;
         if (it < n_it) {
-            sstore((it + 1) & 1, ra[dn], rw[dn]);
+            sstore((it + 1) & 1, ra[dn], rw[dn], rl[dn]);
             compute(it & 1);
             __syncthreads();
         }
     });
+
+    if (FU) {
+        // rank-R extension with the in-kernel U: stage  s*U (bf16/fp32, zero-padded to BK) as an A tile and the
+        // LoRA-B rows of this n-tile as a W tile in LDS buffer 0, run one more k-tile; n-tile-0 blocks publish U.
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            if (A_FULL || tid + i * NT < BM * CPR) *reinterpret_cast<uint4*>(&As[a_row[i] * LD + a_cc[i] * VEC]) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const bool ok = w_ok[i] && w_cc[i] * VEC < p.R;
+            if (AL) {
+                const unsigned off = ok ? (unsigned)(((size_t)(n0 + w_row[i]) * p.ldbl + w_cc[i] * VEC) * sizeof(T)) : CVFT_OOB;
+                u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)off, 0, 0);
+                v = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+            }
+            if (W_FULL || tid + i * NT < BN * CPR) *reinterpret_cast<uint4*>(&Ws[w_row[i] * LD + w_cc[i] * VEC]) = v;
+        }
+        if (tid < 16 * CPR) *reinterpret_cast<uint4*>(&Ls[l_row * LD + l_cc * VEC]) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        if (wn == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * TM + i * 16 + (lane >> 4) * 4 + r, col = lane & 15;
+                    const T uv = from_f32<T>(uacc[i][r] * p.lora_scale);
+                    As[row * LD + col] = uv;
+                    if (n0 == 0 && p.Uout && m0 + row < p.M && col < p.R) p.Uout[(size_t)(m0 + row) * p.ldu + col] = uv;
+                }
+        }
+        __syncthreads();
+        compute(0);
+        __syncthreads();
+    }
 
     // ------------------------------------------------------------- epilogue
 #pragma unroll
@@ -355,15 +413,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
 template <typename T>
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename T, int BM, int BN, int WM, int WN, int D, bool AL>
+template <typename T, int BM, int BN, int WM, int WN, int D, bool AL, bool FU = false>
 static int gemm_launch_cfg(const GP<T>& p, hipStream_t st) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int BK = (sizeof(T) == 2) ? 64 : 16;
     constexpr int LD = BK + VEC;
-    size_t ring = (size_t)2 * (BM + BN) * LD * sizeof(T);
+    size_t ring = (size_t)2 * (BM + BN + (FU ? 16 : 0)) * LD * sizeof(T);
     size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
     size_t sm = ring > cs ? ring : cs;
-    auto kern = gemm_kernel<T, BM, BN, WM, WN, D, AL>;
+    auto kern = gemm_kernel<T, BM, BN, WM, WN, D, AL, FU>;
     if (sm > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) {
@@ -390,6 +448,9 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
     p.bias = a->bias; p.alpha = a->alpha; p.act = a->act;
     p.preact = (T*)a->preact; p.ldp = a->ldp; p.dact_src = (const T*)a->dact_src; p.ldd = a->ldd; p.dact = a->dact;
     p.residual = (const T*)a->residual; p.ldr = a->ldr; p.C = (T*)a->C; p.ldc = a->ldc;
+    p.La = (const T*)a->La; p.ldla = a->ldla; p.lora_scale = a->lora_scale; p.Uout = (T*)a->Uout; p.fuse = a->La != nullptr;
+    p.bytesL = 0;
+    if (p.fuse) { p.R = a->R; p.U = nullptr; }
     p.vecA = (a->K % VEC == 0) && (a->lda % VEC == 0) && al16<T>(a->A);
     p.vecW = (a->K % VEC == 0) && (a->ldw % VEC == 0) && al16<T>(a->W);
     p.vecU = p.R > 0 && (p.R % VEC == 0) && (a->ldu % VEC == 0) && al16<T>(a->U);
@@ -400,7 +461,25 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
     const size_t lim = 0x7fff0000u;
     p.bytesA = (unsigned)bA; p.bytesW = (unsigned)bW; p.bytesU = (unsigned)bU; p.bytesB = (unsigned)bB;
     long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    const bool al = p.vecA && p.vecW && (p.R == 0 || (p.vecU && p.vecB)) && bA < lim && bW < lim && bU < lim && bB < lim;
+    bool al = p.vecA && p.vecW && bA < lim && bW < lim;
+    if (p.fuse) {
+        const size_t bL = (size_t)p.R * p.ldla * sizeof(T);
+        p.bytesL = (unsigned)bL;
+        p.bytesU = 0;
+        p.vecB = (a->ldbl % VEC == 0) && al16<T>(a->Bl);
+        const bool ok = al && p.vecB && (a->ldla % VEC == 0) && al16<T>(a->La) && bL < lim && bB < lim && p.N > 32 &&
+                        (!p.Uout || a->ldu >= p.R);
+        if (!ok) {
+            cvft_set_error("cvft_gemm: fused LoRA side path needs 16-byte aligned operands, K %% %d == 0 and N > 32", VEC);
+            return -1;
+        }
+        long t128f = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        if constexpr (sizeof(T) == 2) {
+            if (p.K >= 2048 && t128f >= 256) return gemm_launch_cfg<T, 256, 128, 4, 2, 2, true, true>(p, st);
+        }
+        return gemm_launch_cfg<T, 64, 64, 2, 2, 4, true, true>(p, st);
+    }
+    al = al && (p.R == 0 || (p.vecU && p.vecB)) && bU < lim && bB < lim;
     if (al) {
         if constexpr (sizeof(T) == 2) {          // experiment hook: CVFT_GEMM_CFG selects a tile configuration
             static const int cfg = getenv("CVFT_GEMM_CFG") ? atoi(getenv("CVFT_GEMM_CFG")) : 0;
@@ -438,7 +517,11 @@ extern "C" int cvft_gemm(const cvft_gemm_args* a, void* stream) {
                    "cvft_gemm: bad row geometry");
     CVFT_CHECK_ARG(a->A && a->W && a->C, "cvft_gemm: null operand");
     CVFT_CHECK_ARG(a->lda >= a->K && a->ldw >= a->ntaps * a->K && a->ldc >= a->N, "cvft_gemm: bad leading dims");
-    if (a->U) {
+    if (a->La) {
+        CVFT_CHECK_ARG(a->Bl && a->R > 0 && a->R <= 16 && a->ldla >= a->K && a->ldbl >= a->R, "cvft_gemm: fused LoRA needs 0 < R <= 16");
+        CVFT_CHECK_ARG(a->ntaps == 1 && a->Tm == a->Tin && a->in_stride == 1 && a->tap_off[0] == 0 && a->out_stride == 1 &&
+                       a->out_off == 0 && a->Tout == a->Tin, "cvft_gemm: fused LoRA side path needs identity row geometry");
+    } else if (a->U) {
         CVFT_CHECK_ARG(a->Bl && a->R > 0 && a->ldu >= a->R && a->ldbl >= a->R, "cvft_gemm: bad LoRA operands");
         CVFT_CHECK_ARG(a->ntaps == 1 && a->Tm == a->Tin && a->in_stride == 1 && a->tap_off[0] == 0,
                        "cvft_gemm: LoRA side path needs identity row geometry");
@@ -586,7 +669,7 @@ template <typename T, int RW>
 __global__ void __launch_bounds__(256) lora_rank_accum_vec_kernel(int M, int Cn, int r, const T* __restrict__ Wd, int ldw,
                                                                    const T* __restrict__ Rk, int ldr,
                                                                    float* __restrict__ out, int ldo, int transpose_out,
-                                                                   size_t part_stride) {
+                                                                   size_t part_stride, int iters) {
     // part_stride != 0: deterministic two-stage mode -- block row y writes its slab to out + y*part_stride with
     // plain stores (no atomics; cvft_lora_grad_reduce sums the slabs).  part_stride == 0: fp32 atomics into out.
     constexpr int VEC = 16 / sizeof(T);
@@ -597,38 +680,41 @@ __global__ void __launch_bounds__(256) lora_rank_accum_vec_kernel(int M, int Cn,
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane / CG;
     const int c = blockIdx.x * 64 + (lane % CG) * VEC;
-    const int row0 = blockIdx.y * (4 * RW) + w * RW + g;
     const bool cok = c < Cn;
-    uint4 wv[NL];
-#pragma unroll
-    for (int u = 0; u < NL; ++u) {
-        const int row = row0 + u * RG;
-        wv[u] = (cok && row < M) ? *reinterpret_cast<const uint4*>(Wd + (size_t)row * ldw + c) : make_uint4(0, 0, 0, 0);
-    }
     for (int j0 = 0; j0 < r; j0 += 16) {
         float acc[16][VEC];
 #pragma unroll
         for (int j = 0; j < 16; ++j)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[j][e] = 0.f;
+        // the block walks `iters` slabs of 4*RW rows; per slab every lane has NL 16-byte loads in flight
+        for (int itr = 0; itr < iters; ++itr) {
+            const int row0 = (blockIdx.y * iters + itr) * (4 * RW) + w * RW + g;
+            uint4 wv[NL];
 #pragma unroll
-        for (int u = 0; u < NL; ++u) {
-            const int row = row0 + u * RG;
-            T rk[16];
-            if (row < M) {
-#pragma unroll
-                for (int q = 0; q < 16 / VEC; ++q)
-                    *reinterpret_cast<uint4*>(&rk[q * VEC]) = *reinterpret_cast<const uint4*>(Rk + (size_t)row * ldr + j0 + q * VEC);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) rk[j] = from_f32<T>(0.f);
+            for (int u = 0; u < NL; ++u) {
+                const int row = row0 + u * RG;
+                wv[u] = (cok && row < M) ? *reinterpret_cast<const uint4*>(Wd + (size_t)row * ldw + c) : make_uint4(0, 0, 0, 0);
             }
-            const T* we = reinterpret_cast<const T*>(&wv[u]);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float rv = to_f32(rk[j]);
+            for (int u = 0; u < NL; ++u) {
+                const int row = row0 + u * RG;
+                T rk[16];
+                if (row < M) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[j][e] += rv * to_f32(we[e]);
+                    for (int q = 0; q < 16 / VEC; ++q)
+                        *reinterpret_cast<uint4*>(&rk[q * VEC]) = *reinterpret_cast<const uint4*>(Rk + (size_t)row * ldr + j0 + q * VEC);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) rk[j] = from_f32<T>(0.f);
+                }
+                const T* we = reinterpret_cast<const T*>(&wv[u]);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float rv = to_f32(rk[j]);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[j][e] += rv * to_f32(we[e]);
+                }
             }
         }
         // combine the RG row groups x 4 waves through LDS (wide ds_write, conflict-free column reads); a register
@@ -658,6 +744,8 @@ __global__ void __launch_bounds__(256) lora_rank_accum_vec_kernel(int M, int Cn,
 template <typename T>
 static int rank_accum_launch(int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, float* out, int ldo,
                              int transpose_out, hipStream_t st, int part_rows = 0) {
+    // part_rows: rows per slab block (multiple of 64).  64 / 128 -> one pass of RW = 16 / 32 rows per wave;
+    // multiples of 256 -> RW = 64 with part_rows / 256 passes.
     constexpr int VEC = 16 / sizeof(T);
     const bool vec = (Cn % VEC == 0) && (ldw % VEC == 0) && ((reinterpret_cast<uintptr_t>(Wd) & 15) == 0) &&
                      (r % 16 == 0) && (ldr % VEC == 0) && ((reinterpret_cast<uintptr_t>(Rk) & 15) == 0);
@@ -667,16 +755,19 @@ static int rank_accum_launch(int M, int Cn, int r, const void* Wd, int ldw, cons
         // rows per block 64 / 128 / 256: the largest that still gives >= 512 blocks (or the caller's choice)
         int RW = 64;
         while (RW > 16 && (long)colblocks * ((M + 4 * RW - 1) / (4 * RW)) < 512) RW >>= 1;
-        if (part_rows) RW = part_rows / 4;
+        int iters = 1;
+        if (part_rows) {
+            if (part_rows >= 256) { RW = 64; iters = part_rows / 256; } else RW = part_rows / 4;
+        }
         const size_t part_stride = part_rows ? (size_t)r * Cn : 0;
-        dim3 grid(colblocks, (M + 4 * RW - 1) / (4 * RW));
+        dim3 grid(colblocks, (M + 4 * RW * iters - 1) / (4 * RW * iters));
         const size_t smr = (size_t)4 * (64 / (64 / VEC)) * 16 * 64 * sizeof(float);       // 4 waves x RG groups x 16 x 64
 #define RV_LAUNCH(RWv)                                                                                                    \
     do {                                                                                                                  \
         auto kern = lora_rank_accum_vec_kernel<T, RWv>;                                                                   \
         if (smr > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr); \
         hipLaunchKernelGGL(kern, grid, dim3(256), smr, st, M, Cn, r, (const T*)Wd, ldw, (const T*)Rk, ldr, out, ldo,       \
-                           transpose_out, part_stride);                                                                  \
+                           transpose_out, part_stride, iters);                                                           \
     } while (0)
         if (RW == 64) RV_LAUNCH(64); else if (RW == 32) RV_LAUNCH(32); else RV_LAUNCH(16);
 #undef RV_LAUNCH
@@ -726,7 +817,8 @@ extern "C" int cvft_lora_rank_partial(int dtype, int M, int Cn, int r, const voi
                                       float* part, int transpose_out, int rows_per_block, void* stream) {
     CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_lora_rank_partial: bad dtype");
     CVFT_CHECK_ARG(M > 0 && Cn > 0 && r > 0 && r % 16 == 0 && ldw >= Cn && ldr >= r && Wd && Rk && part, "cvft_lora_rank_partial: bad args");
-    CVFT_CHECK_ARG(rows_per_block == 64 || rows_per_block == 128 || rows_per_block == 256, "cvft_lora_rank_partial: rows_per_block must be 64/128/256");
+    CVFT_CHECK_ARG(rows_per_block == 64 || rows_per_block == 128 || (rows_per_block >= 256 && rows_per_block % 256 == 0),
+                   "cvft_lora_rank_partial: rows_per_block must be 64, 128 or a multiple of 256");
     hipStream_t st = (hipStream_t)stream;
     int ldo = transpose_out ? r : Cn;
     int rc = dtype == CVFT_F32 ? rank_accum_launch<float>(M, Cn, r, Wd, ldw, Rk, ldr, part, ldo, transpose_out, st, rows_per_block)

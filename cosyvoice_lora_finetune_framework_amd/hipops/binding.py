@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("dact_src", C.c_void_p), ("ldd", C.c_int), ("dact", C.c_int),
         ("residual", C.c_void_p), ("ldr", C.c_int),
         ("C", C.c_void_p), ("ldc", C.c_int),
+        ("La", C.c_void_p), ("ldla", C.c_int), ("lora_scale", C.c_float), ("Uout", C.c_void_p),
     ]
 
 

@@ -65,7 +65,8 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
          dact_src: Optional[torch.Tensor] = None, dact: Optional[str] = None,
          residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
          geo: Optional[Geo] = None, nb: int = 1, in_len: Optional[torch.Tensor] = None,
-         out_len: Optional[torch.Tensor] = None, out_rows: Optional[int] = None) -> torch.Tensor:
+         out_len: Optional[torch.Tensor] = None, out_rows: Optional[int] = None,
+         La: Optional[torch.Tensor] = None, lora_scale: float = 1.0, Uout: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epi(alpha * (taps(x) @ W^T + U @ Bl^T) + bias); W is [N][ntaps*K] (k contiguous)."""
     assert x.dim() == 2 and W.dim() == 2 and x.dtype == W.dtype
     N = W.shape[0] if N is None else N
@@ -90,6 +91,13 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
         assert Bl is not None and U.shape[0] == a.M and Bl.shape[0] == N and U.shape[1] == Bl.shape[1]
         a.U, a.ldu, a.R = ptr(U), U.stride(0), U.shape[1]
         a.Bl, a.ldbl = ptr(Bl), Bl.stride(0)
+    if La is not None:       # fused side path: U = lora_scale * x La^T computed inside the launch, written to Uout
+        assert Bl is not None and U is None and La.shape[0] == Bl.shape[1] and Bl.shape[0] == N
+        a.La, a.ldla, a.lora_scale, a.R = ptr(La), La.stride(0), float(lora_scale), La.shape[0]
+        a.Bl, a.ldbl = ptr(Bl), Bl.stride(0)
+        if Uout is not None:
+            assert Uout.shape[0] == a.M and Uout.shape[1] >= a.R
+            a.Uout, a.ldu = ptr(Uout), Uout.stride(0)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= N
     a.bias, a.alpha, a.act = ptr(bias), float(alpha), ACT[act]
@@ -110,8 +118,10 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
         e0.record()
         check(lib().cvft_gemm(C.byref(a), stream()), "cvft_gemm")
         e1.record()
-        PROFILE.append({"kernel": _gemm_kernel_name(a.M, N, x.dtype, ntaps * K), "start": e0, "end": e1,
-                        "flop": 2.0 * a.M * N * (ntaps * K + (a.R if U is not None else 0))})
+        r_eff = a.R if (U is not None or La is not None) else 0
+        PROFILE.append({"kernel": _gemm_kernel_name(a.M, N, x.dtype, ntaps * K) + (",fusedU" if La is not None else ""),
+                        "start": e0, "end": e1,
+                        "flop": 2.0 * a.M * N * (ntaps * K + r_eff) + (2.0 * a.M * K * a.R if La is not None else 0.0)})
         return out
     check(lib().cvft_gemm(C.byref(a), stream()), "cvft_gemm")
     return out
@@ -216,11 +226,13 @@ class LoraGradSink:
 
     @staticmethod
     def plan(M: int, Cn: int):
-        """rows per block (64/128/256) and number of slabs for an [M, Cn] wide operand."""
+        """rows per slab block (64, 128 or k*256) and number of slabs for an [M, Cn] wide operand: the fewest
+        slabs that still give >= 512 blocks (long row loops per block amortise the cross-wave reduction)."""
         colblocks = -(-Cn // 64)
-        rpb = 256
-        while rpb > 64 and colblocks * (-(-M // rpb)) < 512:
-            rpb //= 2
+        rpb = 64
+        for cand in (128, 256, 512, 768, 1024, 2048):
+            if colblocks * (-(-M // cand)) >= 512:
+                rpb = cand
         return rpb, -(-M // rpb)
 
     @staticmethod
@@ -254,6 +266,17 @@ class LoraGradSink:
         self.tasks = []
 
 
+FUSE_MAX_MN = 3_000_000   # measured (tools/bench_fused.py): the in-launch side path wins for the small estimator GEMMs only
+
+
+def _can_fuse(x: torch.Tensor, La: torch.Tensor, Bl: torch.Tensor, N: int, K: int) -> bool:
+    """Conditions of the in-launch side path (cvft_gemm `La`): rank <= 16, N > 32, 16-byte aligned operands,
+    and a problem small enough that saving a launch beats the extra MFMAs of the fused tile."""
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    return (La.shape[0] <= 16 and N > 32 and x.shape[0] * N <= FUSE_MAX_MN and K % vec == 0 and x.stride(0) % vec == 0 and La.stride(0) % vec == 0
+            and Bl.stride(0) % vec == 0 and x.data_ptr() % 16 == 0 and La.data_ptr() % 16 == 0 and Bl.data_ptr() % 16 == 0)
+
+
 def _lora_operands(P: torch.Tensor, dtype):
     """(compute-dtype copy, transposed copy) of a LoRA master; uses the per-step shadows maintained by
     optim.FlatAdamW when present (one kernel per step for all adapters), else casts on the fly."""
@@ -276,14 +299,23 @@ class LinearFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:3])
         U = None
         ops = None
+        fused = False
         if has_lora:
             Ac, At = _lora_operands(A, x.dtype)
             Bc, Bt = _lora_operands(B, x.dtype)
             ops = (Ac, At, Bc, Bt)
-            U = gemm(x, Ac, alpha=scale)
+            fused = _can_fuse(x, Ac, Bc, pack.N, pack.K)
+            if fused:
+                U = torch.empty((x.shape[0], Ac.shape[0]), dtype=x.dtype, device=x.device)
+            else:
+                U = gemm(x, Ac, alpha=scale)
         z = torch.empty((x.shape[0], pack.N), dtype=x.dtype, device=x.device) if (act and need_grad) else None
-        y = gemm(x, pack.Wf, bias=pack.bias, U=U, Bl=None if ops is None else ops[2], act=act, preact=z,
-                 residual=None if residual is None else _c(residual))
+        if fused:
+            y = gemm(x, pack.Wf, bias=pack.bias, La=Ac, lora_scale=scale, Uout=U, Bl=Bc, act=act, preact=z,
+                     residual=None if residual is None else _c(residual))
+        else:
+            y = gemm(x, pack.Wf, bias=pack.bias, U=U, Bl=None if ops is None else ops[2], act=act, preact=z,
+                     residual=None if residual is None else _c(residual))
         ctx.pack, ctx.scale, ctx.act, ctx.has_lora = pack, scale, act, has_lora
         ctx.ops, ctx.A_ref, ctx.B_ref = ops, A, B
         ctx.save_for_backward(x, U, z)
@@ -298,8 +330,13 @@ class LinearFn(torch.autograd.Function):
         V = None
         if ctx.has_lora:
             Ac, At, Bc, Bt = ctx.ops
-            V = gemm(dz, Bt, alpha=ctx.scale)                             # [M, r] = s * dz B
-        if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0] and _can_fuse(dz, Bt, At, ctx.pack.K, ctx.pack.N):
+                # dgrad with the side path fused: V = s * dz B is produced by the same launch
+                V = torch.empty((dz.shape[0], Bt.shape[0]), dtype=dz.dtype, device=dz.device)
+                dx = gemm(dz, ctx.pack.Wb, La=Bt, lora_scale=ctx.scale, Uout=V, Bl=At)
+            else:
+                V = gemm(dz, Bt, alpha=ctx.scale)                         # [M, r] = s * dz B
+        if ctx.needs_input_grad[0] and dx is None:
             dx = gemm(dz, ctx.pack.Wb, U=V, Bl=None if V is None else At)
         if ctx.has_lora and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
             A, B = ctx.A_ref, ctx.B_ref

@@ -43,6 +43,7 @@ const char* cvft_last_error(void);
  *
  *   C[orow(m), n] = epi( alpha * ( sum_{j<ntaps} A[irow_j(m), :K] . W[n, j*K:(j+1)*K]
  *                                 + U[m, :R] . Bl[n, :R] ) + bias[n] )
+ *   (U either given, or -- fused form -- computed in the same launch as  lora_scale * A . La^T)
  *
  * m = b*Tm + t (t < Tm):   irow_j(m) = b*Tin + (t*in_stride + tap_off[j])   (zero row if the
  * time index is outside [0,Tin) or >= in_len[b]);   orow(m) = b*Tout + t*out_stride + out_off
@@ -75,6 +76,10 @@ typedef struct {
     const void* dact_src; int ldd; int dact;   /* or NULL */
     const void* residual; int ldr;       /* or NULL */
     void* C; int ldc;
+    /* fused side path (optional; R <= 16, identity row geometry, 16-byte aligned operands): when La != NULL the
+     * launch itself computes  Uf = lora_scale * A . La^T  (La [R][ldla]) from the A tiles it streams anyway, uses it
+     * in place of U for the rank-R extension, and writes it to Uout [M][ldu] (may be NULL).  `U` is ignored. */
+    const void* La; int ldla; float lora_scale; void* Uout;
 } cvft_gemm_args;
 
 int cvft_gemm(const cvft_gemm_args* a, void* stream);
@@ -92,7 +97,7 @@ int cvft_tn_accum(int dtype, int M, int P, int Q, const void* Pm, int ldp, const
 int cvft_lora_rank_accum(int dtype, int M, int C, int r, const void* Wd, int ldw, const void* Rk, int ldr,
                          float* out, int ldo, int transpose_out, void* stream);
 /* Deterministic two-stage form of the same gradients (no atomics): stage 1 writes one fp32 slab per row block
- * (part[s][r][C] or part[s][C][r], s < ceil(M / rows_per_block), rows_per_block in {64,128,256}; operands 16-byte
+ * (part[s][r][C] or part[s][C][r], s < ceil(M / rows_per_block), rows_per_block 64, 128 or k*256; operands 16-byte
  * aligned, r % 16 == 0); stage 2 is ONE launch for all adapters: tasks int64[ntasks][4] = {slab ptr, grad ptr,
  * numel, nsplit}, grad[i] += sum_s slab[s*numel + i] in fixed order. */
 int cvft_lora_rank_partial(int dtype, int M, int C, int r, const void* Wd, int ldw, const void* Rk, int ldr,

@@ -434,3 +434,20 @@ def test_lora_grad_sink_matches_atomic_path_and_is_deterministic():
         runs.append(opt.flat_g.clone())
     assert torch.equal(runs[0], runs[1])
     assert rel(runs[0], g_atomic) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,r", [(333, 200, 264, 16), (4000, 512, 256, 16), (700, 1024, 4096, 16), (129, 96, 64, 8)])
+def test_gemm_fused_lora_side_path(dtype, M, N, K, r):
+    """x W^T + b + (s x A^T) B^T with U computed INSIDE the launch (cvft_gemm La/Uout) == two-launch form."""
+    HF = HFmod()
+    x, w = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    A, Bm, b = q(rnd(r, K, seed=3) / math.sqrt(K), dtype), q(rnd(N, r, seed=4) * 0.1, dtype), rnd(N, seed=5)
+    U = torch.full((M, r), 7.0, device=DEV, dtype=dtype)
+    y = HF.gemm(x.to(DEV, dtype), w.to(DEV, dtype), bias=b.to(DEV), La=A.to(DEV, dtype), lora_scale=2.0, Uout=U,
+                Bl=Bm.to(DEV, dtype), act="silu")
+    ur = 2.0 * (x.double() @ A.double().t())
+    assert rel(U, ur) < TOL[dtype]
+    uq = q(ur.float(), dtype).double()            # the kernel feeds the rounded U to the extension step
+    ref = F.silu(x.double() @ w.double().t() + b.double() + uq @ Bm.double().t())
+    assert rel(y, ref) < TOL[dtype]

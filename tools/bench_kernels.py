@@ -32,32 +32,38 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / (5 * reps) * 1e3   # us
 
 
-shapes = [(4000, 512, 256), (8000, 512, 256), (4000, 1536, 256), (4000, 1024, 256), (4000, 256, 1024), (4640, 512, 512),
-          (4640, 2048, 512), (5328, 1024, 1024), (5328, 4096, 1024), (5328, 1024, 4096), (5328, 4097, 1024)]
-print("main GEMM (LoRA r=16 side path, bias):")
-for M, N, K in shapes:
-    x = torch.randn(M, K, device=dev, dtype=dt)
-    w = torch.randn(N, K, device=dev, dtype=dt) / K ** 0.5
-    u = torch.randn(M, 16, device=dev, dtype=dt)
-    bl = torch.randn(N, 16, device=dev, dtype=dt)
-    b = torch.randn(N, device=dev)
-    out = torch.empty(M, N, device=dev, dtype=dt)
-    t = timeit(lambda: HF.gemm(x, w, bias=b, U=u, Bl=bl, out=out))
-    t2 = timeit(lambda: torch.nn.functional.linear(x, w))
-    fl = 2 * M * N * (K + 16)
-    print(f"  M{M:5d} N{N:5d} K{K:5d}: {t:7.1f} us  {fl / t / 1e6:7.1f} TF/s   [{HF._gemm_kernel_name(M, N, dt, K)}]   hipBLASLt {t2:7.1f} us {2*M*N*K/t2/1e6:7.1f} TF/s")
-if os.environ.get("ONLY_MAIN"):
-    sys.exit(0)
-print("skinny (U = s x A^T):")
-for M, K in [(4000, 256), (8000, 256), (4640, 512), (5328, 1024), (5328, 4096)]:
-    x = torch.randn(M, K, device=dev, dtype=dt)
-    a = torch.randn(16, K, device=dev, dtype=dt)
-    t = timeit(lambda: HF.gemm(x, a, alpha=2.0))
-    print(f"  M{M:5d} K{K:5d}: {t:7.1f} us   {M * K * 2 / t / 1e3:7.1f} GB/s")
-print("rank accum (dA = V^T X):")
-for M, Cn in [(4000, 256), (8000, 256), (4000, 512), (4640, 512), (5328, 1024), (5328, 4096)]:
-    x = torch.randn(M, Cn, device=dev, dtype=dt)
-    v = torch.randn(M, 16, device=dev, dtype=dt)
-    o = torch.zeros(16, Cn, device=dev)
-    t = timeit(lambda: HF.rank_accum(x, v, o, False))
-    print(f"  M{M:5d} C{Cn:5d}: {t:7.1f} us   {M * Cn * 2 / t / 1e3:7.1f} GB/s")
+def main():
+    shapes = [(4000, 512, 256), (8000, 512, 256), (4000, 1536, 256), (4000, 1024, 256), (4000, 256, 1024), (4640, 512, 512),
+              (4640, 2048, 512), (5328, 1024, 1024), (5328, 4096, 1024), (5328, 1024, 4096), (5328, 4097, 1024)]
+    print("main GEMM (LoRA r=16 side path, bias):")
+    for M, N, K in shapes:
+        x = torch.randn(M, K, device=dev, dtype=dt)
+        w = torch.randn(N, K, device=dev, dtype=dt) / K ** 0.5
+        u = torch.randn(M, 16, device=dev, dtype=dt)
+        bl = torch.randn(N, 16, device=dev, dtype=dt)
+        b = torch.randn(N, device=dev)
+        out = torch.empty(M, N, device=dev, dtype=dt)
+        t = timeit(lambda: HF.gemm(x, w, bias=b, U=u, Bl=bl, out=out))
+        t2 = timeit(lambda: torch.nn.functional.linear(x, w))
+        fl = 2 * M * N * (K + 16)
+        print(f"  M{M:5d} N{N:5d} K{K:5d}: {t:7.1f} us  {fl / t / 1e6:7.1f} TF/s   [{HF._gemm_kernel_name(M, N, dt, K)}]   hipBLASLt {t2:7.1f} us {2*M*N*K/t2/1e6:7.1f} TF/s")
+    if os.environ.get("ONLY_MAIN"):
+        sys.exit(0)
+    print("skinny (U = s x A^T):")
+    for M, K in [(4000, 256), (8000, 256), (4640, 512), (5328, 1024), (5328, 4096)]:
+        x = torch.randn(M, K, device=dev, dtype=dt)
+        a = torch.randn(16, K, device=dev, dtype=dt)
+        t = timeit(lambda: HF.gemm(x, a, alpha=2.0))
+        print(f"  M{M:5d} K{K:5d}: {t:7.1f} us   {M * K * 2 / t / 1e3:7.1f} GB/s")
+    print("rank accum (dA = V^T X):")
+    for M, Cn in [(4000, 256), (8000, 256), (4000, 512), (4640, 512), (5328, 1024), (5328, 4096)]:
+        x = torch.randn(M, Cn, device=dev, dtype=dt)
+        v = torch.randn(M, 16, device=dev, dtype=dt)
+        o = torch.zeros(16, Cn, device=dev)
+        t = timeit(lambda: HF.rank_accum(x, v, o, False))
+        print(f"  M{M:5d} C{Cn:5d}: {t:7.1f} us   {M * Cn * 2 / t / 1e3:7.1f} GB/s")
+
+
+
+if __name__ == "__main__":
+    main()
