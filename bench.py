@@ -39,6 +39,19 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup quota (the GPU box exposes
+    all host CPUs through os.cpu_count() but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def build(workload, dtype, device, r, alpha):
     from cosyvoice_lora_finetune_framework_amd.flow_model import build_flow_model
     from cosyvoice_lora_finetune_framework_amd.llm_flow_model import JointLLMFlowModel
@@ -66,8 +79,9 @@ def cpu_baseline(jm, workload, T, seconds_budget=30.0):
     """Time the CPU oracle (port of the reference math) on a bounded sample: B=1 utterances/step."""
     from oracle import ref_math as R
     from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"[bench] cpu_baseline: timing the CPU oracle on {cores} host threads ...")
     sd_f = {k: v.detach().float().cpu() for k, v in jm.flow.state_dict().items()}
     sd_l = {k: v.detach().float().cpu() for k, v in jm.llm.state_dict().items()} if workload != 'flow_only' else {}
     for sd in (sd_f, sd_l):
@@ -87,6 +101,7 @@ def cpu_baseline(jm, workload, T, seconds_budget=30.0):
     t0 = time.time()
     one()
     first = time.time() - t0
+    log(f"[bench] cpu_baseline: warm-up step took {first:.1f} s")
     n = max(1, min(3, int((seconds_budget - first) / max(first, 1e-3))))
     t0 = time.time()
     for _ in range(n):
@@ -166,6 +181,7 @@ def main():
         opt.zero_grad()
         return loss
 
+    log(f"[bench] rank {rank}: model ready ({'hipGraph' if graph is not None else 'eager'}); warm-up {a.warmup}, timing {a.steps} steps")
     for _ in range(a.warmup):
         step()
     dp.barrier()
@@ -182,6 +198,7 @@ def main():
     elapsed = float(el)
     final_loss = float(loss)
 
+    log(f"[bench] timed region done: {elapsed / a.steps * 1e3:.2f} ms/step")
     roof = None
     if not a.no_roofline:
         # event-instrumented eager step: every tap-GEMM launch bracketed by HIP events on the launch stream
