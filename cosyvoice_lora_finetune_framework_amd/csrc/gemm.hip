@@ -234,13 +234,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
     auto sstore = [&](int buf, const uint4 (&ra_)[A_IT], const uint4 (&rw_)[W_IT], const uint4& rl_) __attribute__((always_inline)) {
         T* Ab = As + buf * BM * LD;
         T* Wb = Ws + buf * BN * LD;
-        if (FU && tid < 16 * CPR) *reinterpret_cast<uint4*>(&Ls[buf * 16 * LD + l_row * LD + l_cc * VEC]) = rl_;
+        if (FU && tid < 16 * CPR) *reinterpret_cast<uint4*>(&Ls[buf * 16 * LD + l_row * LD + MM::chunk_sw(l_row, l_cc) * VEC]) = rl_;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            if (A_FULL || tid + i * NT < BM * CPR) *reinterpret_cast<uint4*>(&Ab[a_row[i] * LD + a_cc[i] * VEC]) = ra_[i];
+            if (A_FULL || tid + i * NT < BM * CPR) *reinterpret_cast<uint4*>(&Ab[a_row[i] * LD + MM::chunk_sw(a_row[i], a_cc[i]) * VEC]) = ra_[i];
 #pragma unroll
         for (int i = 0; i < W_IT; ++i)
-            if (W_FULL || tid + i * NT < BN * CPR) *reinterpret_cast<uint4*>(&Wb[w_row[i] * LD + w_cc[i] * VEC]) = rw_[i];
+            if (W_FULL || tid + i * NT < BN * CPR) *reinterpret_cast<uint4*>(&Wb[w_row[i] * LD + MM::chunk_sw(w_row[i], w_cc[i]) * VEC]) = rw_[i];
     };
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const T* Ab = As + buf * BM * LD;
@@ -249,15 +249,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
         for (int ks = 0; ks < BK; ks += MM::K) {
             typename MM::Frag a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = MM::load(&Ab[(wm * TM + i * 16 + (lane & 15)) * LD + ks], lane);
+            for (int i = 0; i < MI; ++i) a[i] = MM::load_sw(&Ab[(wm * TM + i * 16 + (lane & 15)) * LD + ks], lane);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = MM::load(&Wb[(wn * TN + j * 16 + (lane & 15)) * LD + ks], lane);
+            for (int j = 0; j < NI; ++j) b[j] = MM::load_sw(&Wb[(wn * TN + j * 16 + (lane & 15)) * LD + ks], lane);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) MM::mma(acc[i][j], a[i], b[j]);
             if (FU && wn == 0) {          // wave-uniform: side-path product on the A fragments already in registers
-                typename MM::Frag bl = MM::load(&Ls[buf * 16 * LD + (lane & 15) * LD + ks], lane);
+                typename MM::Frag bl = MM::load_sw(&Ls[buf * 16 * LD + (lane & 15) * LD + ks], lane);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) MM::mma(uacc[i], a[i], bl);
             }
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
                 u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)off, 0, 0);
                 v = make_uint4(t4[0], t4[1], t4[2], t4[3]);
             }
-            if (W_FULL || tid + i * NT < BN * CPR) *reinterpret_cast<uint4*>(&Ws[w_row[i] * LD + w_cc[i] * VEC]) = v;
+            if (W_FULL || tid + i * NT < BN * CPR) *reinterpret_cast<uint4*>(&Ws[w_row[i] * LD + MM::chunk_sw(w_row[i], w_cc[i]) * VEC]) = v;
         }
         if (tid < 16 * CPR) *reinterpret_cast<uint4*>(&Ls[l_row * LD + l_cc * VEC]) = make_uint4(0, 0, 0, 0);
         __syncthreads();
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
                 for (int r = 0; r < 4; ++r) {
                     const int row = wm * TM + i * 16 + (lane >> 4) * 4 + r, col = lane & 15;
                     const T uv = from_f32<T>(uacc[i][r] * p.lora_scale);
-                    As[row * LD + col] = uv;
+                    As[row * LD + MM::chunk_sw(row, col / VEC) * VEC + (col % VEC)] = uv;
                     if (n0 == 0 && p.Uout && m0 + row < p.M && col < p.R) p.Uout[(size_t)(m0 + row) * p.ldu + col] = uv;
                 }
         }
