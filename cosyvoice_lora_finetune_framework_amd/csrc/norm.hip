@@ -8,15 +8,59 @@
 // GroupNorm(1)+Mish (length_regulator.py:34-41).
 #include "common.cuh"
 
-template <typename T>
+// One wavefront per row.  VP (C % VEC == 0, C <= 64*VEC*NCH, aligned): the row is read ONCE with 16-byte loads
+// into registers (NCH chunks per lane) and every later pass runs on registers; otherwise strided scalar passes.
+template <typename T, bool VP>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(int rows, int C, const T* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, int relu, float post, T* __restrict__ y,
                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int NCH = 4;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T* xr = x + (size_t)row * C;
+    T* yr = y + (size_t)row * C;
+    if (VP) {
+        const int nch = C / VEC;
+        float v[NCH][VEC];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int ch = lane + q * 64;
+            if (ch < nch) {
+                uint4 raw = *reinterpret_cast<const uint4*>(xr + ch * VEC);
+                const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { v[q][k] = to_f32(e[k]); s += v[q][k]; }
+            }
+        }
+        const float mu = wave_sum(s) / (float)C;
+        float s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+            if (lane + q * 64 < nch)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { float d = v[q][k] - mu; s2 += d * d; }
+        const float rs = 1.0f / sqrtf(wave_sum(s2) / (float)C + eps);
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int ch = lane + q * 64;
+            if (ch < nch) {
+                T o[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float t = (v[q][k] - mu) * rs * gamma[ch * VEC + k] + beta[ch * VEC + k];
+                    if (relu) t = fmaxf(t, 0.f);
+                    o[k] = from_f32<T>(t * post);
+                }
+                *reinterpret_cast<uint4*>(yr + ch * VEC) = *reinterpret_cast<uint4*>(o);
+            }
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        return;
+    }
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += to_f32(xr[c]);
     const float mu = wave_sum(s) / (float)C;
@@ -26,7 +70,6 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(int rows, int C, const T* _
         v += d * d;
     }
     const float rs = 1.0f / sqrtf(wave_sum(v) / (float)C + eps);
-    T* yr = y + (size_t)row * C;
     for (int c = lane; c < C; c += 64) {
         float o = (to_f32(xr[c]) - mu) * rs * gamma[c] + beta[c];
         if (relu) o = fmaxf(o, 0.f);
@@ -38,18 +81,61 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(int rows, int C, const T* _
     }
 }
 
-template <typename T>
+template <typename T, bool VP>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       int relu, float post, const T* __restrict__ dy,
                                                       T* __restrict__ dx) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int NCH = 4;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T* xr = x + (size_t)row * C;
     const T* dr = dy + (size_t)row * C;
+    T* ox = dx + (size_t)row * C;
     const float mu = mean[row], rs = rstd[row];
+    if (VP) {
+        const int nch = C / VEC;
+        float xh[NCH][VEC], g[NCH][VEC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int ch = lane + q * 64;
+            if (ch < nch) {
+                uint4 rx = *reinterpret_cast<const uint4*>(xr + ch * VEC);
+                uint4 rd = *reinterpret_cast<const uint4*>(dr + ch * VEC);
+                const T* ex = reinterpret_cast<const T*>(&rx);
+                const T* ed = reinterpret_cast<const T*>(&rd);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const int c = ch * VEC + k;
+                    float h = (to_f32(ex[k]) - mu) * rs;
+                    float gg = to_f32(ed[k]) * post;
+                    if (relu && (h * gamma[c] + beta[c]) <= 0.f) gg = 0.f;
+                    gg *= gamma[c];
+                    xh[q][k] = h;
+                    g[q][k] = gg;
+                    s1 += gg;
+                    s2 += gg * h;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int ch = lane + q * 64;
+            if (ch < nch) {
+                T o[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o[k] = from_f32<T>(rs * (g[q][k] - s1 - xh[q][k] * s2));
+                *reinterpret_cast<uint4*>(ox + ch * VEC) = *reinterpret_cast<uint4*>(o);
+            }
+        }
+        return;
+    }
     float s1 = 0.f, s2 = 0.f;
     for (int c = lane; c < C; c += 64) {
         float xh = (to_f32(xr[c]) - mu) * rs;
@@ -61,7 +147,6 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
     }
     s1 = wave_sum(s1) / (float)C;
     s2 = wave_sum(s2) / (float)C;
-    T* ox = dx + (size_t)row * C;
     for (int c = lane; c < C; c += 64) {
         float xh = (to_f32(xr[c]) - mu) * rs;
         float g = to_f32(dr[c]) * post;
@@ -69,6 +154,13 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
         g *= gamma[c];
         ox[c] = from_f32<T>(rs * (g - s1 - xh * s2));
     }
+}
+
+template <typename T>
+static bool ln_vec_ok(int C, const void* a, const void* b, const void* c) {
+    constexpr int VEC = 16 / sizeof(T);
+    uintptr_t m = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c);
+    return (C % VEC == 0) && (C <= 64 * VEC * 4) && ((m & 15) == 0);
 }
 
 extern "C" int cvft_layernorm_fwd(int dtype, int rows, int C, const void* x, const float* gamma, const float* beta,
@@ -79,12 +171,11 @@ extern "C" int cvft_layernorm_fwd(int dtype, int rows, int C, const void* x, con
     if (rows == 0) return 0;
     dim3 grid((rows + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == CVFT_F32)
-        hipLaunchKernelGGL((ln_fwd_kernel<float>), grid, dim3(256), 0, st, rows, C, (const float*)x, gamma, beta, eps,
-                           relu, post_scale, (float*)y, mean, rstd);
-    else
-        hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, rows, C, (const bf16_t*)x, gamma, beta, eps,
-                           relu, post_scale, (bf16_t*)y, mean, rstd);
+#define LN_FWD(TT, VPv) hipLaunchKernelGGL((ln_fwd_kernel<TT, VPv>), grid, dim3(256), 0, st, rows, C, (const TT*)x, gamma, beta, eps, \
+                                           relu, post_scale, (TT*)y, mean, rstd)
+    if (dtype == CVFT_F32) { if (ln_vec_ok<float>(C, x, y, y)) LN_FWD(float, true); else LN_FWD(float, false); }
+    else { if (ln_vec_ok<bf16_t>(C, x, y, y)) LN_FWD(bf16_t, true); else LN_FWD(bf16_t, false); }
+#undef LN_FWD
     CVFT_LAUNCH_CHECK("cvft_layernorm_fwd");
     return 0;
 }
@@ -97,12 +188,11 @@ extern "C" int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, con
     if (rows == 0) return 0;
     dim3 grid((rows + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == CVFT_F32)
-        hipLaunchKernelGGL((ln_bwd_kernel<float>), grid, dim3(256), 0, st, rows, C, (const float*)x, gamma, beta, mean,
-                           rstd, relu, post_scale, (const float*)dy, (float*)dx);
-    else
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, rows, C, (const bf16_t*)x, gamma, beta, mean,
-                           rstd, relu, post_scale, (const bf16_t*)dy, (bf16_t*)dx);
+#define LN_BWD(TT, VPv) hipLaunchKernelGGL((ln_bwd_kernel<TT, VPv>), grid, dim3(256), 0, st, rows, C, (const TT*)x, gamma, beta, mean, \
+                                           rstd, relu, post_scale, (const TT*)dy, (TT*)dx)
+    if (dtype == CVFT_F32) { if (ln_vec_ok<float>(C, x, dy, dx)) LN_BWD(float, true); else LN_BWD(float, false); }
+    else { if (ln_vec_ok<bf16_t>(C, x, dy, dx)) LN_BWD(bf16_t, true); else LN_BWD(bf16_t, false); }
+#undef LN_BWD
     CVFT_LAUNCH_CHECK("cvft_layernorm_bwd");
     return 0;
 }

@@ -133,3 +133,42 @@ def test_data_parallel_equals_global_batch_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_mask_helpers_match_reference_fixtures():
+    """utils.py helpers vs the reference's outputs (ops.npz)."""
+    from conftest import load_npz
+    from cosyvoice_lora_finetune_framework_amd import utils as U
+    g = load_npz("ops.npz")
+    assert torch.equal(U.make_pad_mask(torch.tensor([5, 3, 2])), g["pad_mask_5_3_2"])
+    assert torch.equal(U.subsequent_chunk_mask(6, 1), g["chunk_mask_6_1"])
+    assert torch.equal(U.mask_to_bias(torch.tensor([[True, False, True]]), torch.float32), g["mask_bias"])
+    m = ~U.make_pad_mask(torch.tensor([4, 2]), 4).unsqueeze(1)
+    cm = U.add_optional_chunk_mask(torch.zeros(2, 4, 8), m, False, False, 0, 1, -1)
+    assert cm.shape == (2, 4, 4) and bool(cm[0].equal(torch.tril(torch.ones(4, 4, dtype=torch.bool))))
+    assert cm[1, 3].tolist() == [True, True, False, False]
+    assert U.pad_list([torch.ones(2), torch.ones(3)], -1).tolist() == [[1, 1, -1], [1, 1, 1]]
+
+
+def test_callbacks_follow_reference_rules():
+    """LossThresholdCallback: LLM checked before Flow, first hit returns (train_joint.py:80-102); EarlyStopping:
+    min_delta 1e-3, patience."""
+    from cosyvoice_lora_finetune_framework_amd.train_joint import EarlyStopping, LossThresholdCallback
+
+    class T:
+        callback_metrics = {}
+        should_stop = False
+    t = T()
+    cb = LossThresholdCallback(llm_loss_threshold=1.5, flow_loss_threshold=0.3)
+    t.callback_metrics = {"llm_loss_epoch": 1.6, "flow_loss_epoch": 0.31}
+    cb.on_train_epoch_end(t)
+    assert not t.should_stop
+    t.callback_metrics = {"llm_loss_epoch": 1.6, "flow_loss_epoch": 0.29}
+    cb.on_train_epoch_end(t)
+    assert t.should_stop
+    t2 = T()
+    es = EarlyStopping(patience=2)
+    for v in (1.0, 0.9, 0.8995, 0.8999):
+        t2.callback_metrics = {"train_loss_epoch": v}
+        es.on_train_epoch_end(t2)
+    assert t2.should_stop

@@ -160,3 +160,80 @@ def test_full_size_llm_matches_reference(case):
     with torch.no_grad():
         lb = float(m.forward_no_prompt(batch, DEV)["loss"])
     assert abs(lb - c["loss"]) / c["loss"] < 2e-2, lb
+
+
+def test_conformer_convolution_module_matches_reference():
+    """ConvolutionModule (pointwise -> GLU -> depthwise k=15 -> LayerNorm -> SiLU -> pointwise) vs the
+    vendored cosyvoice/transformer/convolution.py output (ops.npz), both dtypes."""
+    from oracle.detweights import det_state_dict
+    from cosyvoice_lora_finetune_framework_amd.modules import ConvolutionModule
+    g, m = load_npz("ops.npz"), load_json("ops_meta.json")
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 3e-2)):
+        cm = ConvolutionModule(32, 15, "silu", "layer_norm", causal=False)
+        cm.load_state_dict(det_state_dict([(k, tuple(s)) for k, s in m["convmod_spec"]], m["convmod_seed"]), strict=True)
+        cm = cm.to(DEV)
+        x = g["convmod_x"]
+        B, T, Cc = x.shape
+        length = g["convmod_mask"].reshape(B, T).sum(1).to(torch.int32).to(DEV)
+        y = cm.forward_cl(x.reshape(B * T, Cc).to(DEV, dtype), B, T, length)
+        assert rel(y.reshape(B, T, Cc), g["convmod_y"]) < tol
+
+
+def test_lora_conv1d_matches_reference():
+    """LoRAConv1d (1x1 conv == Linear over channels) forward vs reference lora.py:121-131."""
+    from oracle.detweights import det_state_dict
+    from cosyvoice_lora_finetune_framework_amd.lora import LoRAConv1d
+    g, m = load_npz("ops.npz"), load_json("ops_meta.json")
+    lc = LoRAConv1d(torch.nn.Conv1d(12, 20, 1), r=4, lora_alpha=8, lora_dropout=0.0)
+    lc.load_state_dict(det_state_dict([(k, tuple(s)) for k, s in m["loraconv_spec"]], m["loraconv_seed"]), strict=True)
+    lc = lc.to(DEV).eval()
+    y = lc(g["loraconv_x"].to(DEV))
+    assert rel(y, g["loraconv_y"]) < 2e-5
+
+
+def test_lora_linear_module_any_shape_and_dropout():
+    """LoRALinear.forward is a drop-in for arbitrary leading dims (lora.py:64-76); in train() mode the LoRA-path
+    dropout changes the output, in eval() it is deterministic."""
+    from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
+    lin = torch.nn.Linear(24, 40)
+    ll = LoRALinear(lin, r=4, lora_alpha=8, lora_dropout=0.5).to(DEV)
+    x = torch.randn(3, 5, 24, device=DEV)
+    ll.eval()
+    y0, y1 = ll(x), ll(x)
+    assert y0.shape == (3, 5, 40) and torch.equal(y0, y1)
+    ref = torch.nn.functional.linear(x, lin.weight.to(DEV), lin.bias.to(DEV)) + 2.0 * (x @ ll.lora_A.t()) @ ll.lora_B.t()
+    assert rel(y0, ref) < 2e-5
+    ll.train()
+    assert not torch.equal(ll(x), y0)
+
+
+def test_checkpoint_roundtrip_lightning_layout(tiny_meta, tmp_path):
+    """Trainer checkpoints use the Lightning key layout (model.llm.* / model.flow.*, merge_joint_weights.py:95-104)
+    and restore parameters + optimiser state (resume, train_joint.py:364-368)."""
+    from cosyvoice_lora_finetune_framework_amd.llm_flow_model import JointLLMFlowModel
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    from cosyvoice_lora_finetune_framework_amd.synthetic import synth_batch
+    from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, Trainer
+    num = Numerics(dtype=torch.float32)
+
+    def make():
+        flow = build_flow_product(tiny_meta["flow"], DEV, num)
+        llm = build_llm_product(tiny_meta["llm"], DEV, num)
+        return JointLightningModule('joint', learning_rate=1e-3, warmup_steps=1, model=JointLLMFlowModel(llm, flow, 'joint', 2.0, 1.0),
+                                    numerics=num)
+    batches = [synth_batch([20 + i], text_lens=[5], token_lens=[9 + i], seed=i, text_vocab=100, speech_vocab=50) for i in range(2)]
+    mod = make()
+    tr = Trainer(max_epochs=1, accumulate_grad_batches=1, default_root_dir=str(tmp_path), log_every_n_steps=1)
+    tr.fit(mod, batches)
+    ck = torch.load(str(tmp_path / "joint_joint_last.ckpt"), map_location="cpu")
+    assert all(k.startswith("model.llm.") or k.startswith("model.flow.") for k in ck["state_dict"])
+    assert ck["global_step"] == 2
+    mod2 = make()
+    tr2 = Trainer(max_epochs=1, default_root_dir=str(tmp_path), save_checkpoints=False)
+    mod2.setup()
+    opt2 = mod2.configure_optimizers()
+    tr2.load_checkpoint(mod2, opt2, str(tmp_path / "joint_joint_last.ckpt"))
+    a = dict(mod.model.named_parameters())
+    for k, v in mod2.model.named_parameters():
+        assert torch.equal(v.detach().cpu(), a[k].detach().cpu()), k
+    assert torch.equal(opt2.m.cpu(), tr.optimizer.m.cpu()) and opt2.step_count == 2
