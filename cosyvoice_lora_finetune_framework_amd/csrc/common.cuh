@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define WAVE 64
 
 extern "C" void cvft_set_error(const char* fmt, ...);
+extern "C" void cvft_set_kernel_label(const char* fmt, ...);
 
 #define CVFT_CHECK_ARG(cond, ...)                      \
     do {                                               \

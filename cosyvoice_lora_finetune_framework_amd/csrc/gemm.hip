@@ -5,44 +5,7 @@
 // Replaces (reference): lora.py:64-76, nn.Linear/Conv1d/ConvTranspose1d calls of
 // modules.py:60-120 & matcha/models/components/decoder.py:35-158, and their dgrad.
 #include <stdlib.h>
-#include "common.cuh"
-
-#include <utility>
-template <int... I, typename F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
-
-template <typename T>
-struct GP {
-    int M, N, K, Tm, Tin, Tout, in_stride, out_stride, out_off, ntaps;
-    int tap_off[4];
-    const int* in_len;
-    const int* out_len;
-    const T* A; int lda;
-    const T* W; int ldw;
-    const T* U; int ldu; int R;
-    const T* Bl; int ldbl;
-    const float* bias;
-    float alpha;
-    int act;
-    T* preact; int ldp;
-    const T* dact_src; int ldd; int dact;
-    const T* residual; int ldr;
-    T* C; int ldc;
-    int vecA, vecW, vecU, vecB;   // 16-byte vector loads legal for that operand
-    unsigned bytesA, bytesW, bytesU, bytesB;   // buffer extents for the hardware range check
-    // fused side path: U = lora_scale * A_tile . La^T is computed inside this launch (La [R][K], R <= 16),
-    // fed to the rank-R extension step and written to Uout [M][ldu] by the n-tile-0 blocks
-    const T* La; int ldla; unsigned bytesL; float lora_scale; T* Uout; int fuse;
-};
-
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-#define CVFT_OOB 0x80000000u      // byte offset past every buffer (< 2 GiB each, host-checked): the load returns 0
+#include "gemm_common.cuh"
 
 // Main loop: the K extent (all taps, then the rank-r LoRA segment) is cut into BK-wide tiles.  D tiles
 // are kept in flight in registers (these GEMMs are small and latency-bound: the lever is bytes in
@@ -342,72 +305,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(GP<T> p) {
             for (int r = 0; r < 4; ++r)
                 Cs[(wm * TM + i * 16 + (lane >> 4) * 4 + r) * CLD + wn * TN + j * 16 + (lane & 15)] = acc[i][j][r];
     __syncthreads();
-    const bool ident = (p.Tm == p.M) && p.out_stride == 1 && p.out_off == 0;
-    const bool vec_out = (p.N % VEC == 0) && (p.ldc % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
-                         (!p.preact || ((p.ldp % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.preact) & 15) == 0))) &&
-                         (!p.dact_src || ((p.ldd % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.dact_src) & 15) == 0))) &&
-                         (!p.residual || ((p.ldr % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
-    constexpr int CPRO = BN / VEC;                 // output chunks per tile row
-    for (int c = tid; c < BM * CPRO; c += NT) {
-        const int row = c / CPRO, cc = c % CPRO;
-        const int m = m0 + row;
-        const int nb = n0 + cc * VEC;
-        if (m >= p.M || nb >= p.N) continue;
-        int b = 0, to = m;
-        if (!ident) {
-            b = m / p.Tm;
-            to = (m - b * p.Tm) * p.out_stride + p.out_off;
-            if (to >= p.Tout) continue;
-        }
-        const size_t orow = (size_t)b * p.Tout + to;
-        const bool live = p.out_len ? (to < p.out_len[b]) : true;
-        float v[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const int n = nb + e;
-            float x = Cs[row * CLD + cc * VEC + e] * p.alpha;
-            if (p.bias && n < p.N) x += p.bias[n];
-            v[e] = x;
-        }
-        if (vec_out) {
-            T tmp[VEC];
-            if (p.preact) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) tmp[e] = from_f32<T>(v[e]);
-                *reinterpret_cast<uint4*>(&p.preact[orow * p.ldp + nb]) = *reinterpret_cast<uint4*>(tmp);
-            }
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] = act_apply(p.act, v[e]);
-            if (p.dact_src) {
-                uint4 dv = *reinterpret_cast<const uint4*>(&p.dact_src[orow * p.ldd + nb]);
-                const T* de = reinterpret_cast<const T*>(&dv);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] *= act_grad(p.dact, to_f32(de[e]));
-            }
-            if (p.residual) {
-                uint4 rv = *reinterpret_cast<const uint4*>(&p.residual[orow * p.ldr + nb]);
-                const T* re = reinterpret_cast<const T*>(&rv);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] += to_f32(re[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) tmp[e] = from_f32<T>(live ? v[e] : 0.f);
-            *reinterpret_cast<uint4*>(&p.C[orow * p.ldc + nb]) = *reinterpret_cast<uint4*>(tmp);
-        } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const int n = nb + e;
-                if (n >= p.N) continue;
-                float x = v[e];
-                if (p.preact) p.preact[orow * p.ldp + n] = from_f32<T>(x);
-                x = act_apply(p.act, x);
-                if (p.dact_src) x *= act_grad(p.dact, to_f32(p.dact_src[orow * p.ldd + n]));
-                if (p.residual) x += to_f32(p.residual[orow * p.ldr + n]);
-                if (!live) x = 0.f;
-                p.C[orow * p.ldc + n] = from_f32<T>(x);
-            }
-        }
-    }
+    gemm_epilogue_store<T, BM, BN, NT>(p, Cs, m0, n0, tid);
 }
 
 template <typename T>
@@ -422,7 +320,9 @@ static int gemm_launch_cfg(const GP<T>& p, hipStream_t st) {
     size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
     size_t sm = ring > cs ? ring : cs;
     auto kern = gemm_kernel<T, BM, BN, WM, WN, D, AL, FU>;
-    if (sm > 48 * 1024) {
+    static bool attr_set = false;             // per instantiation; a host call per launch is visible in eager mode
+    if (sm > 48 * 1024 && !attr_set) {
+        attr_set = true;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) {
             cvft_set_error("cvft_gemm: hipFuncSetAttribute(%zu) failed: %s", sm, hipGetErrorString(e));
@@ -431,6 +331,7 @@ static int gemm_launch_cfg(const GP<T>& p, hipStream_t st) {
     }
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, p);
+    cvft_set_kernel_label("gemm_kernel<%s,%d,%d,%d,%d>%s", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, FU ? ",fusedU" : "");
     CVFT_LAUNCH_CHECK("cvft_gemm");
     return 0;
 }
@@ -475,12 +376,27 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
         }
         long t128f = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         if constexpr (sizeof(T) == 2) {
+            static const int gcfg = getenv("CVFT_GLDS_CFG") ? atoi(getenv("CVFT_GLDS_CFG")) : 0;
+            if (gcfg >= 0) {
+                int rc = gemm_glds_launch(p, st, gcfg);
+                if (rc != 1) return rc;
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
             if (p.K >= 2048 && t128f >= 256) return gemm_launch_cfg<T, 256, 128, 4, 2, 2, true, true>(p, st);
         }
         return gemm_launch_cfg<T, 64, 64, 2, 2, 4, true, true>(p, st);
     }
     al = al && (p.R == 0 || (p.vecU && p.vecB)) && bU < lim && bB < lim;
     if (al) {
+        if constexpr (sizeof(T) == 2) {
+            // LDS-DMA kernels take every eligible shape (CVFT_GLDS_CFG: -1 = off, > 0 = forced tile; experiments)
+            static const int gcfg = getenv("CVFT_GLDS_CFG") ? atoi(getenv("CVFT_GLDS_CFG")) : 0;
+            if (gcfg >= 0) {
+                int rc = gemm_glds_launch(p, st, gcfg);
+                if (rc != 1) return rc;
+            }
+        }
         if constexpr (sizeof(T) == 2) {          // experiment hook: CVFT_GEMM_CFG selects a tile configuration
             static const int cfg = getenv("CVFT_GEMM_CFG") ? atoi(getenv("CVFT_GEMM_CFG")) : 0;
             if (cfg && p.N > 32) {
@@ -491,6 +407,12 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
                     case 4: return gemm_launch_cfg<T, 128, 256, 2, 4, 2, true>(p, st);
                     case 5: return gemm_launch_cfg<T, 64, 64, 2, 2, 4, true>(p, st);
                     case 6: return gemm_launch_cfg<T, 128, 64, 2, 2, 4, true>(p, st);
+                    case 7: return gemm_launch_cfg<T, 32, 64, 2, 2, 4, true>(p, st);
+                    case 8: return gemm_launch_cfg<T, 64, 32, 2, 2, 4, true>(p, st);
+                    case 9: return gemm_launch_cfg<T, 32, 32, 2, 2, 4, true>(p, st);
+                    case 10: return gemm_launch_cfg<T, 32, 64, 1, 2, 4, true>(p, st);
+                    case 11: return gemm_launch_cfg<T, 128, 128, 2, 4, 2, true>(p, st);
+                    case 12: return gemm_launch_cfg<T, 128, 64, 4, 2, 4, true>(p, st);
                     default: break;
                 }
             }

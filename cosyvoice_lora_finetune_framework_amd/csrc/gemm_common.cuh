@@ -1,0 +1,117 @@
+// gemm_common.cuh -- pieces shared by the tap-GEMM kernels (register-staged gemm.hip, LDS-DMA gemm_glds.hip).
+#pragma once
+#include "common.cuh"
+
+#include <utility>
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <typename T>
+struct GP {
+    int M, N, K, Tm, Tin, Tout, in_stride, out_stride, out_off, ntaps;
+    int tap_off[4];
+    const int* in_len;
+    const int* out_len;
+    const T* A; int lda;
+    const T* W; int ldw;
+    const T* U; int ldu; int R;
+    const T* Bl; int ldbl;
+    const float* bias;
+    float alpha;
+    int act;
+    T* preact; int ldp;
+    const T* dact_src; int ldd; int dact;
+    const T* residual; int ldr;
+    T* C; int ldc;
+    int vecA, vecW, vecU, vecB;   // 16-byte vector loads legal for that operand
+    unsigned bytesA, bytesW, bytesU, bytesB;   // buffer extents for the hardware range check
+    // fused side path: U = lora_scale * A_tile . La^T is computed inside this launch (La [R][K], R <= 16),
+    // fed to the rank-R extension step and written to Uout [M][ldu] by the n-tile-0 blocks
+    const T* La; int ldla; unsigned bytesL; float lora_scale; T* Uout; int fuse;
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#define CVFT_OOB 0x80000000u      // byte offset past every buffer (< 2 GiB each, host-checked): the load returns 0
+
+// Epilogue tail shared by every tap-GEMM kernel: Cs holds the block's fp32 accumulators ([BM][BN + 4], already
+// synchronised); rows are written as 16-byte coalesced segments with the bias/act/act'/residual/mask chain.
+template <typename T, int BM, int BN, int NT>
+__device__ __forceinline__ void gemm_epilogue_store(const GP<T>& p, const float* Cs, int m0, int n0, int tid) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int CLD = BN + 4;
+    const bool ident = (p.Tm == p.M) && p.out_stride == 1 && p.out_off == 0;
+    const bool vec_out = (p.N % VEC == 0) && (p.ldc % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                         (!p.preact || ((p.ldp % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.preact) & 15) == 0))) &&
+                         (!p.dact_src || ((p.ldd % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.dact_src) & 15) == 0))) &&
+                         (!p.residual || ((p.ldr % VEC == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
+    constexpr int CPRO = BN / VEC;                 // output chunks per tile row
+    for (int c = tid; c < BM * CPRO; c += NT) {
+        const int row = c / CPRO, cc = c % CPRO;
+        const int m = m0 + row;
+        const int nb = n0 + cc * VEC;
+        if (m >= p.M || nb >= p.N) continue;
+        int b = 0, to = m;
+        if (!ident) {
+            b = m / p.Tm;
+            to = (m - b * p.Tm) * p.out_stride + p.out_off;
+            if (to >= p.Tout) continue;
+        }
+        const size_t orow = (size_t)b * p.Tout + to;
+        const bool live = p.out_len ? (to < p.out_len[b]) : true;
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int n = nb + e;
+            float x = Cs[row * CLD + cc * VEC + e] * p.alpha;
+            if (p.bias && n < p.N) x += p.bias[n];
+            v[e] = x;
+        }
+        if (vec_out) {
+            T tmp[VEC];
+            if (p.preact) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) tmp[e] = from_f32<T>(v[e]);
+                *reinterpret_cast<uint4*>(&p.preact[orow * p.ldp + nb]) = *reinterpret_cast<uint4*>(tmp);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = act_apply(p.act, v[e]);
+            if (p.dact_src) {
+                uint4 dv = *reinterpret_cast<const uint4*>(&p.dact_src[orow * p.ldd + nb]);
+                const T* de = reinterpret_cast<const T*>(&dv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] *= act_grad(p.dact, to_f32(de[e]));
+            }
+            if (p.residual) {
+                uint4 rv = *reinterpret_cast<const uint4*>(&p.residual[orow * p.ldr + nb]);
+                const T* re = reinterpret_cast<const T*>(&rv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] += to_f32(re[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tmp[e] = from_f32<T>(live ? v[e] : 0.f);
+            *reinterpret_cast<uint4*>(&p.C[orow * p.ldc + nb]) = *reinterpret_cast<uint4*>(tmp);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int n = nb + e;
+                if (n >= p.N) continue;
+                float x = v[e];
+                if (p.preact) p.preact[orow * p.ldp + n] = from_f32<T>(x);
+                x = act_apply(p.act, x);
+                if (p.dact_src) x *= act_grad(p.dact, to_f32(p.dact_src[orow * p.ldd + n]));
+                if (p.residual) x += to_f32(p.residual[orow * p.ldr + n]);
+                if (!live) x = 0.f;
+                p.C[orow * p.ldc + n] = from_f32<T>(x);
+            }
+        }
+    }
+}
+
+// LDS-DMA (global_load_lds) bf16 kernels for identity-geometry GEMMs; returns 1 when the shape is not eligible.
+int gemm_glds_launch(const GP<bf16_t>& p, hipStream_t st, int cfg);

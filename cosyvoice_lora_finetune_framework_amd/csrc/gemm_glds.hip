@@ -1,0 +1,256 @@
+// gemm_glds.hip -- bf16 tap-GEMM for the common identity-geometry case (Linear / LoRALinear forward and dgrad),
+// operand tiles moved HBM/L2 -> LDS by the LDS-DMA path (global_load_lds_dwordx4, cdna_hip_programming.md
+// section 5): no staging registers, no ds_write pass, the next k-tile lands while the current one feeds the MFMAs.
+//
+//   C[M,N] = epilogue( alpha * ( A[M,K] . W[N,K]^T  +  U[M,R] . Bl[N,R]^T ) )          K % 64 == 0, R % 8 == 0
+//
+// LDS image of one k-tile: unpadded 128-byte rows (64 bf16), rows in tile order, so one wave-instruction
+// (64 lanes x 16 B) fills 8 consecutive rows -- the DMA's "wave-uniform base + lane * 16" rule.  Bank conflicts of
+// the ds_read_b128 fragment reads are removed by an XOR on the SOURCE side: slot s of row r holds global chunk
+// s ^ ((r >> 1) & 7); readers apply the same XOR.  Two LDS buffers, one barrier per k-tile.
+// The rank-R LoRA extension runs on fragment-shaped direct loads (16 rows x 16 B per lane group) issued before the
+// main loop.  Everything else (row geometry, taps, masks, fp32, odd shapes) stays on gemm.hip's register-staged kernel.
+//
+// Replaces (reference): lora.py:64-76 and the nn.Linear calls of the estimator / encoders, and their dgrad.
+#include "gemm_common.cuh"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// FU: the side-path input  U = lora_scale * A . La^T  (La [R <= 16][K]) is produced inside the launch: the La k-tile
+// rides along as 16 more DMA rows, the wn == 0 waves run one extra MFMA per A fragment, the bf16 result goes through a
+// small LDS panel into every wave's extension fragments, and the n-tile-0 blocks publish it to Uout for backward.
+template <int BM, int BN, int WM, int WN, bool FU>
+__global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
+    typedef bf16_t T;
+    constexpr int NW = WM * WN, NT = NW * 64, BK = 64;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, L_BYTES = FU ? 16 * 128 : 0, BUF = A_BYTES + W_BYTES + L_BYTES;
+    constexpr int UP_OFF = 2 * BUF;                               // FU: [BM][16] bf16 panel behind the ring
+    constexpr int A_INS = BM / 8 / NW, W_INS = BN / 8 / NW;      // DMA wave-instructions per wave per k-tile
+    constexpr int CLD = BN + 4;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA pieces per wave");
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Cs = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap (see gemm.hip)
+        const int nwg = gridDim.x, q = nwg >> 3, rm = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+    }
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
+
+    // DMA sources: lane -> (row piece*8 + lane/8, slot lane%8); rows past the edge are clamped (their outputs are
+    // never stored), the chunk is XOR-ed so the LDS image comes out swizzled
+    const char* ga[A_INS];
+    const char* gw[W_INS];
+#pragma unroll
+    for (int i = 0; i < A_INS; ++i) {
+        const int r = (wid * A_INS + i) * 8 + (lane >> 3);
+        const int gc = (lane & 7) ^ ((r >> 1) & 7);
+        const int m = min(m0 + r, p.M - 1);
+        ga[i] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda + gc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < W_INS; ++i) {
+        const int r = (wid * W_INS + i) * 8 + (lane >> 3);
+        const int gc = (lane & 7) ^ ((r >> 1) & 7);
+        const int n = min(n0 + r, p.N - 1);
+        gw[i] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw + gc * 8);
+    }
+    const char* gl = nullptr;                                     // FU: waves 0/1 each move 8 of the 16 La rows
+    if (FU) {
+        const int r = (wid & 1) * 8 + (lane >> 3);
+        const int gc = (lane & 7) ^ ((r >> 1) & 7);
+        gl = reinterpret_cast<const char*>(p.La + (size_t)min(r, p.R - 1) * p.ldla + gc * 8);
+    }
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* base = smem + buf * BUF;
+        if (FU && wid < 2) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)gl, (lds_void_t*)(base + A_BYTES + W_BYTES + wid * 1024), 16, 0, 0);
+            gl += BK * 2;
+        }
+#pragma unroll
+        for (int i = 0; i < A_INS; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)ga[i], (lds_void_t*)(base + (wid * A_INS + i) * 1024), 16, 0, 0);
+            ga[i] += BK * 2;
+        }
+#pragma unroll
+        for (int i = 0; i < W_INS; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)gw[i], (lds_void_t*)(base + A_BYTES + (wid * W_INS + i) * 1024), 16, 0, 0);
+            gw[i] += BK * 2;
+        }
+    };
+
+    // rank-R extension operands, fragment-shaped, straight to registers (in flight during the whole main loop)
+    constexpr int RS = 2;                         // up to R = 64
+    bf16x8 ua[RS][MI], ub[RS][NI];
+    const int kg = lane >> 4, l15 = lane & 15;
+    const int nrs = (p.R + 31) >> 5;
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) ua[s][i] = Mma<T>::zero();
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ub[s][j] = Mma<T>::zero();
+    }
+    if (p.R > 0) {
+#pragma unroll
+        for (int s = 0; s < RS; ++s) {
+            const int kk = s * 32 + kg * 8;
+            if (kk < p.R) {
+                if (!FU) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int m = m0 + wm * TM + i * 16 + l15;
+                        if (m < p.M) ua[s][i] = *reinterpret_cast<const bf16x8*>(p.U + (size_t)m * p.ldu + kk);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int n = n0 + wn * TN + j * 16 + l15;
+                    if (n < p.N) ub[s][j] = *reinterpret_cast<const bf16x8*>(p.Bl + (size_t)n * p.ldbl + kk);
+                }
+            }
+        }
+    }
+
+    f32x4 acc[MI][NI];
+    f32x4 uacc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        uacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // fragment read addresses: row l15 of a 16-row group, chunk (ks*4 + kg) ^ (l15 >> 1)
+    const int fx = l15 >> 1;
+    const int rd0 = l15 * 128 + ((kg ^ fx) << 4);
+    const int rd1 = l15 * 128 + (((4 + kg) ^ fx) << 4);
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* Ab = smem + buf * BUF + (wm * TM) * 128;
+        const unsigned char* Wb = smem + buf * BUF + A_BYTES + (wn * TN) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rd = ks ? rd1 : rd0;
+            bf16x8 a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 2048 + rd);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Wb + j * 2048 + rd);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma<T>::mma(acc[i][j], a[i], b[j]);
+            if (FU && wn == 0) {                                  // wave-uniform
+                const bf16x8 la = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + A_BYTES + W_BYTES + rd);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) Mma<T>::mma(uacc[i], a[i], la);
+            }
+        }
+    };
+
+    const int nk = p.K / BK;
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile kt has landed (this wave's pieces) ...
+        __syncthreads();                                        // ... everyone's; and buffer (kt+1)&1 is free again
+        if (kt + 1 < nk) issue((kt + 1) & 1);
+        compute(kt & 1);
+    }
+    if (FU) {
+        bf16_t* Up = reinterpret_cast<bf16_t*>(smem + UP_OFF);
+        if (wn == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * TM + i * 16 + kg * 4 + r;
+                    const bf16_t uv = from_f32<T>(l15 < p.R ? uacc[i][r] * p.lora_scale : 0.f);
+                    Up[row * 16 + l15] = uv;
+                    if (n0 == 0 && p.Uout && m0 + row < p.M && l15 < p.R) p.Uout[(size_t)(m0 + row) * p.ldu + l15] = uv;
+                }
+        }
+        __syncthreads();
+        if (kg < 2) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) ua[0][i] = *reinterpret_cast<const bf16x8*>(Up + (wm * TM + i * 16 + l15) * 16 + kg * 8);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < RS; ++s)
+        if (s < nrs) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma<T>::mma(acc[i][j], ua[s][i], ub[s][j]);
+        }
+
+    __syncthreads();                                            // operand ring is dead: reuse it for the fp32 tile
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[(wm * TM + i * 16 + (lane >> 4) * 4 + r) * CLD + wn * TN + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+    gemm_epilogue_store<T, BM, BN, NT>(p, Cs, m0, n0, tid);
+}
+
+template <int BM, int BN, int WM, int WN, bool FU = false>
+static int glds_launch_cfg(const GP<bf16_t>& p, hipStream_t st) {
+    size_t ring = (size_t)2 * (BM + BN + (FU ? 16 : 0)) * 128 + (FU ? BM * 32 : 0);
+    size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
+    size_t sm = ring > cs ? ring : cs;
+    auto kern = gemm_glds_kernel<BM, BN, WM, WN, FU>;
+    static bool attr_set = false;             // per instantiation; a host call per launch is visible in eager mode
+    if (sm > 48 * 1024 && !attr_set) {
+        attr_set = true;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            cvft_set_error("cvft_gemm: hipFuncSetAttribute(%zu) failed: %s", sm, hipGetErrorString(e));
+            return -2;
+        }
+    }
+    long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, p);
+    cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d>%s", BM, BN, WM, WN, FU ? ",fusedU" : "");
+    CVFT_LAUNCH_CHECK("cvft_gemm");
+    return 0;
+}
+
+// cfg: 0 = pick by shape, > 0 = forced tile (experiment hook, CVFT_GLDS_CFG).  Returns 1 when not eligible.
+int gemm_glds_launch(const GP<bf16_t>& p, hipStream_t st, int cfg) {
+    const bool ident = p.ntaps == 1 && p.tap_off[0] == 0 && p.in_stride == 1 && p.Tin == p.Tm && !p.in_len;
+    if (!ident || p.K % 64 != 0 || !p.vecA || !p.vecW || p.N <= 32) return 1;
+    const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (p.fuse) {     // gemm_launch has already checked the La / Bl alignment; R <= 16 by the ABI contract
+        if (p.R < 1 || p.R > 16 || p.Tm != p.M || p.out_stride != 1 || p.out_off != 0) return 1;
+        if (cfg == 8 || (cfg == 0 && t64 >= 1024)) return glds_launch_cfg<128, 64, 4, 2, true>(p, st);
+        return glds_launch_cfg<64, 64, 2, 2, true>(p, st);
+    }
+    if (p.R > 0 && (p.R % 8 != 0 || p.R > 64 || !p.vecU || !p.vecB)) return 1;
+    switch (cfg) {
+        case 1: return glds_launch_cfg<128, 128, 2, 2>(p, st);
+        case 2: return glds_launch_cfg<128, 128, 2, 4>(p, st);
+        case 3: return glds_launch_cfg<128, 64, 2, 2>(p, st);
+        case 4: return glds_launch_cfg<64, 64, 2, 2>(p, st);
+        case 5: return glds_launch_cfg<256, 128, 4, 2>(p, st);
+        case 6: return glds_launch_cfg<128, 256, 2, 4>(p, st);
+        case 7: return glds_launch_cfg<64, 128, 2, 2>(p, st);
+        case 8: return glds_launch_cfg<128, 64, 4, 2>(p, st);
+        default: break;
+    }
+    // measured on MI355X (tools/sweep_gemm.py): 128x64 x 8 waves once there are >= 4 64x64 tiles per CU, else 64x64
+    if (t64 >= 1024) return glds_launch_cfg<128, 64, 4, 2>(p, st);
+    return glds_launch_cfg<64, 64, 2, 2>(p, st);
+}

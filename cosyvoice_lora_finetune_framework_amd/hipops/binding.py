@@ -46,6 +46,7 @@ SIGNATURES = {
     "cvft_version": [],
     "cvft_last_error": [],
     "cvft_gemm": [C.POINTER(GemmArgs), _p],
+    "cvft_gemm_last_kernel": [],
     "cvft_tn_accum": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "cvft_lora_rank_accum": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "cvft_lora_rank_partial": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
@@ -99,7 +100,7 @@ def lib() -> C.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError if a declared symbol is not exported
             fn.argtypes = argtypes
-            fn.restype = C.c_char_p if name == "cvft_last_error" else C.c_int
+            fn.restype = C.c_char_p if name in ("cvft_last_error", "cvft_gemm_last_kernel") else C.c_int
         _lib = l
     return _lib
 

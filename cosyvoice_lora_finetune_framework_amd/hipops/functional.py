@@ -22,16 +22,6 @@ from .binding import ACT, GemmArgs, check, dt, lib, ptr, stream
 PROFILE = None   # bench.py sets this to a list: every tap-GEMM launch is then bracketed by HIP events
 
 
-def _gemm_kernel_name(M: int, N: int, dtype: torch.dtype, Ktot: int = 0) -> str:
-    """Mirror of the tile selection in csrc/gemm.hip::gemm_launch."""
-    t = "bf16" if dtype == torch.bfloat16 else "f32"
-    if N <= 32:
-        return f"gemm_kernel<{t},32,32,2,1>"
-    if dtype == torch.bfloat16 and Ktot >= 2048 and -(-M // 128) * -(-N // 128) >= 256:
-        return f"gemm_kernel<{t},256,128,4,2>"
-    return f"gemm_kernel<{t},64,64,2,2>"
-
-
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -119,8 +109,8 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
         check(lib().cvft_gemm(C.byref(a), stream()), "cvft_gemm")
         e1.record()
         r_eff = a.R if (U is not None or La is not None) else 0
-        PROFILE.append({"kernel": _gemm_kernel_name(a.M, N, x.dtype, ntaps * K) + (",fusedU" if La is not None else ""),
-                        "start": e0, "end": e1,
+        PROFILE.append({"kernel": lib().cvft_gemm_last_kernel().decode(),
+                        "start": e0, "end": e1, "shape": (a.M, N, K, ntaps, a.R if (U is not None or La is not None) else 0),
                         "flop": 2.0 * a.M * N * (ntaps * K + r_eff) + (2.0 * a.M * K * a.R if La is not None else 0.0)})
         return out
     check(lib().cvft_gemm(C.byref(a), stream()), "cvft_gemm")
@@ -172,6 +162,24 @@ class LinearPack:
         self.Wf = weight.detach().to(dtype).contiguous()
         self._Wb = None
         self.bias = None if bias is None else bias.detach().float().contiguous()
+        # N not a multiple of the 16-byte vector (the LLM decoder: 4097 classes): zero-padded copies so that the
+        # forward stores and the dgrad's K extent stay on the aligned kernels; see LinearFn
+        vec = 16 // self.Wf.element_size()
+        self.Npad = self.N if self.N % vec == 0 else -(-self.N // 64) * 64
+        self._pad = None
+
+    @property
+    def padded(self):
+        """(Wf_pad [Npad][K], bias_pad [Npad], Wb_pad [K][Npad]) with zero rows / columns past N."""
+        if self._pad is None:
+            Wf = self.Wf.new_zeros((self.Npad, self.K))
+            Wf[:self.N] = self.Wf
+            b = None
+            if self.bias is not None:
+                b = self.bias.new_zeros(self.Npad)
+                b[:self.N] = self.bias
+            self._pad = (Wf, b, Wf.t().contiguous())
+        return self._pad
 
     @property
     def Wb(self) -> torch.Tensor:
@@ -287,6 +295,30 @@ def _lora_operands(P: torch.Tensor, dtype):
     return _c(Pc), Pc.t().contiguous()
 
 
+# zero-padded row-pitch buffers handed between ops: data_ptr -> (weakref to the [M][pitch] base, pitch).  A [:, :N]
+# view found here may be widened back to the base (its pad columns are zero) instead of being copied.
+_ZERO_PADDED = {}
+
+
+def _register_zero_padded(base: torch.Tensor) -> None:
+    import weakref
+    if len(_ZERO_PADDED) > 64:
+        for k in [k for k, (w, _) in _ZERO_PADDED.items() if w() is None]:
+            del _ZERO_PADDED[k]
+    _ZERO_PADDED[base.data_ptr()] = (weakref.ref(base), base.shape[1])
+
+
+def _widen_zero_padded(t: torch.Tensor, pitch: int) -> torch.Tensor:
+    """[M][N] -> [M][pitch] with zero pad columns (no copy when `t` is a registered zero-padded view)."""
+    ent = _ZERO_PADDED.get(t.data_ptr())
+    if ent is not None and ent[0]() is not None and ent[1] == pitch and t.stride() == (pitch, 1) and \
+            ent[0]().shape[0] == t.shape[0] and ent[0]().dtype == t.dtype:
+        return ent[0]()
+    w = t.new_zeros((t.shape[0], pitch))
+    w[:, :t.shape[1]] = t
+    return w
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b + scale * (x A^T) B^T) (+ residual): reference lora.py:64-76 as ONE
     GEMM launch plus a rank-r pre-GEMM; backward = dgrad (+ rank-r side path) and dA/dB, the latter
@@ -309,6 +341,14 @@ class LinearFn(torch.autograd.Function):
                 U = torch.empty((x.shape[0], Ac.shape[0]), dtype=x.dtype, device=x.device)
             else:
                 U = gemm(x, Ac, alpha=scale)
+        ctx.padded = False
+        if not has_lora and act is None and residual is None and pack.Npad != pack.N:
+            Wf, bias, _ = pack.padded
+            y = gemm(x, Wf, bias=bias)                                  # [M][Npad], pad columns exactly zero
+            _register_zero_padded(y)
+            ctx.pack, ctx.scale, ctx.act, ctx.has_lora, ctx.padded = pack, scale, act, False, True
+            ctx.save_for_backward(x, None, None)
+            return y[:, :pack.N]
         z = torch.empty((x.shape[0], pack.N), dtype=x.dtype, device=x.device) if (act and need_grad) else None
         if fused:
             y = gemm(x, pack.Wf, bias=pack.bias, La=Ac, lora_scale=scale, Uout=U, Bl=Bc, act=act, preact=z,
@@ -324,6 +364,9 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, U, z = ctx.saved_tensors
+        if ctx.padded:
+            dx = gemm(_widen_zero_padded(dy, ctx.pack.Npad), ctx.pack.padded[2]) if ctx.needs_input_grad[0] else None
+            return dx, None, None, None, None, None, None
         dy = _c(dy) if ctx.act else _rowc(dy)
         dz = act_bwd(z, dy, ctx.act) if ctx.act else dy
         dx = dA = dB = None
@@ -750,7 +793,7 @@ class CrossEntropyFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, target):
-        logits = _c(logits)
+        logits = _rowc(logits)
         n, V = logits.shape
         out3 = torch.zeros(3, dtype=torch.float32, device=logits.device)
         row_lse = torch.empty(n, dtype=torch.float32, device=logits.device)
@@ -767,7 +810,12 @@ class CrossEntropyFn(torch.autograd.Function):
         logits, target, row_lse, out3 = ctx.saved_tensors
         n, V = logits.shape
         gs = (g.float() / out3[1]).reshape(1).contiguous()
-        dl = torch.empty_like(logits)
+        pitch = logits.stride(0)
+        base = torch.empty((n, pitch), dtype=logits.dtype, device=logits.device)   # same row pitch as the logits
+        dl = base[:, :V]
+        if pitch > V:
+            base[:, V:].zero_()
+            _register_zero_padded(base)
         check(lib().cvft_ce_bwd(dt(logits), n, V, ptr(logits), logits.stride(0), ptr(target), ptr(row_lse), ptr(gs),
                                 ptr(dl), dl.stride(0), stream()), "cvft_ce_bwd")
         return dl, None

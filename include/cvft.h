@@ -83,6 +83,9 @@ typedef struct {
 } cvft_gemm_args;
 
 int cvft_gemm(const cvft_gemm_args* a, void* stream);
+/* Name of the kernel the calling thread's most recent cvft_gemm launched, e.g. "gemm_glds_kernel<bf16,128,64,4,2>"
+ * (profiling label only: bench.py groups its HIP-event timings by it). */
+const char* cvft_gemm_last_kernel(void);
 
 /* LoRA adapter gradients (lora.py:71-76 backward; W frozen => no wgrad):
  *   dA[r,k] += sum_m V[m,r] * X[m,k]      (V = s * dY B,  already scaled)

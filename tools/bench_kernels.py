@@ -46,7 +46,7 @@ def main():
         t = timeit(lambda: HF.gemm(x, w, bias=b, U=u, Bl=bl, out=out))
         t2 = timeit(lambda: torch.nn.functional.linear(x, w))
         fl = 2 * M * N * (K + 16)
-        print(f"  M{M:5d} N{N:5d} K{K:5d}: {t:7.1f} us  {fl / t / 1e6:7.1f} TF/s   [{HF._gemm_kernel_name(M, N, dt, K)}]   hipBLASLt {t2:7.1f} us {2*M*N*K/t2/1e6:7.1f} TF/s")
+        print(f"  M{M:5d} N{N:5d} K{K:5d}: {t:7.1f} us  {fl / t / 1e6:7.1f} TF/s   [{HF.lib().cvft_gemm_last_kernel().decode()}]   hipBLASLt {t2:7.1f} us {2*M*N*K/t2/1e6:7.1f} TF/s")
     if os.environ.get("ONLY_MAIN"):
         sys.exit(0)
     print("skinny (U = s x A^T):")
