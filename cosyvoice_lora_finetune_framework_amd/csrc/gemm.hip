@@ -734,6 +734,9 @@ extern "C" int cvft_lora_rank_accum(int dtype, int M, int Cn, int r, const void*
     return 0;
 }
 
+int lora_rank_mfma_launch(int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, float* part,
+                          int transpose_out, int rows_per_block, hipStream_t st);
+
 // Two-stage (deterministic, atomic-free) form: slabs, then ONE reduce launch for every adapter of the step.
 extern "C" int cvft_lora_rank_partial(int dtype, int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr,
                                       float* part, int transpose_out, int rows_per_block, void* stream) {
@@ -743,6 +746,13 @@ extern "C" int cvft_lora_rank_partial(int dtype, int M, int Cn, int r, const voi
                    "cvft_lora_rank_partial: rows_per_block must be 64, 128 or a multiple of 256");
     hipStream_t st = (hipStream_t)stream;
     int ldo = transpose_out ? r : Cn;
+    if (dtype == CVFT_BF16) {          // matrix-core kernel (lora_grad.hip) for every eligible bf16 launch
+        static const int off = getenv("CVFT_RANK_VALU") ? atoi(getenv("CVFT_RANK_VALU")) : 0;
+        if (!off && lora_rank_mfma_launch(M, Cn, r, Wd, ldw, Rk, ldr, part, transpose_out, rows_per_block, st) == 0) {
+            CVFT_LAUNCH_CHECK("cvft_lora_rank_partial");
+            return 0;
+        }
+    }
     int rc = dtype == CVFT_F32 ? rank_accum_launch<float>(M, Cn, r, Wd, ldw, Rk, ldr, part, ldo, transpose_out, st, rows_per_block)
                                : rank_accum_launch<bf16_t>(M, Cn, r, Wd, ldw, Rk, ldr, part, ldo, transpose_out, st, rows_per_block);
     CVFT_CHECK_ARG(rc == 0, "cvft_lora_rank_partial: operands must be 16-byte aligned with C %% VEC == 0");

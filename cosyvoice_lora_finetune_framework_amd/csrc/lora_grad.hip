@@ -1,0 +1,179 @@
+// lora_grad.hip -- LoRA adapter gradients on the matrix cores (bf16, deterministic slab mode).
+//
+//   slab_y[j, c] = sum_{m in rows of slab y} Rk[m, j] * Wd[m, c]          (dA = V^T X,  dB^T = U^T dY)
+//
+// Both operands are stored with the reduction index m as the SLOW index, i.e. transposed for the MFMA's
+// k-contiguous operand layout.  gfx950's ds_read_b64_tr_b16 does that transpose for free on the LDS read
+// (cdna_hip_programming.md T10), so the wide operand goes HBM/L2 -> LDS by LDS-DMA in its natural row-major
+// form (128-byte row segments, source-side XOR swizzle for the transposed reads) and is never touched by VALU.
+// One wavefront owns a 64-column stripe and a contiguous row range: no cross-wave reduction, no barrier, no
+// atomics; accumulators go straight to the slab with 64-byte coalesced stores.  The VALU kernel this replaces
+// (gemm.hip lora_rank_accum_vec_kernel) spent 128 FMAs + conversions per 16-byte load and a 128 KB LDS reduction
+// per 8 KB of input.
+//
+// Replaces (reference): the autograd of lora.py:71-76 (grad of lora_A / lora_B).
+#include "common.cuh"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* lo, const unsigned char* hi) {
+    bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)lo);
+    bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)hi);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// RB = r / 16.  Block = 4 wavefronts = 4 x 64 columns; blockIdx.y = slab; each wave walks its slab's rows in
+// 32-row chunks (MFMA k = 32), double-buffered in a private LDS region.
+template <int RB>
+__global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, int Cn, const bf16_t* __restrict__ Wd, int ldw,
+                                                             const bf16_t* __restrict__ Rk, int ldr,
+                                                             float* __restrict__ out, int ldo, int transpose_out,
+                                                             size_t part_stride, int rows_per_block) {
+    constexpr int R = RB * 16;
+    constexpr int WD_BYTES = 32 * 128;               // 32 rows x 64 columns
+    constexpr int RK_BYTES = 32 * R * 2;
+    constexpr int BUF = WD_BYTES + RK_BYTES;
+    constexpr int RCH = R / 8;                       // 16-byte chunks per Rk row
+    constexpr int RK_ROWS_PER_INS = 64 / RCH;        // rows one wave-wide 16-byte load covers
+    constexpr int RK_INS = 32 / RK_ROWS_PER_INS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = (blockIdx.x * 4 + wid) * 64;
+    if (c0 >= Cn) return;                            // whole wave (no barriers in this kernel)
+    const int mb = blockIdx.y * rows_per_block;
+    const int me = min(M, mb + rows_per_block);
+    const int nchunk = (me - mb + 31) >> 5;
+    unsigned char* my = smem + wid * 2 * BUF;
+
+    // DMA source of the wide operand: lane -> (row i*8 + lane/8, slot lane%8); slot s of row r holds global chunk
+    // s ^ f(r), f(r) = 2*bit1(r) | 4*bit3(r), which makes the transposed reads below bank-conflict free.  Rows past
+    // the slab end are clamped to the last valid row (their Rk rows are zero), chunks past Cn to the last valid chunk.
+    const int nchk = Cn >> 3;
+    int w_row[4], w_chk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = i * 8 + (lane >> 3);
+        const int f = (((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2);
+        w_row[i] = r;
+        w_chk[i] = min((c0 >> 3) + ((lane & 7) ^ f), nchk - 1);
+    }
+    auto issue = [&](int chunk, int buf) __attribute__((always_inline)) {
+        const int m0 = mb + chunk * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = min(m0 + w_row[i], me - 1);
+            const bf16_t* g = Wd + (size_t)m * ldw + w_chk[i] * 8;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)(my + buf * BUF + i * 1024), 16, 0, 0);
+        }
+    };
+    // narrow operand: guarded register loads (zero rows past the slab end), written to LDS row-major
+    uint4 rk[RK_INS];
+    const int rk_row = lane / RCH, rk_c = lane % RCH;
+    auto load_rk = [&](int chunk) __attribute__((always_inline)) {
+        const int m0 = mb + chunk * 32;
+#pragma unroll
+        for (int i = 0; i < RK_INS; ++i) {
+            const int m = m0 + i * RK_ROWS_PER_INS + rk_row;
+            rk[i] = m < me ? *reinterpret_cast<const uint4*>(Rk + (size_t)m * ldr + rk_c * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_rk = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < RK_INS; ++i)
+            *reinterpret_cast<uint4*>(my + buf * BUF + WD_BYTES + ((i * RK_ROWS_PER_INS + rk_row) * RCH + rk_c) * 16) = rk[i];
+    };
+
+    f32x4 acc[RB][4];
+#pragma unroll
+    for (int jb = 0; jb < RB; ++jb)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[jb][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read addresses: lane 4q+p of 16-lane group kg supplies row 8kg + q (+4), columns 4p..4p+3
+    const int kg = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int rlo = 8 * kg + q, rhi = rlo + 4;
+    const int flo = (((rlo >> 1) & 1) << 1) | (((rlo >> 3) & 1) << 2);
+    const int fhi = (((rhi >> 1) & 1) << 1) | (((rhi >> 3) & 1) << 2);
+    int b_lo[4], b_hi[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int ch = nt * 2 + (pp >> 1);
+        b_lo[nt] = rlo * 128 + ((ch ^ flo) << 4) + 8 * (pp & 1);
+        b_hi[nt] = rhi * 128 + ((ch ^ fhi) << 4) + 8 * (pp & 1);
+    }
+    const int a_lo = WD_BYTES + rlo * (R * 2) + pp * 8, a_hi = WD_BYTES + rhi * (R * 2) + pp * 8;
+
+    issue(0, 0);
+    load_rk(0);
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk c: DMA landed, Rk registers arrived
+        store_rk(buf);
+        if (c + 1 < nchunk) {                                  // wave-uniform
+            issue(c + 1, buf ^ 1);
+            load_rk(c + 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned char* bb = my + buf * BUF;
+        bf16x8 a[RB], b[4];
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) a[jb] = tr_read8(bb + a_lo + jb * 32, bb + a_hi + jb * 32);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) b[nt] = tr_read8(bb + b_lo[nt], bb + b_hi[nt]);
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[jb][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jb], b[nt], acc[jb][nt], 0, 0, 0);
+    }
+
+    // acc[jb][nt][i] = slab[j = jb*16 + kg*4 + i][c = c0 + nt*16 + (lane & 15)]
+    float* base = out + (size_t)blockIdx.y * part_stride;
+    const int l15 = lane & 15;
+#pragma unroll
+    for (int jb = 0; jb < RB; ++jb)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int cl = c0 + nt * 16 + l15;
+            if (cl >= Cn) continue;
+            const int j = jb * 16 + kg * 4;
+            if (transpose_out) {
+                *reinterpret_cast<float4*>(&base[(size_t)cl * ldo + j]) =
+                    make_float4(acc[jb][nt][0], acc[jb][nt][1], acc[jb][nt][2], acc[jb][nt][3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) base[(size_t)(j + i) * ldo + cl] = acc[jb][nt][i];
+            }
+        }
+}
+
+// Slab mode only (part_stride = r * Cn): returns 1 when the operands are not eligible.
+int lora_rank_mfma_launch(int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, float* part,
+                          int transpose_out, int rows_per_block, hipStream_t st) {
+    const bool ok = (r == 16 || r == 32 || r == 64) && Cn % 8 == 0 && ldw % 8 == 0 && ldr % 8 == 0 &&
+                    (reinterpret_cast<uintptr_t>(Wd) & 15) == 0 && (reinterpret_cast<uintptr_t>(Rk) & 15) == 0 &&
+                    rows_per_block % 32 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+    if (!ok) return 1;
+    const int ldo = transpose_out ? r : Cn;
+    const size_t part_stride = (size_t)r * Cn;
+    dim3 grid((Cn + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
+    const size_t sm = (size_t)4 * 2 * (32 * 128 + 32 * r * 2);
+#define RM_LAUNCH(RBv)                                                                                                   \
+    do {                                                                                                                 \
+        auto kern = lora_rank_mfma_kernel<RBv>;                                                                          \
+        static bool attr_set = false;                                                                                    \
+        if (sm > 48 * 1024 && !attr_set) {                                                                               \
+            attr_set = true;                                                                                             \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        }                                                                                                                \
+        hipLaunchKernelGGL(kern, grid, dim3(256), sm, st, M, Cn, (const bf16_t*)Wd, ldw, (const bf16_t*)Rk, ldr, part,    \
+                           ldo, transpose_out, part_stride, rows_per_block);                                            \
+    } while (0)
+    if (r == 16) RM_LAUNCH(1); else if (r == 32) RM_LAUNCH(2); else RM_LAUNCH(4);
+#undef RM_LAUNCH
+    return 0;
+}
