@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       int relu, float post, const T* __restrict__ dy,
-                                                      T* __restrict__ dx) {
+                                                      const T* __restrict__ dres, T* __restrict__ dx) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int NCH = 4;
     const int lane = threadIdx.x & 63;
@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
     const T* xr = x + (size_t)row * C;
     const T* dr = dy + (size_t)row * C;
     T* ox = dx + (size_t)row * C;
+    const T* rr = dres ? dres + (size_t)row * C : nullptr;      // second gradient branch of x, added into dx
     const float mu = mean[row], rs = rstd[row];
     if (VP) {
         const int nch = C / VEC;
@@ -129,8 +130,17 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
             const int ch = lane + q * 64;
             if (ch < nch) {
                 T o[VEC];
+                float add[VEC];
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) o[k] = from_f32<T>(rs * (g[q][k] - s1 - xh[q][k] * s2));
+                for (int k = 0; k < VEC; ++k) add[k] = 0.f;
+                if (rr) {
+                    uint4 ra = *reinterpret_cast<const uint4*>(rr + ch * VEC);
+                    const T* ea = reinterpret_cast<const T*>(&ra);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) add[k] = to_f32(ea[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o[k] = from_f32<T>(rs * (g[q][k] - s1 - xh[q][k] * s2) + add[k]);
                 *reinterpret_cast<uint4*>(ox + ch * VEC) = *reinterpret_cast<uint4*>(o);
             }
         }
@@ -152,7 +162,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
         float g = to_f32(dr[c]) * post;
         if (relu && (xh * gamma[c] + beta[c]) <= 0.f) g = 0.f;
         g *= gamma[c];
-        ox[c] = from_f32<T>(rs * (g - s1 - xh * s2));
+        ox[c] = from_f32<T>(rs * (g - s1 - xh * s2) + (rr ? to_f32(rr[c]) : 0.f));
     }
 }
 
@@ -182,16 +192,17 @@ extern "C" int cvft_layernorm_fwd(int dtype, int rows, int C, const void* x, con
 
 extern "C" int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, const float* gamma, const float* beta,
                                   const float* mean, const float* rstd, int relu, float post_scale, const void* dy,
-                                  void* dx, void* stream) {
+                                  const void* dres, void* dx, void* stream) {
     CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_layernorm_bwd: bad dtype");
     CVFT_CHECK_ARG(rows >= 0 && C > 0 && x && gamma && beta && mean && rstd && dy && dx, "cvft_layernorm_bwd: bad args");
     if (rows == 0) return 0;
     dim3 grid((rows + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
 #define LN_BWD(TT, VPv) hipLaunchKernelGGL((ln_bwd_kernel<TT, VPv>), grid, dim3(256), 0, st, rows, C, (const TT*)x, gamma, beta, mean, \
-                                           rstd, relu, post_scale, (const TT*)dy, (TT*)dx)
-    if (dtype == CVFT_F32) { if (ln_vec_ok<float>(C, x, dy, dx)) LN_BWD(float, true); else LN_BWD(float, false); }
-    else { if (ln_vec_ok<bf16_t>(C, x, dy, dx)) LN_BWD(bf16_t, true); else LN_BWD(bf16_t, false); }
+                                           rstd, relu, post_scale, (const TT*)dy, (const TT*)dres, (TT*)dx)
+    const bool ra = (reinterpret_cast<uintptr_t>(dres) & 15) == 0;
+    if (dtype == CVFT_F32) { if (ra && ln_vec_ok<float>(C, x, dy, dx)) LN_BWD(float, true); else LN_BWD(float, false); }
+    else { if (ra && ln_vec_ok<bf16_t>(C, x, dy, dx)) LN_BWD(bf16_t, true); else LN_BWD(bf16_t, false); }
 #undef LN_BWD
     CVFT_LAUNCH_CHECK("cvft_layernorm_bwd");
     return 0;

@@ -274,7 +274,8 @@ class LoraGradSink:
         self.tasks = []
 
 
-FUSE_MAX_MN = 3_000_000   # measured (tools/bench_fused.py): the in-launch side path wins for the small estimator GEMMs only
+import os as _os
+FUSE_MAX_MN = int(_os.environ.get('CVFT_FUSE_MAX_MN', 3_000_000))   # measured (tools/bench_fused.py): the in-launch side path wins for the small estimator GEMMs only
 
 
 def _can_fuse(x: torch.Tensor, La: torch.Tensor, Bl: torch.Tensor, N: int, K: int) -> bool:
@@ -319,6 +320,85 @@ def _widen_zero_padded(t: torch.Tensor, pitch: int) -> torch.Tensor:
     return w
 
 
+def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residual, keep_preact: bool):
+    """One LoRA linear forward: y = act(x W^T + b + scale * (x A^T) B^T) (+ residual).
+    Returns (y, U, z, ops): U = scale * x A^T [M, r] (saved for dB), z = pre-activation (when kept), ops = the
+    compute-dtype (A, A^T, B, B^T) operands."""
+    U = z = ops = None
+    fused = False
+    if A is not None:
+        Ac, At = _lora_operands(A, x.dtype)
+        Bc, Bt = _lora_operands(B, x.dtype)
+        ops = (Ac, At, Bc, Bt)
+        fused = _can_fuse(x, Ac, Bc, pack.N, pack.K)
+        if fused:
+            U = torch.empty((x.shape[0], Ac.shape[0]), dtype=x.dtype, device=x.device)
+        else:
+            U = gemm(x, Ac, alpha=scale)
+    if act and keep_preact:
+        z = torch.empty((x.shape[0], pack.N), dtype=x.dtype, device=x.device)
+    res = None if residual is None else _c(residual)
+    if fused:
+        y = gemm(x, pack.Wf, bias=pack.bias, La=ops[0], lora_scale=scale, Uout=U, Bl=ops[2], act=act, preact=z, residual=res)
+    else:
+        y = gemm(x, pack.Wf, bias=pack.bias, U=U, Bl=None if ops is None else ops[2], act=act, preact=z, residual=res)
+    return y, U, z, ops
+
+
+def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_dx: bool, need_dAB: bool,
+             dx_residual=None, dact_src=None, dact: Optional[str] = None):
+    """Backward of one LoRA linear given dz = gradient at its pre-activation output.
+    dx = (dz W + (scale * dz B) A) [* act'(dact_src)] [+ dx_residual]  -- the last two ride in the dgrad epilogue
+    (fused producer-activation backward, fused gradient accumulation);  dA / dB go to the parameters' flat .grad
+    buffers (through the active LoraGradSink when there is one) or are returned."""
+    dx = dA = dB = V = None
+    has_lora = ops is not None
+    if has_lora:
+        Ac, At, Bc, Bt = ops
+        if need_dx and _can_fuse(dz, Bt, At, pack.K, pack.N):
+            # dgrad with the side path fused: V = s * dz B is produced by the same launch
+            V = torch.empty((dz.shape[0], Bt.shape[0]), dtype=dz.dtype, device=dz.device)
+            dx = gemm(dz, pack.Wb, La=Bt, lora_scale=scale, Uout=V, Bl=At, dact_src=dact_src, dact=dact, residual=dx_residual)
+        elif need_dx or need_dAB:
+            V = gemm(dz, Bt, alpha=scale)                         # [M, r] = s * dz B
+    if need_dx and dx is None:
+        dx = gemm(dz, pack.Wb, U=V, Bl=None if V is None else ops[1], dact_src=dact_src, dact=dact, residual=dx_residual)
+    if has_lora and need_dAB:
+        A, B = A_ref, B_ref
+        gA, gB = A.grad, B.grad
+        direct = gA is not None and gB is not None and gA.dtype == torch.float32 and gA.is_contiguous() \
+            and gB.is_contiguous() and gA.dim() == 2 and gB.dim() == 2
+        if not direct:
+            gA = torch.zeros(ops[0].shape, dtype=torch.float32, device=x.device)
+            gB = torch.zeros(ops[2].shape, dtype=torch.float32, device=x.device)
+        sink = LoraGradSink.active
+        r = V.shape[1]
+        vec = 8 if x.dtype == torch.bfloat16 else 4
+        if (sink is not None and direct and r % 16 == 0 and x.shape[1] % vec == 0 and dz.shape[1] % vec == 0
+                and x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0):
+            M = x.shape[0]
+            # the slab kernels are off the critical path (nothing downstream in backward reads them): launch them
+            # on the sink's side stream so they overlap the latency-bound dgrad chain; joined in sink.flush()
+            cur = torch.cuda.current_stream()
+            ctxm = torch.cuda.stream(sink.side) if sink.side is not None else contextlib.nullcontext()
+            if sink.side is not None:
+                sink.side.wait_stream(cur)
+                sink.keep.append((x, V, dz, U))
+            with ctxm:
+                for Wd, Rk, P, g, tr in ((x, V, A, gA, False), (dz, U, B, gB, True)):
+                    rpb, ns = LoraGradSink.plan(M, Wd.shape[1])
+                    ws = LoraGradSink.workspace(P, ns)
+                    check(lib().cvft_lora_rank_partial(dt(Wd), M, Wd.shape[1], r, ptr(Wd), Wd.stride(0), ptr(Rk),
+                                                       Rk.stride(0), ptr(ws), int(tr), rpb, stream()), "cvft_lora_rank_partial")
+                    sink.add(ws, g, P.numel(), ns)
+        else:
+            rank_accum(x, V, gA, False)                               # dA[r,K] += V^T x
+            rank_accum(dz, U, gB, True)                               # dB[N,r] += dz^T U
+        if not direct:
+            dA, dB = gA, gB
+    return dx, dA, dB
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b + scale * (x A^T) B^T) (+ residual): reference lora.py:64-76 as ONE
     GEMM launch plus a rank-r pre-GEMM; backward = dgrad (+ rank-r side path) and dA/dB, the latter
@@ -327,36 +407,17 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, A, B, residual, pack: LinearPack, scale: float, act: Optional[str]):
         x = _c(x)
-        has_lora = A is not None
         need_grad = any(ctx.needs_input_grad[:3])
-        U = None
-        ops = None
-        fused = False
-        if has_lora:
-            Ac, At = _lora_operands(A, x.dtype)
-            Bc, Bt = _lora_operands(B, x.dtype)
-            ops = (Ac, At, Bc, Bt)
-            fused = _can_fuse(x, Ac, Bc, pack.N, pack.K)
-            if fused:
-                U = torch.empty((x.shape[0], Ac.shape[0]), dtype=x.dtype, device=x.device)
-            else:
-                U = gemm(x, Ac, alpha=scale)
         ctx.padded = False
-        if not has_lora and act is None and residual is None and pack.Npad != pack.N:
+        if A is None and act is None and residual is None and pack.Npad != pack.N:
             Wf, bias, _ = pack.padded
             y = gemm(x, Wf, bias=bias)                                  # [M][Npad], pad columns exactly zero
             _register_zero_padded(y)
-            ctx.pack, ctx.scale, ctx.act, ctx.has_lora, ctx.padded = pack, scale, act, False, True
+            ctx.pack, ctx.padded = pack, True
             ctx.save_for_backward(x, None, None)
             return y[:, :pack.N]
-        z = torch.empty((x.shape[0], pack.N), dtype=x.dtype, device=x.device) if (act and need_grad) else None
-        if fused:
-            y = gemm(x, pack.Wf, bias=pack.bias, La=Ac, lora_scale=scale, Uout=U, Bl=Bc, act=act, preact=z,
-                     residual=None if residual is None else _c(residual))
-        else:
-            y = gemm(x, pack.Wf, bias=pack.bias, U=U, Bl=None if ops is None else ops[2], act=act, preact=z,
-                     residual=None if residual is None else _c(residual))
-        ctx.pack, ctx.scale, ctx.act, ctx.has_lora = pack, scale, act, has_lora
+        y, U, z, ops = _lin_fwd(x, A, B, pack, scale, act, residual, need_grad)
+        ctx.pack, ctx.scale, ctx.act = pack, scale, act
         ctx.ops, ctx.A_ref, ctx.B_ref = ops, A, B
         ctx.save_for_backward(x, U, z)
         return y
@@ -369,57 +430,91 @@ class LinearFn(torch.autograd.Function):
             return dx, None, None, None, None, None, None
         dy = _c(dy) if ctx.act else _rowc(dy)
         dz = act_bwd(z, dy, ctx.act) if ctx.act else dy
-        dx = dA = dB = None
-        V = None
-        if ctx.has_lora:
-            Ac, At, Bc, Bt = ctx.ops
-            if ctx.needs_input_grad[0] and _can_fuse(dz, Bt, At, ctx.pack.K, ctx.pack.N):
-                # dgrad with the side path fused: V = s * dz B is produced by the same launch
-                V = torch.empty((dz.shape[0], Bt.shape[0]), dtype=dz.dtype, device=dz.device)
-                dx = gemm(dz, ctx.pack.Wb, La=Bt, lora_scale=ctx.scale, Uout=V, Bl=At)
-            else:
-                V = gemm(dz, Bt, alpha=ctx.scale)                         # [M, r] = s * dz B
-        if ctx.needs_input_grad[0] and dx is None:
-            dx = gemm(dz, ctx.pack.Wb, U=V, Bl=None if V is None else At)
-        if ctx.has_lora and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
-            A, B = ctx.A_ref, ctx.B_ref
-            gA, gB = A.grad, B.grad
-            direct = gA is not None and gB is not None and gA.dtype == torch.float32 and gA.is_contiguous() \
-                and gB.is_contiguous() and gA.dim() == 2 and gB.dim() == 2
-            if not direct:
-                gA = torch.zeros(Ac.shape, dtype=torch.float32, device=x.device)
-                gB = torch.zeros(Bc.shape, dtype=torch.float32, device=x.device)
-            sink = LoraGradSink.active
-            r = V.shape[1]
-            vec = 8 if x.dtype == torch.bfloat16 else 4
-            if (sink is not None and direct and r % 16 == 0 and x.shape[1] % vec == 0 and dz.shape[1] % vec == 0
-                    and x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0):
-                M = x.shape[0]
-                # the slab kernels are off the critical path (nothing downstream in backward reads them): launch them
-                # on the sink's side stream so they overlap the latency-bound dgrad chain; joined in sink.flush()
-                cur = torch.cuda.current_stream()
-                ctxm = torch.cuda.stream(sink.side) if sink.side is not None else contextlib.nullcontext()
-                if sink.side is not None:
-                    sink.side.wait_stream(cur)
-                    sink.keep.append((x, V, dz, U))
-                with ctxm:
-                    for Wd, Rk, P, g, tr in ((x, V, A, gA, False), (dz, U, B, gB, True)):
-                        rpb, ns = LoraGradSink.plan(M, Wd.shape[1])
-                        ws = LoraGradSink.workspace(P, ns)
-                        check(lib().cvft_lora_rank_partial(dt(Wd), M, Wd.shape[1], r, ptr(Wd), Wd.stride(0), ptr(Rk),
-                                                           Rk.stride(0), ptr(ws), int(tr), rpb, stream()), "cvft_lora_rank_partial")
-                        sink.add(ws, g, P.numel(), ns)
-            else:
-                rank_accum(x, V, gA, False)                               # dA[r,K] += V^T x
-                rank_accum(dz, U, gB, True)                               # dB[N,r] += dz^T U
-            if not direct:
-                dA, dB = gA, gB
+        dx, dA, dB = _lin_bwd(x, U, ctx.ops, ctx.A_ref, ctx.B_ref, ctx.pack, ctx.scale, dz, ctx.needs_input_grad[0],
+                              ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         dres = dy if ctx.needs_input_grad[3] else None
         return dx, dA, dB, dres, None, None, None
 
 
+class LinearQKVFn(torch.autograd.Function):
+    """q, k, v = three LoRA linears of the SAME input (attention projections).  Forward is three launches; the
+    point is backward: dx = dq Wq + dk Wk + dv Wv is accumulated through the dgrad epilogue (each launch adds the
+    previous partial), so autograd never sees three separate dx tensors to sum."""
+
+    @staticmethod
+    def forward(ctx, x, Aq, Bq, Ak, Bk, Av, Bv, packs, scales):
+        x = _c(x)
+        outs, saved, ctx.ops = [], [x], []
+        for (A, B), pack, s in zip(((Aq, Bq), (Ak, Bk), (Av, Bv)), packs, scales):
+            y, U, _, ops = _lin_fwd(x, A, B, pack, s, None, None, False)
+            outs.append(y)
+            saved.append(U)
+            ctx.ops.append(ops)
+        ctx.packs, ctx.scales, ctx.refs = packs, scales, ((Aq, Bq), (Ak, Bk), (Av, Bv))
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x, Uq, Uk, Uv = ctx.saved_tensors
+        dx = None
+        grads = []
+        for i, (d, U) in enumerate(((dq, Uq), (dk, Uk), (dv, Uv))):
+            A, B = ctx.refs[i]
+            if d is None:
+                grads += [None, None]
+                continue
+            need_dAB = ctx.needs_input_grad[1 + 2 * i] or ctx.needs_input_grad[2 + 2 * i]
+            dxi, dA, dB = _lin_bwd(x, U, ctx.ops[i], A, B, ctx.packs[i], ctx.scales[i], _rowc(d), ctx.needs_input_grad[0],
+                                   need_dAB, dx_residual=dx)
+            dx = dxi if dxi is not None else dx
+            grads += [dA, dB]
+        return (dx, *grads, None, None)
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """y = W2 act(W1 x + b1) + b2 (+ residual), both linears with optional LoRA.  Backward applies act'(z) in the
+    epilogue of W2's dgrad launch (no separate activation-backward pass over the [M, hidden] tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, A1, B1, A2, B2, residual, pack1, pack2, s1: float, s2: float, act: str):
+        x = _c(x)
+        need_grad = any(ctx.needs_input_grad[:5])
+        h, U1, z, ops1 = _lin_fwd(x, A1, B1, pack1, s1, act, None, need_grad)
+        y, U2, _, ops2 = _lin_fwd(h, A2, B2, pack2, s2, None, residual, False)
+        ctx.cfg = (pack1, pack2, s1, s2, act, ops1, ops2, (A1, B1), (A2, B2))
+        ctx.save_for_backward(x, U1, z, h if A2 is not None else None, U2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, U1, z, h, U2 = ctx.saved_tensors
+        pack1, pack2, s1, s2, act, ops1, ops2, (A1, B1), (A2, B2) = ctx.cfg
+        dy = _rowc(dy)
+        need1 = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        need2 = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        need_dx = ctx.needs_input_grad[0]
+        dz, dA2, dB2 = _lin_bwd(h, U2, ops2, A2, B2, pack2, s2, dy, need_dx or need1, need2, dact_src=z, dact=act)
+        dx = dA1 = dB1 = None
+        if dz is not None:
+            dx, dA1, dB1 = _lin_bwd(x, U1, ops1, A1, B1, pack1, s1, dz, need_dx, need1)
+        dres = dy if ctx.needs_input_grad[5] else None
+        return dx, dA1, dB1, dA2, dB2, dres, None, None, None, None, None
+
+
 def lora_linear(x, pack: LinearPack, A=None, B=None, scale: float = 1.0, act: Optional[str] = None, residual=None):
     return LinearFn.apply(x, A, B, residual, pack, scale, act)
+
+
+def lora_linear_qkv(x, packs, loras, scales):
+    """(q, k, v) = three LoRA linears of x; loras = ((Aq, Bq), (Ak, Bk), (Av, Bv)) with None entries for plain layers."""
+    (Aq, Bq), (Ak, Bk), (Av, Bv) = loras
+    return LinearQKVFn.apply(x, Aq, Bq, Ak, Bk, Av, Bv, tuple(packs), tuple(scales))
+
+
+def lora_feed_forward(x, pack1, pack2, lora1=(None, None), lora2=(None, None), s1: float = 1.0, s2: float = 1.0,
+                      act: str = "relu", residual=None):
+    return FeedForwardFn.apply(x, lora1[0], lora1[1], lora2[0], lora2[1], residual, pack1, pack2, s1, s2, act)
 
 
 # ---------------------------------------------------------------------------------
@@ -536,12 +631,47 @@ class LayerNormFn(torch.autograd.Function):
         dy = _c(dy)
         dx = torch.empty_like(x)
         check(lib().cvft_layernorm_bwd(dt(x), x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
-                                       int(ctx.relu), ctx.post, ptr(dy), ptr(dx), stream()), "cvft_layernorm_bwd")
+                                       int(ctx.relu), ctx.post, ptr(dy), None, ptr(dx), stream()), "cvft_layernorm_bwd")
         return dx, None, None, None, None, None
 
 
 def layernorm(x, gamma, beta, eps: float = 1e-5, relu: bool = False, post_scale: float = 1.0):
     return LayerNormFn.apply(x, gamma, beta, eps, relu, post_scale)
+
+
+class LayerNormForkFn(torch.autograd.Function):
+    """(x, LN(x)) for the pre-norm residual pattern  x + f(LN(x)):  both gradient branches of x arrive at this one
+    node, so  dx = d_residual + LN'(d_normed)  is ONE kernel (cvft_layernorm_bwd `dres`) instead of a LayerNorm
+    backward plus an autograd accumulation add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float):
+        x = _c(x)
+        rows, Cn = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib().cvft_layernorm_fwd(dt(x), rows, Cn, ptr(x), ptr(gamma), ptr(beta), eps, 0, 1.0,
+                                       ptr(y), ptr(mean), ptr(rstd), stream()), "cvft_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        dy = _c(dy)
+        dres = None if dres is None else _c(dres)
+        dx = torch.empty_like(x)
+        check(lib().cvft_layernorm_bwd(dt(x), x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                       0, 1.0, ptr(dy), ptr(dres), ptr(dx), stream()), "cvft_layernorm_bwd")
+        return dx, None, None, None
+
+
+def layernorm_fork(x, gamma, beta, eps: float = 1e-5):
+    """-> (x_residual, LN(x)); use x_residual (not x) for the residual connection."""
+    return LayerNormForkFn.apply(x, gamma, beta, eps)
 
 
 class GroupNormMishFn(torch.autograd.Function):

@@ -83,6 +83,29 @@ def hip_linear(mod: nn.Module, x: torch.Tensor, dtype: Optional[torch.dtype] = N
     return HF.lora_linear(x, pack, A, Bm, scale, act, residual)
 
 
+def _lora_dropout_on(mod: nn.Module, drop) -> bool:
+    return mod.training and isinstance(drop, nn.Dropout) and drop.p > 0
+
+
+def hip_qkv(mq: nn.Module, mk: nn.Module, mv: nn.Module, x: torch.Tensor):
+    """(q, k, v) projections of one input with the input-gradient accumulation fused (HF.LinearQKVFn)."""
+    parts = [_lin_parts(m) for m in (mq, mk, mv)]
+    if any(p[3] is not None and _lora_dropout_on(m, p[6]) for m, p in zip((mq, mk, mv), parts)):
+        return hip_linear(mq, x), hip_linear(mk, x), hip_linear(mv, x)
+    packs = [_cached(p[0], "lin", p[0].weight, x.dtype, lambda p=p: HF.LinearPack(p[1], p[2], x.dtype)) for p in parts]
+    return HF.lora_linear_qkv(x, packs, [(p[3], p[4]) for p in parts], [p[5] for p in parts])
+
+
+def hip_ffn(m1: nn.Module, m2: nn.Module, x: torch.Tensor, act: str, residual: Optional[torch.Tensor] = None):
+    """W2 act(W1 x) (+ residual) with the activation backward fused into W2's dgrad (HF.FeedForwardFn)."""
+    p1, p2 = _lin_parts(m1), _lin_parts(m2)
+    if (p1[3] is not None and _lora_dropout_on(m1, p1[6])) or (p2[3] is not None and _lora_dropout_on(m2, p2[6])):
+        return hip_linear(m2, hip_linear(m1, x, act=act), residual=residual)
+    k1 = _cached(p1[0], "lin", p1[0].weight, x.dtype, lambda: HF.LinearPack(p1[1], p1[2], x.dtype))
+    k2 = _cached(p2[0], "lin", p2[0].weight, x.dtype, lambda: HF.LinearPack(p2[1], p2[2], x.dtype))
+    return HF.lora_feed_forward(x, k1, k2, (p1[3], p1[4]), (p2[3], p2[4]), p1[5], p2[5], act, residual)
+
+
 def _lora_dropout_path(x, pack, A, Bm, scale, drop, act, residual):
     # y = act(x W^T + b + s * (drop(x) A^T) B^T): main GEMM without side path + separate rank-r GEMMs
     assert act is None, "LoRA dropout with a fused activation is not supported"
@@ -115,6 +138,11 @@ def _f32(p: torch.Tensor) -> torch.Tensor:
 
 def hip_layernorm(ln: nn.LayerNorm, x, eps: Optional[float] = None, relu=False, post_scale=1.0):
     return HF.layernorm(x, _f32(ln.weight), _f32(ln.bias), ln.eps if eps is None else eps, relu, post_scale)
+
+
+def hip_layernorm_fork(ln: nn.LayerNorm, x, eps: Optional[float] = None):
+    """-> (x_residual, LN(x)) for pre-norm residual blocks: the two gradient branches of x meet in one kernel."""
+    return HF.layernorm_fork(x, _f32(ln.weight), _f32(ln.bias), ln.eps if eps is None else eps)
 
 
 def to_len(lens: torch.Tensor, device) -> torch.Tensor:
@@ -248,14 +276,13 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, B, T, length, gelu: str):
         a = self.attn1
-        y = hip_layernorm(self.norm1, x)
-        q, k, v = hip_linear(a.to_q, y), hip_linear(a.to_k, y), hip_linear(a.to_v, y)
+        x, y = hip_layernorm_fork(self.norm1, x)
+        q, k, v = hip_qkv(a.to_q, a.to_k, a.to_v, y)
         o = HF.attn_bias(q, k, v, B, a.heads, T, length, a.scale)
         x = hip_linear(a.to_out[0], o, residual=x)
-        y = hip_layernorm(self.norm3, x)
+        x, y = hip_layernorm_fork(self.norm3, x)
         act = "gelu_tanh" if self.ff.net[0].approximate == "tanh" else gelu
-        h = hip_linear(self.ff.net[0].proj, y, act=act)
-        return hip_linear(self.ff.net[2], h, residual=x)
+        return hip_ffn(self.ff.net[0].proj, self.ff.net[2], y, act, residual=x)
 
 
 class ConditionalDecoder(nn.Module):
@@ -431,7 +458,7 @@ class RelPositionMultiHeadedAttention(nn.Module):
         nn.init.xavier_uniform_(self.pos_bias_v)
 
     def forward(self, y, residual, pos_emb, B, L, length, causal):
-        q, k, v = hip_linear(self.linear_q, y), hip_linear(self.linear_k, y), hip_linear(self.linear_v, y)
+        q, k, v = hip_qkv(self.linear_q, self.linear_k, self.linear_v, y)
         p = hip_linear(self.linear_pos, pos_emb)
         o = HF.attn_relpos(q, k, v, p, _f32(self.pos_bias_u), _f32(self.pos_bias_v), B, self.h, L, length, causal,
                            1.0 / math.sqrt(self.d_k))
@@ -446,7 +473,7 @@ class PositionwiseFeedForward(nn.Module):
         self.w_2 = nn.Linear(hidden_units, idim)
 
     def forward(self, y, residual):
-        return hip_linear(self.w_2, hip_linear(self.w_1, y, act=self.activation), residual=residual)
+        return hip_ffn(self.w_1, self.w_2, y, self.activation, residual=residual)
 
 
 class EncoderLayer(nn.Module):
@@ -467,8 +494,10 @@ class EncoderLayer(nn.Module):
 
     def forward(self, x, pos_emb, B, L, length, causal, eps):
         n_att, n_ff = (self.norm_mha, self.norm_ff) if self.conformer else (self.norm1, self.norm2)
-        x = self.self_attn(hip_layernorm(n_att, x, eps), x, pos_emb, B, L, length, causal)
-        return self.feed_forward(hip_layernorm(n_ff, x, eps), x)
+        x, y = hip_layernorm_fork(n_att, x, eps)
+        x = self.self_attn(y, x, pos_emb, B, L, length, causal)
+        x, y = hip_layernorm_fork(n_ff, x, eps)
+        return self.feed_forward(y, x)
 
 
 class RelPosEncoder(nn.Module):

@@ -120,7 +120,8 @@ int cvft_layernorm_fwd(int dtype, int rows, int C, const void* x, const float* g
                        float eps, int relu, float post_scale, void* y, float* mean, float* rstd, void* stream);
 int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, const float* gamma, const float* beta,
                        const float* mean, const float* rstd, int relu, float post_scale,
-                       const void* dy, void* dx, void* stream);
+                       const void* dy, const void* dres, void* dx, void* stream);
+/* dres (or NULL): a second gradient of x (the residual branch of a pre-norm block), added into dx by the same launch */
 
 /* ---------------------------------------------------------------------------------
  * GroupNorm(G) + Mish (+ length mask, + per-(batch,channel) additive term), channel-last.
