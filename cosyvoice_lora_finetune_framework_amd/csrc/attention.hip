@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
     typedef Mma<T> MM;
     typedef typename MM::Frag Frag;
     constexpr int LDK = A::LDK, NK = A::NK, LDG = 84;
-    constexpr bool TR = sizeof(T) == 2;      // bf16: k-major operands are staged transposed (one 16-byte read per fragment)
+    constexpr bool TR = false;                // (transposed staging copies retired: bf16 k-major operands use the transposing LDS read)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* Ks = reinterpret_cast<T*>(smem);
     T* Vs = Ks + A::TILE;
@@ -49,6 +49,25 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
     const T* pg = REL ? p.p + h * 64 : nullptr;
     const int lb = p.len ? p.len[b] : L;
 
+    int jmax;
+    if (REL) {
+        jmax = min(L, lb);
+        if (p.causal) jmax = min(jmax, q0 + 64);
+    } else {
+        jmax = (lb >= 1) ? min(L, lb) : L;
+    }
+    TileRegs<T> kr, vr, pr0, pr1;
+    auto prefetch = [&](int j0) __attribute__((always_inline)) {
+        tile_load(kr, kg, p.ld, j0, L, tid);
+        tile_load(vr, vg, p.ld, j0, L, tid);
+        if (REL) {
+            const int mb = (L - 1) - (q0 + 63) + j0;
+            tile_load(pr0, pg, p.ldp, mb, 2 * L - 1, tid);
+            tile_load(pr1, pg, p.ldp, mb + 64, 2 * L - 1, tid);
+        }
+    };
+    if (jmax > 0) prefetch(0);
+
     stage64(qg, p.ld, q0, L, Ks, tid);
     __syncthreads();
     Frag qf[NK], qv[NK];
@@ -63,13 +82,6 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
     }
     __syncthreads();
 
-    int jmax;
-    if (REL) {
-        jmax = min(L, lb);
-        if (p.causal) jmax = min(jmax, q0 + 64);
-    } else {
-        jmax = (lb >= 1) ? min(L, lb) : L;
-    }
     float m_run[4], l_run[4];
     f32x4 oacc[4];
 #pragma unroll
@@ -78,15 +90,15 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
     float* Gw = Gs + w * 16 * LDG;
 
     for (int j0 = 0; j0 < jmax; j0 += 64) {
-        stage64(kg, p.ld, j0, L, Ks, tid);
-        if (TR) stage64_tr<T>(vg, p.ld, j0, L, nullptr, Vs, LDK, 0, tid);      // bf16: V only ever read k(=kv)-major => keep V^T
-        else stage64(vg, p.ld, j0, L, Vs, tid);
+        tile_store(kr, Ks, tid);
+        if (TR) tile_store_tr<T>(vr, nullptr, Vs, LDK, 0, tid);      // bf16: V only ever read k(=kv)-major => keep V^T
+        else tile_store(vr, Vs, tid);
         if (REL) {
-            const int mb = (L - 1) - (q0 + 63) + j0;
-            stage64(pg, p.ldp, mb, 2 * L - 1, Pb, tid);
-            stage64(pg, p.ldp, mb + 64, 2 * L - 1, Pb + 64 * LDK, tid);
+            tile_store(pr0, Pb, tid);
+            tile_store(pr1, Pb + 64 * LDK, tid);
         }
         __syncthreads();
+        if (j0 + 64 < jmax) prefetch(j0 + 64);                       // in flight under this tile's MFMAs
         f32x4 s[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -129,11 +141,11 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
             tm = row16_max(tm);
             const float mn = fmaxf(m_run[r], tm);
             const float ms = (mn == NEG_INF) ? 0.f : mn;
-            const float alpha = expf(m_run[r] - ms);
+            const float alpha = __expf(m_run[r] - ms);
             float rs = 0.f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                float pv = expf(s[nt][r] - ms);
+                float pv = __expf(s[nt][r] - ms);
                 s[nt][r] = pv;
                 rs += pv;
             }
@@ -178,7 +190,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
     typedef Mma<T> MM;
     typedef typename MM::Frag Frag;
     constexpr int LDK = A::LDK, NK = A::NK, LDG = 100;
-    constexpr bool TR = sizeof(T) == 2;
+    constexpr bool TR = false;
     constexpr int KB = (sizeof(T) == 2) ? 96 : 80;     // skewed dS width, padded to the MFMA k-step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* Ks = reinterpret_cast<T*>(smem);
@@ -198,6 +210,26 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
     const T* dog = p.d_o + rowbase * p.ldo + h * 64;
     const T* pg = REL ? p.p + h * 64 : nullptr;
     const int lb = p.len ? p.len[b] : L;
+
+    int jmax;
+    if (REL) {
+        jmax = min(L, lb);
+        if (p.causal) jmax = min(jmax, q0 + 64);
+    } else {
+        jmax = (lb >= 1) ? min(L, lb) : L;
+    }
+    TileRegs<T> kr, vr, pr0, pr1, pr2;
+    auto prefetch = [&](int j0) __attribute__((always_inline)) {
+        tile_load(kr, kg, p.ld, j0, L, tid);
+        tile_load(vr, vg, p.ld, j0, L, tid);
+        if (REL) {
+            const int mb = (L - 1) - (q0 + 63) + j0;
+            tile_load(pr0, pg, p.ldp, mb, 2 * L - 1, tid);
+            tile_load(pr1, pg, p.ldp, mb + 64, 2 * L - 1, tid);
+            tile_load(pr2, pg, p.ldp, mb + 128, 2 * L - 1, tid);
+        }
+    };
+    if (jmax > 0) prefetch(0);
 
     stage64(qg, p.ld, q0, L, Ks, tid);
     stage64(dog, p.ldo, q0, L, Vs, tid);
@@ -222,13 +254,6 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
     }
     __syncthreads();
 
-    int jmax;
-    if (REL) {
-        jmax = min(L, lb);
-        if (p.causal) jmax = min(jmax, q0 + 64);
-    } else {
-        jmax = (lb >= 1) ? min(L, lb) : L;
-    }
     f32x4 dqacc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) dqacc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -236,17 +261,17 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
     float* Gw = Gs + w * 16 * LDG;
 
     for (int j0 = 0; j0 < jmax; j0 += 64) {
-        if (TR) stage64_tr<T>(kg, p.ld, j0, L, Ks, Kt, LDK, 0, tid);
-        else stage64(kg, p.ld, j0, L, Ks, tid);
-        stage64(vg, p.ld, j0, L, Vs, tid);
+        if (TR) tile_store_tr<T>(kr, Ks, Kt, LDK, 0, tid);
+        else tile_store(kr, Ks, tid);
+        tile_store(vr, Vs, tid);
         if (REL) {
-            const int mb = (L - 1) - (q0 + 63) + j0;
             // (a transposed copy of the band was measured slower than strided reads here: 3 scatter passes per tile)
-            stage64(pg, p.ldp, mb, 2 * L - 1, Pb, tid);
-            stage64(pg, p.ldp, mb + 64, 2 * L - 1, Pb + 64 * LDK, tid);
-            stage64(pg, p.ldp, mb + 128, 2 * L - 1, Pb + 128 * LDK, tid);
+            tile_store(pr0, Pb, tid);
+            tile_store(pr1, Pb + 64 * LDK, tid);
+            tile_store(pr2, Pb + 128 * LDK, tid);
         }
         __syncthreads();
+        if (j0 + 64 < jmax) prefetch(j0 + 64);
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) { s[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -288,7 +313,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
                     valid = (j < L);
                     x += (j < lb ? 0.f : -1.0e10f);
                 }
-                const float pv = valid ? expf(x - lse_r[r]) : 0.f;
+                const float pv = valid ? __expf(x - lse_r[r]) : 0.f;
                 const float ds = pv * (dp[nt][r] - del_r[r]) * p.scale;
                 Dw[row * LDK + nt * 16 + (lane & 15)] = from_f32<T>(ds);
                 if (REL) Gw[row * LDG + 15 - row + nt * 16 + (lane & 15)] = ds;
@@ -331,7 +356,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) {
     typedef Mma<T> MM;
     typedef typename MM::Frag Frag;
     constexpr int LDK = A::LDK, NK = A::NK, LDG = 36;
-    constexpr bool TR = sizeof(T) == 2;
+    constexpr bool TR = false;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* Ks = reinterpret_cast<T*>(smem);
     T* Vs = Ks + A::TILE;
@@ -378,25 +403,41 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) {
         T* Dw = Dt + w * 16 * LDK;
         float* Gw = Gs + w * 16 * LDG;
         const int ibeg = (REL && p.causal) ? j0 : 0;
-        for (int i0 = ibeg; i0 < L; i0 += 64) {
-            if (TR) {
-                stage64_tr<T>(qg, p.ld, i0, L, Qs, Qt, LDK, 0, tid);
-                stage64_tr<T>(dog, p.ldo, i0, L, Os, Ot, LDK, 0, tid);
-            } else {
-                stage64(qg, p.ld, i0, L, Qs, tid);
-                stage64(dog, p.ldo, i0, L, Os, tid);
-            }
+        TileRegs<T> qr, dor, pr0, pr1;
+        float lse_n = 0.f, del_n = 0.f;
+        auto prefetch = [&](int i0) __attribute__((always_inline)) {
+            tile_load(qr, qg, p.ld, i0, L, tid);
+            tile_load(dor, dog, p.ldo, i0, L, tid);
             if (tid < 64) {
-                int i = i0 + tid;
-                lse_s[tid] = (i < L) ? p.lse[((size_t)b * p.H + h) * L + i] : __builtin_inff();
-                del_s[tid] = (i < L) ? p.delta[((size_t)b * p.H + h) * L + i] : 0.f;
+                const int i = i0 + tid;
+                lse_n = (i < L) ? p.lse[((size_t)b * p.H + h) * L + i] : __builtin_inff();
+                del_n = (i < L) ? p.delta[((size_t)b * p.H + h) * L + i] : 0.f;
             }
             if (REL) {
                 const int mb = (L - 1) - (i0 + 63) + j0;
-                stage64(pg, p.ldp, mb, 2 * L - 1, Pb, tid);
-                stage64(pg, p.ldp, mb + 64, 2 * L - 1, Pb + 64 * LDK, tid);
+                tile_load(pr0, pg, p.ldp, mb, 2 * L - 1, tid);
+                tile_load(pr1, pg, p.ldp, mb + 64, 2 * L - 1, tid);
+            }
+        };
+        if (ibeg < L) prefetch(ibeg);
+        for (int i0 = ibeg; i0 < L; i0 += 64) {
+            if (TR) {
+                tile_store_tr<T>(qr, Qs, Qt, LDK, 0, tid);
+                tile_store_tr<T>(dor, Os, Ot, LDK, 0, tid);
+            } else {
+                tile_store(qr, Qs, tid);
+                tile_store(dor, Os, tid);
+            }
+            if (tid < 64) {
+                lse_s[tid] = lse_n;
+                del_s[tid] = del_n;
+            }
+            if (REL) {
+                tile_store(pr0, Pb, tid);
+                tile_store(pr1, Pb + 64 * LDK, tid);
             }
             __syncthreads();
+            if (i0 + 64 < L) prefetch(i0 + 64);
 #pragma unroll 1
             for (int mt = 0; mt < 4; ++mt) {
                 Frag au[NK], av[NK], ad[NK];
@@ -446,7 +487,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) {
                         valid = (j < L) && (i < L);
                         x += (j < lb ? 0.f : -1.0e10f);
                     }
-                    const float pv = valid ? expf(x - lse_s[il]) : 0.f;
+                    const float pv = valid ? __expf(x - lse_s[il]) : 0.f;
                     const float ds = pv * (dp[r] - del_s[il]) * p.scale;
                     Pw[(lane & 15) * LDK + il] = from_f32<T>(pv);
                     Dw[(lane & 15) * LDK + il] = from_f32<T>(ds);
@@ -503,19 +544,22 @@ template <typename T> static size_t smem_dq(bool rel) {
     typedef AttnCfg<T> A;
     size_t s = (size_t)(2 * A::TILE + 4 * 16 * A::LDK) * sizeof(T);
     if (rel) s += (size_t)192 * A::LDK * sizeof(T) + 4 * 16 * 100 * sizeof(float);
-    if (sizeof(T) == 2) s += (size_t)A::TILE * sizeof(T);                                               // K^T
     return s;
 }
 template <typename T> static size_t smem_dkv(bool rel) {
     typedef AttnCfg<T> A;
     size_t s = (size_t)(4 * A::TILE + 2 * 4 * 16 * A::LDK) * sizeof(T) + 128 * sizeof(float);
     if (rel) s += (size_t)128 * A::LDK * sizeof(T) + 4 * 16 * 36 * sizeof(float);
-    if (sizeof(T) == 2) s += (size_t)2 * A::TILE * sizeof(T);                                           // Q^T, dO^T
     return s;
 }
 
 template <typename K>
 static int set_smem(K kernel, size_t bytes, const char* name) {
+    static K seen[16];                        // kernels of this signature whose attribute is already set
+    static int nseen = 0;
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i] == kernel) return 0;
+    if (nseen < 16) seen[nseen++] = kernel;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
         cvft_set_error("%s: hipFuncSetAttribute(%zu bytes) failed: %s", name, bytes, hipGetErrorString(e));

@@ -43,18 +43,62 @@ __device__ __forceinline__ void stage64_tr(const T* __restrict__ g, int ld, int 
     }
 }
 
+// ---- split staging (issue-early / write-late, cdna_hip_programming.md T14): the next tile's global loads are issued
+// right after the barrier that publishes the current tile and stay in flight under its MFMAs; they are written to
+// LDS at the top of the next iteration.  One 64x64 tile = 64*CPR 16-byte chunks over 256 threads.
+template <typename T> struct TileRegs { uint4 v[(64 * AttnCfg<T>::CPR) / 256]; };
+
+template <typename T>
+__device__ __forceinline__ void tile_load(TileRegs<T>& t, const T* __restrict__ g, int ld, int r0, int rlim, int tid) {
+    typedef AttnCfg<T> A;
+#pragma unroll
+    for (int i = 0; i < (64 * A::CPR) / 256; ++i) {
+        const int c = tid + i * 256, r = c / A::CPR, cc = c % A::CPR;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < rlim && r0 + r >= 0) v = *reinterpret_cast<const uint4*>(g + (size_t)(r0 + r) * ld + cc * A::VEC);
+        t.v[i] = v;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void tile_store(const TileRegs<T>& t, T* S, int tid) {
+    typedef AttnCfg<T> A;
+#pragma unroll
+    for (int i = 0; i < (64 * A::CPR) / 256; ++i) {
+        const int c = tid + i * 256, r = c / A::CPR, cc = c % A::CPR;
+        *reinterpret_cast<uint4*>(&S[r * A::LDK + cc * A::VEC]) = t.v[i];
+    }
+}
+// transposed image St[c][coff + r] (+ optional straight copy S[r][c])
+template <typename T>
+__device__ __forceinline__ void tile_store_tr(const TileRegs<T>& t, T* S, T* St, int ldt, int coff, int tid) {
+    typedef AttnCfg<T> A;
+#pragma unroll
+    for (int i = 0; i < (64 * A::CPR) / 256; ++i) {
+        const int c = tid + i * 256, r = c / A::CPR, cc = c % A::CPR;
+        if (S) *reinterpret_cast<uint4*>(&S[r * A::LDK + cc * A::VEC]) = t.v[i];
+        const T* e = reinterpret_cast<const T*>(&t.v[i]);
+#pragma unroll
+        for (int j = 0; j < A::VEC; ++j) St[(cc * A::VEC + j) * ldt + coff + r] = e[j];
+    }
+}
+
 // ---- operand loaders -------------------------------------------------------------
 template <typename T, typename S> struct FragLd;
 template <> struct FragLd<bf16_t, bf16_t> {
     static __device__ __forceinline__ bf16x8 kc(const bf16_t* base, int ld, int rc0, int k0, int lane) {
         return *reinterpret_cast<const bf16x8*>(base + (rc0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4));
     }
+    // operand stored reduction-index-major ([k][rc], the natural row-major image of V / K / Q / dO): gfx950's
+    // transposing LDS read (ds_read_b64_tr_b16, cdna_hip_programming.md T10) returns, per 16-lane group, a 4-row x
+    // 16-column block column-major -- lane 4q+p supplies row q / columns 4p..4p+3, lane i receives column i.  Two reads
+    // (rows 8g..8g+3 and 8g+4..8g+7) give the 8 consecutive k the MFMA operand wants; no transposed staging copy.
+    // Needs EXEC all ones (every call site is wave-uniform) and 8-byte aligned addresses (ld % 4 == 0, rc0 % 4 == 0).
     static __device__ __forceinline__ bf16x8 km(const bf16_t* base, int ld, int rc0, int k0, int lane) {
-        bf16x8 f;
-        const bf16_t* p = base + (k0 + 8 * (lane >> 4)) * ld + rc0 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = p[j * ld];
-        return f;
+        typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+        const bf16_t* p = base + (k0 + 8 * (lane >> 4) + ((lane >> 2) & 3)) * ld + rc0 + 4 * (lane & 3);
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)p);
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(p + 4 * ld));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 };
 template <> struct FragLd<bf16_t, float> {
