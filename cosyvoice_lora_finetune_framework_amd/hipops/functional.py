@@ -212,7 +212,11 @@ class LoraGradSink:
     _cache = {}
     _side = None
 
-    def __init__(self, side_stream: bool = True):
+    def __init__(self, side_stream: Optional[bool] = None):
+        if side_stream is None:
+            # measured: in a captured hipGraph every main<->side dependency edge crosses hardware queues (~9 us idle each,
+            # ~4 ms / step); with the matrix-core slab kernels at ~3 us the serial order is faster
+            side_stream = _os.environ.get('CVFT_SINK_SIDE', '0') != '0'
         self.tasks = []
         self.keep = []                    # operands of side-stream launches stay alive until the join
         self.side = None
