@@ -397,26 +397,6 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
                 if (rc != 1) return rc;
             }
         }
-        if constexpr (sizeof(T) == 2) {          // experiment hook: CVFT_GEMM_CFG selects a tile configuration
-            static const int cfg = getenv("CVFT_GEMM_CFG") ? atoi(getenv("CVFT_GEMM_CFG")) : 0;
-            if (cfg && p.N > 32) {
-                switch (cfg) {
-                    case 1: return gemm_launch_cfg<T, 128, 128, 2, 2, 2, true>(p, st);
-                    case 2: return gemm_launch_cfg<T, 128, 128, 4, 2, 3, true>(p, st);
-                    case 3: return gemm_launch_cfg<T, 256, 128, 4, 2, 2, true>(p, st);
-                    case 4: return gemm_launch_cfg<T, 128, 256, 2, 4, 2, true>(p, st);
-                    case 5: return gemm_launch_cfg<T, 64, 64, 2, 2, 4, true>(p, st);
-                    case 6: return gemm_launch_cfg<T, 128, 64, 2, 2, 4, true>(p, st);
-                    case 7: return gemm_launch_cfg<T, 32, 64, 2, 2, 4, true>(p, st);
-                    case 8: return gemm_launch_cfg<T, 64, 32, 2, 2, 4, true>(p, st);
-                    case 9: return gemm_launch_cfg<T, 32, 32, 2, 2, 4, true>(p, st);
-                    case 10: return gemm_launch_cfg<T, 32, 64, 1, 2, 4, true>(p, st);
-                    case 11: return gemm_launch_cfg<T, 128, 128, 2, 4, 2, true>(p, st);
-                    case 12: return gemm_launch_cfg<T, 128, 64, 4, 2, 4, true>(p, st);
-                    default: break;
-                }
-            }
-        }
         if (p.N <= 32) return gemm_launch_cfg<T, 32, 32, 2, 1, 4, true>(p, st);
         // measured on MI355X (tools/bench_kernels.py, CVFT_GEMM_CFG sweep): 64x64 tiles with 4 k-tiles in flight win
         // on every step shape up to K = 1024; long-K GEMMs (w_2 dgrad / forward, K = 4096) prefer 256x128 x 8 waves.

@@ -12,6 +12,7 @@
 // main loop.  Everything else (row geometry, taps, masks, fp32, odd shapes) stays on gemm.hip's register-staged kernel.
 //
 // Replaces (reference): lora.py:64-76 and the nn.Linear calls of the estimator / encoders, and their dgrad.
+#include <stdlib.h>
 #include "gemm_common.cuh"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -20,14 +21,21 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // FU: the side-path input  U = lora_scale * A . La^T  (La [R <= 16][K]) is produced inside the launch: the La k-tile
 // rides along as 16 more DMA rows, the wn == 0 waves run one extra MFMA per A fragment, the bf16 result goes through a
 // small LDS panel into every wave's extension fragments, and the n-tile-0 blocks publish it to Uout for backward.
-template <int BM, int BN, int WM, int WN, bool FU>
+// NS = LDS stages: tiles kt+1 .. kt+NS-1 are in flight while tile kt feeds the MFMAs (counted s_waitcnt vmcnt, raw
+// s_barrier -- __syncthreads() would drain the DMA queue).  These GEMMs are small (1-4 blocks per CU, 4-16 k-tiles):
+// with one tile of lookahead every k-tile cost a full memory round trip (~0.9 us measured in the training step).
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, bool FU, int NS>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     typedef bf16_t T;
     constexpr int NW = WM * WN, NT = NW * 64, BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, L_BYTES = FU ? 16 * 128 : 0, BUF = A_BYTES + W_BYTES + L_BYTES;
-    constexpr int UP_OFF = 2 * BUF;                               // FU: [BM][16] bf16 panel behind the ring
+    constexpr int UP_OFF = NS * BUF;                              // FU: [BM][16] bf16 panel behind the ring
     constexpr int A_INS = BM / 8 / NW, W_INS = BN / 8 / NW;      // DMA wave-instructions per wave per k-tile
+    constexpr int INS = A_INS + W_INS;                            // DMA instructions per wave per tile (waves 0/1: +1 when FU)
+    static_assert(NS >= 2 && (NS - 2) * (INS + 1) < 64, "vmcnt is a 6-bit counter");
     constexpr int CLD = BN + 4;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA pieces per wave");
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
@@ -91,32 +99,36 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
 
     // rank-R extension operands, fragment-shaped, straight to registers (in flight during the whole main loop)
     constexpr int RS = 2;                         // up to R = 64
-    bf16x8 ua[RS][MI], ub[RS][NI];
+    uint4 ua[RS][MI], ub[RS][NI];                 // raw 16-byte chunks; masked and reinterpreted only after the main loop
     const int kg = lane >> 4, l15 = lane & 15;
     const int nrs = (p.R + 31) >> 5;
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) ua[s][i] = Mma<T>::zero();
+        for (int i = 0; i < MI; ++i) ua[s][i] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) ub[s][j] = Mma<T>::zero();
+        for (int j = 0; j < NI; ++j) ub[s][j] = make_uint4(0, 0, 0, 0);
     }
     if (p.R > 0) {
+        // unconditional loads from clamped addresses; the lane mask (k >= R -> 0) is applied where the fragments are
+        // consumed, after the main loop: a guarded load makes hipcc branch around it and wait vmcnt(0) at the join, a
+        // mask applied here makes it wait right here -- either way one exposed memory round trip before the first DMA
 #pragma unroll
         for (int s = 0; s < RS; ++s) {
             const int kk = s * 32 + kg * 8;
-            if (kk < p.R) {
+            const int kkc = kk < p.R ? kk : 0;
+            if (s * 32 < p.R) {                                   // wave-uniform
                 if (!FU) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
-                        const int m = m0 + wm * TM + i * 16 + l15;
-                        if (m < p.M) ua[s][i] = *reinterpret_cast<const bf16x8*>(p.U + (size_t)m * p.ldu + kk);
+                        const int m = min(m0 + wm * TM + i * 16 + l15, p.M - 1);
+                        ua[s][i] = *reinterpret_cast<const uint4*>(p.U + (size_t)m * p.ldu + kkc);
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    const int n = n0 + wn * TN + j * 16 + l15;
-                    if (n < p.N) ub[s][j] = *reinterpret_cast<const bf16x8*>(p.Bl + (size_t)n * p.ldbl + kk);
+                    const int n = min(n0 + wn * TN + j * 16 + l15, p.N - 1);
+                    ub[s][j] = *reinterpret_cast<const uint4*>(p.Bl + (size_t)n * p.ldbl + kkc);
                 }
             }
         }
@@ -159,12 +171,24 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     };
 
     const int nk = p.K / BK;
-    issue(0);
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) issue(t);
+    int cb = 0, ib = NS - 1;                                    // buffer of tile kt / of tile kt + NS - 1
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile kt has landed (this wave's pieces) ...
-        __syncthreads();                                        // ... everyone's; and buffer (kt+1)&1 is free again
-        if (kt + 1 < nk) issue((kt + 1) & 1);
-        compute(kt & 1);
+        // this wave's pieces of tile kt have landed once at most the NS-2 younger tiles are still outstanding
+        // (loads retire in order; the LoRA fragment loads are older than every tile)
+        if (kt + NS - 2 < nk) {
+            if (FU && wid < 2) wait_vmcnt<(NS - 2) * (INS + 1)>(); else wait_vmcnt<(NS - 2) * INS>();
+        } else {
+            wait_vmcnt<0>();                                    // pipeline tail
+        }
+        __builtin_amdgcn_s_barrier();                           // everyone's pieces; and buffer ib (tile kt-1) is free
+        asm volatile("" ::: "memory");
+        if (kt + NS - 1 < nk) issue(ib);
+        compute(cb);
+        cb = (cb + 1 == NS) ? 0 : cb + 1;
+        ib = (ib + 1 == NS) ? 0 : ib + 1;
     }
     if (FU) {
         bf16_t* Up = reinterpret_cast<bf16_t*>(smem + UP_OFF);
@@ -182,16 +206,30 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         __syncthreads();
         if (kg < 2) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) ua[0][i] = *reinterpret_cast<const bf16x8*>(Up + (wm * TM + i * 16 + l15) * 16 + kg * 8);
+            for (int i = 0; i < MI; ++i) ua[0][i] = *reinterpret_cast<const uint4*>(Up + (wm * TM + i * 16 + l15) * 16 + kg * 8);
         }
     }
 #pragma unroll
     for (int s = 0; s < RS; ++s)
         if (s < nrs) {
+            const unsigned keep = (s * 32 + kg * 8) < p.R ? 0xffffffffu : 0u;
+            bf16x8 fa[MI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                uint4 v = ua[s][i];
+                v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+                fa[i] = *reinterpret_cast<bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                uint4 v = ub[s][j];
+                v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+                fb[j] = *reinterpret_cast<bf16x8*>(&v);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) Mma<T>::mma(acc[i][j], ua[s][i], ub[s][j]);
+                for (int j = 0; j < NI; ++j) Mma<T>::mma(acc[i][j], fa[i], fb[j]);
         }
 
     __syncthreads();                                            // operand ring is dead: reuse it for the fp32 tile
@@ -206,12 +244,12 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     gemm_epilogue_store<T, BM, BN, NT>(p, Cs, m0, n0, tid);
 }
 
-template <int BM, int BN, int WM, int WN, bool FU = false>
+template <int BM, int BN, int WM, int WN, bool FU = false, int NS = 2>
 static int glds_launch_cfg(const GP<bf16_t>& p, hipStream_t st) {
-    size_t ring = (size_t)2 * (BM + BN + (FU ? 16 : 0)) * 128 + (FU ? BM * 32 : 0);
+    size_t ring = (size_t)NS * (BM + BN + (FU ? 16 : 0)) * 128 + (FU ? BM * 32 : 0);
     size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
     size_t sm = ring > cs ? ring : cs;
-    auto kern = gemm_glds_kernel<BM, BN, WM, WN, FU>;
+    auto kern = gemm_glds_kernel<BM, BN, WM, WN, FU, NS>;
     static bool attr_set = false;             // per instantiation; a host call per launch is visible in eager mode
     if (sm > 48 * 1024 && !attr_set) {
         attr_set = true;
@@ -223,34 +261,46 @@ static int glds_launch_cfg(const GP<bf16_t>& p, hipStream_t st) {
     }
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, p);
-    cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d>%s", BM, BN, WM, WN, FU ? ",fusedU" : "");
+    cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d>%s", BM, BN, WM, WN, NS, FU ? ",fusedU" : "");
     CVFT_LAUNCH_CHECK("cvft_gemm");
     return 0;
 }
 
-// cfg: 0 = pick by shape, > 0 = forced tile (experiment hook, CVFT_GLDS_CFG).  Returns 1 when not eligible.
-int gemm_glds_launch(const GP<bf16_t>& p, hipStream_t st, int cfg) {
+// Returns 1 when the launch is not eligible (the caller falls back to gemm.hip's register-staged kernel).
+int gemm_glds_launch(const GP<bf16_t>& p, hipStream_t st, int /*cfg*/) {
     const bool ident = p.ntaps == 1 && p.tap_off[0] == 0 && p.in_stride == 1 && p.Tin == p.Tm && !p.in_len;
     if (!ident || p.K % 64 != 0 || !p.vecA || !p.vecW || p.N <= 32) return 1;
     const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    // Stage count: a deep DMA pipeline only pays while the CU still holds every block that wants to run there
+    // (16 / 24 KB per stage), measured on cold operands (tools/bench_cold.py): <= 2 blocks per CU and >= 4 k-tiles ->
+    // 4 stages (64x64) / 3 (128x64); a third block per CU -> 3; beyond that 2.  CVFT_GLDS_NS overrides (experiments).
+    static const int ns_env = getenv("CVFT_GLDS_NS") ? atoi(getenv("CVFT_GLDS_NS")) : 0;
+    const bool big = t64 >= 1024;
+    const long blocks = big ? (long)((p.M + 127) / 128) * ((p.N + 63) / 64) : t64;
+    const int nk = p.K / 64;
+    int ns = 2;
+    if (nk >= 4) {
+        if (big) ns = blocks <= 512 ? 3 : 2;
+        else ns = blocks <= 512 ? 4 : (blocks <= 768 ? 3 : 2);
+    }
+    if (ns_env) ns = ns_env;
     if (p.fuse) {     // gemm_launch has already checked the La / Bl alignment; R <= 16 by the ABI contract
         if (p.R < 1 || p.R > 16 || p.Tm != p.M || p.out_stride != 1 || p.out_off != 0) return 1;
-        if (cfg == 8 || (cfg == 0 && t64 >= 1024)) return glds_launch_cfg<128, 64, 4, 2, true>(p, st);
-        return glds_launch_cfg<64, 64, 2, 2, true>(p, st);
+        if (big) {
+            if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, true, 3>(p, st);
+            return glds_launch_cfg<128, 64, 4, 2, true, 2>(p, st);
+        }
+        if (ns >= 4) return glds_launch_cfg<64, 64, 2, 2, true, 4>(p, st);
+        if (ns == 3) return glds_launch_cfg<64, 64, 2, 2, true, 3>(p, st);
+        return glds_launch_cfg<64, 64, 2, 2, true, 2>(p, st);
     }
     if (p.R > 0 && (p.R % 8 != 0 || p.R > 64 || !p.vecU || !p.vecB)) return 1;
-    switch (cfg) {
-        case 1: return glds_launch_cfg<128, 128, 2, 2>(p, st);
-        case 2: return glds_launch_cfg<128, 128, 2, 4>(p, st);
-        case 3: return glds_launch_cfg<128, 64, 2, 2>(p, st);
-        case 4: return glds_launch_cfg<64, 64, 2, 2>(p, st);
-        case 5: return glds_launch_cfg<256, 128, 4, 2>(p, st);
-        case 6: return glds_launch_cfg<128, 256, 2, 4>(p, st);
-        case 7: return glds_launch_cfg<64, 128, 2, 2>(p, st);
-        case 8: return glds_launch_cfg<128, 64, 4, 2>(p, st);
-        default: break;
-    }
     // measured on MI355X (tools/sweep_gemm.py): 128x64 x 8 waves once there are >= 4 64x64 tiles per CU, else 64x64
-    if (t64 >= 1024) return glds_launch_cfg<128, 64, 4, 2>(p, st);
-    return glds_launch_cfg<64, 64, 2, 2>(p, st);
+    if (big) {
+        if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, false, 3>(p, st);
+        return glds_launch_cfg<128, 64, 4, 2, false, 2>(p, st);
+    }
+    if (ns >= 4) return glds_launch_cfg<64, 64, 2, 2, false, 4>(p, st);
+    if (ns == 3) return glds_launch_cfg<64, 64, 2, 2, false, 3>(p, st);
+    return glds_launch_cfg<64, 64, 2, 2, false, 2>(p, st);
 }
