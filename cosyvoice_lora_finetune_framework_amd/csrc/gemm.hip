@@ -722,8 +722,7 @@ extern "C" int cvft_lora_rank_partial(int dtype, int M, int Cn, int r, const voi
                                       float* part, int transpose_out, int rows_per_block, void* stream) {
     CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_lora_rank_partial: bad dtype");
     CVFT_CHECK_ARG(M > 0 && Cn > 0 && r > 0 && r % 16 == 0 && ldw >= Cn && ldr >= r && Wd && Rk && part, "cvft_lora_rank_partial: bad args");
-    CVFT_CHECK_ARG(rows_per_block == 64 || rows_per_block == 128 || (rows_per_block >= 256 && rows_per_block % 256 == 0),
-                   "cvft_lora_rank_partial: rows_per_block must be 64, 128 or a multiple of 256");
+    CVFT_CHECK_ARG(rows_per_block > 0 && rows_per_block % 32 == 0, "cvft_lora_rank_partial: rows_per_block must be a multiple of 32");
     hipStream_t st = (hipStream_t)stream;
     int ldo = transpose_out ? r : Cn;
     if (dtype == CVFT_BF16) {          // matrix-core kernel (lora_grad.hip) for every eligible bf16 launch
@@ -733,6 +732,8 @@ extern "C" int cvft_lora_rank_partial(int dtype, int M, int Cn, int r, const voi
             return 0;
         }
     }
+    CVFT_CHECK_ARG(rows_per_block == 64 || rows_per_block == 128 || (rows_per_block >= 256 && rows_per_block % 256 == 0),
+                   "cvft_lora_rank_partial: the VALU path needs rows_per_block 64, 128 or a multiple of 256");
     int rc = dtype == CVFT_F32 ? rank_accum_launch<float>(M, Cn, r, Wd, ldw, Rk, ldr, part, ldo, transpose_out, st, rows_per_block)
                                : rank_accum_launch<bf16_t>(M, Cn, r, Wd, ldw, Rk, ldr, part, ldo, transpose_out, st, rows_per_block);
     CVFT_CHECK_ARG(rc == 0, "cvft_lora_rank_partial: operands must be 16-byte aligned with C %% VEC == 0");
@@ -740,16 +741,19 @@ extern "C" int cvft_lora_rank_partial(int dtype, int M, int Cn, int r, const voi
     return 0;
 }
 
-// tasks[t] = {slab base, grad base, numel, nsplit} (int64 x 4):  grad[i] += sum_s slab[s*numel + i], fixed order.
+// tasks[t] = {slab base, grad base, rows, cols, slab_pitch, slab_stride, nsplit, 0} (int64 x 8):
+//   grad[i*cols + j] += sum_s slab[s*slab_stride + i*slab_pitch + j], fixed order.
 __global__ void __launch_bounds__(256) lora_grad_reduce_kernel(const long long* __restrict__ tasks) {
-    const long long* t = tasks + (size_t)blockIdx.y * 4;
+    const long long* t = tasks + (size_t)blockIdx.y * 8;
     const float* slab = reinterpret_cast<const float*>(t[0]);
     float* grad = reinterpret_cast<float*>(t[1]);
-    const long long numel = t[2];
-    const int nsplit = (int)t[3];
+    const long long rows = t[2], cols = t[3], pitch = t[4], stride = t[5];
+    const int nsplit = (int)t[6];
+    const long long numel = rows * cols;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long long)gridDim.x * 256) {
+        const long long src = (pitch == cols) ? i : (i / cols) * pitch + (i % cols);
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * numel + i];
+        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * stride + src];
         grad[i] += s;
     }
 }
@@ -767,32 +771,35 @@ extern "C" int cvft_lora_grad_reduce(int ntasks, const void* tasks, int max_bloc
 // of `flat_t` -- one launch per optimiser step for all adapters (32x32 LDS tiles).
 //   tiles[t] = {param offset, rows, cols, tile_row * 65536 + tile_col}
 // ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) lora_shadow_kernel(const int4* __restrict__ tiles, const float* __restrict__ flat_p,
-                                                           bf16_t* __restrict__ flat_c, bf16_t* __restrict__ flat_t) {
+__global__ void __launch_bounds__(256) lora_shadow_kernel(const long long* __restrict__ tiles, const float* __restrict__ flat_p) {
     __shared__ float tl[32][33];
-    const int4 d = tiles[blockIdx.x];
-    const int off = d.x, rows = d.y, cols = d.z, tr = (d.w >> 16) * 32, tc = (d.w & 0xffff) * 32;
+    const long long* d = tiles + (size_t)blockIdx.x * 6;
+    const float* src = flat_p + d[0];
+    bf16_t* dc = reinterpret_cast<bf16_t*>(d[1]);
+    bf16_t* dtp = reinterpret_cast<bf16_t*>(d[2]);
+    const int rows = (int)(d[3] & 0xffffffffLL), cols = (int)(d[3] >> 32);
+    const int tr = (int)(d[4] & 0xffffffffLL) * 32, tc = (int)(d[4] >> 32) * 32;
+    const int pc = (int)(d[5] & 0xffffffffLL), pt = (int)(d[5] >> 32);
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;     // 32 x 8
     for (int i = ly; i < 32; i += 8) {
         int rr = tr + i, cc = tc + lx;
         float v = 0.f;
         if (rr < rows && cc < cols) {
-            v = flat_p[(size_t)off + (size_t)rr * cols + cc];
-            flat_c[(size_t)off + (size_t)rr * cols + cc] = (bf16_t)v;
+            v = src[(size_t)rr * cols + cc];
+            dc[(size_t)rr * pc + cc] = (bf16_t)v;
         }
         tl[i][lx] = v;
     }
     __syncthreads();
     for (int i = ly; i < 32; i += 8) {
         int cc = tc + i, rr = tr + lx;
-        if (rr < rows && cc < cols) flat_t[(size_t)off + (size_t)cc * rows + rr] = (bf16_t)tl[lx][i];
+        if (rr < rows && cc < cols) dtp[(size_t)cc * pt + rr] = (bf16_t)tl[lx][i];
     }
 }
-extern "C" int cvft_lora_shadow(int ntiles, const void* tiles, const float* flat_p, void* flat_c, void* flat_t, void* stream) {
-    CVFT_CHECK_ARG(ntiles >= 0 && tiles && flat_p && flat_c && flat_t, "cvft_lora_shadow: bad args");
+extern "C" int cvft_lora_shadow(int ntiles, const void* tiles, const float* flat_p, void* stream) {
+    CVFT_CHECK_ARG(ntiles >= 0 && tiles && flat_p, "cvft_lora_shadow: bad args");
     if (ntiles == 0) return 0;
-    hipLaunchKernelGGL(lora_shadow_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, (const int4*)tiles, flat_p,
-                       (bf16_t*)flat_c, (bf16_t*)flat_t);
+    hipLaunchKernelGGL(lora_shadow_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, (const long long*)tiles, flat_p);
     CVFT_LAUNCH_CHECK("cvft_lora_shadow");
     return 0;
 }

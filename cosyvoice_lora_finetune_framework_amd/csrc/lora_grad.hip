@@ -36,8 +36,7 @@ __global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, int Cn, cons
     constexpr int RK_BYTES = 32 * R * 2;
     constexpr int BUF = WD_BYTES + RK_BYTES;
     constexpr int RCH = R / 8;                       // 16-byte chunks per Rk row
-    constexpr int RK_ROWS_PER_INS = 64 / RCH;        // rows one wave-wide 16-byte load covers
-    constexpr int RK_INS = 32 / RK_ROWS_PER_INS;
+    constexpr int RK_INS = 32 * RCH / 64;            // wave-wide 16-byte loads per 32-row chunk (chunk id = i*64 + lane)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -72,19 +71,19 @@ __global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, int Cn, cons
     };
     // narrow operand: guarded register loads (zero rows past the slab end), written to LDS row-major
     uint4 rk[RK_INS];
-    const int rk_row = lane / RCH, rk_c = lane % RCH;
     auto load_rk = [&](int chunk) __attribute__((always_inline)) {
         const int m0 = mb + chunk * 32;
 #pragma unroll
         for (int i = 0; i < RK_INS; ++i) {
-            const int m = m0 + i * RK_ROWS_PER_INS + rk_row;
-            rk[i] = m < me ? *reinterpret_cast<const uint4*>(Rk + (size_t)m * ldr + rk_c * 8) : make_uint4(0, 0, 0, 0);
+            const int id = i * 64 + lane;
+            const int m = m0 + id / RCH;
+            rk[i] = m < me ? *reinterpret_cast<const uint4*>(Rk + (size_t)m * ldr + (id % RCH) * 8) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_rk = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < RK_INS; ++i)
-            *reinterpret_cast<uint4*>(my + buf * BUF + WD_BYTES + ((i * RK_ROWS_PER_INS + rk_row) * RCH + rk_c) * 16) = rk[i];
+            *reinterpret_cast<uint4*>(my + buf * BUF + WD_BYTES + (i * 64 + lane) * 16) = rk[i];
     };
 
     f32x4 acc[RB][4];
@@ -154,7 +153,7 @@ __global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, int Cn, cons
 // Slab mode only (part_stride = r * Cn): returns 1 when the operands are not eligible.
 int lora_rank_mfma_launch(int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, float* part,
                           int transpose_out, int rows_per_block, hipStream_t st) {
-    const bool ok = (r == 16 || r == 32 || r == 64) && Cn % 8 == 0 && ldw % 8 == 0 && ldr % 8 == 0 &&
+    const bool ok = (r == 16 || r == 32 || r == 48 || r == 64) && Cn % 8 == 0 && ldw % 8 == 0 && ldr % 8 == 0 &&
                     (reinterpret_cast<uintptr_t>(Wd) & 15) == 0 && (reinterpret_cast<uintptr_t>(Rk) & 15) == 0 &&
                     rows_per_block % 32 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
     if (!ok) return 1;
@@ -173,7 +172,7 @@ int lora_rank_mfma_launch(int M, int Cn, int r, const void* Wd, int ldw, const v
         hipLaunchKernelGGL(kern, grid, dim3(256), sm, st, M, Cn, (const bf16_t*)Wd, ldw, (const bf16_t*)Rk, ldr, part,    \
                            ldo, transpose_out, part_stride, rows_per_block);                                            \
     } while (0)
-    if (r == 16) RM_LAUNCH(1); else if (r == 32) RM_LAUNCH(2); else RM_LAUNCH(4);
+    if (r == 16) RM_LAUNCH(1); else if (r == 32) RM_LAUNCH(2); else if (r == 48) RM_LAUNCH(3); else RM_LAUNCH(4);
 #undef RM_LAUNCH
     return 0;
 }

@@ -51,7 +51,7 @@ SIGNATURES = {
     "cvft_lora_rank_accum": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "cvft_lora_rank_partial": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "cvft_lora_grad_reduce": [_i, _p, _i, _p],
-    "cvft_lora_shadow": [_i, _p, _p, _p, _p, _p],
+    "cvft_lora_shadow": [_i, _p, _p, _p],
     "cvft_layernorm_fwd": [_i, _i, _i, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p],
     "cvft_layernorm_bwd": [_i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p],
     "cvft_groupnorm_mish_fwd": [_i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p],

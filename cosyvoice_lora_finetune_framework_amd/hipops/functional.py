@@ -257,7 +257,12 @@ class LoraGradSink:
         return ws
 
     def add(self, part: torch.Tensor, grad: torch.Tensor, numel: int, nsplit: int):
-        self.tasks.append((part.data_ptr(), grad.data_ptr(), numel, nsplit))
+        """grad (contiguous, numel) += sum of nsplit contiguous slabs."""
+        self.tasks.append((part.data_ptr(), grad.data_ptr(), 1, numel, numel, numel, nsplit, 0))
+
+    def add_block(self, part_ptr: int, grad: torch.Tensor, rows: int, cols: int, pitch: int, stride: int, nsplit: int):
+        """grad [rows, cols] += sum over slabs of the [rows, cols] sub-block at part_ptr (row pitch / slab stride in floats)."""
+        self.tasks.append((part_ptr, grad.data_ptr(), rows, cols, pitch, stride, nsplit, 0))
 
     def flush(self):
         if not self.tasks:
@@ -270,7 +275,7 @@ class LoraGradSink:
         if ent is None:
             dev = torch.device("cuda", torch.cuda.current_device())
             tbl = torch.tensor(self.tasks, dtype=torch.int64).to(dev)
-            ent = (tbl, min(64, max(1, -(-max(t[2] for t in self.tasks) // 1024))))
+            ent = (tbl, min(64, max(1, -(-max(t[2] * t[3] for t in self.tasks) // 1024))))
             if len(LoraGradSink._cache) > 8:
                 LoraGradSink._cache.clear()
             LoraGradSink._cache[key] = ent
@@ -476,6 +481,80 @@ class LinearQKVFn(torch.autograd.Function):
         return (dx, *grads, None, None)
 
 
+class QKVStack:
+    """Frozen side of a stacked q|k|v projection: W [3N, K], its transpose [K, 3N], bias [3N] (compute dtype)."""
+
+    def __init__(self, packs):
+        self.N, self.K = packs[0].N, packs[0].K
+        self.Wf = torch.cat([p.Wf for p in packs], 0).contiguous()
+        self.Wb = self.Wf.t().contiguous()
+        if all(p.bias is None for p in packs):
+            self.bias = None
+        else:
+            self.bias = torch.cat([p.bias if p.bias is not None else torch.zeros(p.N, device=self.Wf.device) for p in packs]).contiguous()
+
+
+class LinearQKVStackedFn(torch.autograd.Function):
+    """q|k|v as ONE projection: Y [M, 3N] = x Wqkv^T + b + (s x A_stack^T) B_blk^T with the three adapters stacked
+    (A_stack [3r, K]) / block-diagonal (B_blk [3N, 3r]).  Backward = one rank-3r GEMM, one dgrad over K = 3N, and two
+    matrix-core slab launches (r = 3r) whose sub-blocks are routed to the six .grad buffers by the reduce tasks.
+    bf16 training path only (needs the optimiser-maintained stacked shadows); anything else uses LinearQKVFn."""
+
+    @staticmethod
+    def forward(ctx, x, Aq, Bq, Ak, Bk, Av, Bv, wstack: QKVStack, ops, scale: float):
+        x = _c(x)
+        A, At, Bb, Bbt = ops
+        U = gemm(x, A, alpha=scale)                                     # [M, 3r]
+        Y = gemm(x, wstack.Wf, bias=wstack.bias, U=U, Bl=Bb)           # [M, 3N]
+        ctx.w, ctx.ops, ctx.scale, ctx.refs = wstack, ops, scale, ((Aq, Bq), (Ak, Bk), (Av, Bv))
+        ctx.save_for_backward(x, U)
+        N = wstack.N
+        return Y[:, :N], Y[:, N:2 * N], Y[:, 2 * N:]
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x, U = ctx.saved_tensors
+        w, (A, At, Bb, Bbt), scale = ctx.w, ctx.ops, ctx.scale
+        N, M = w.N, x.shape[0]
+        es = dq.element_size()
+        if (dq.stride() == (3 * N, 1) and dk.stride() == (3 * N, 1) and dv.stride() == (3 * N, 1)
+                and dk.data_ptr() == dq.data_ptr() + N * es and dv.data_ptr() == dq.data_ptr() + 2 * N * es):
+            dY = torch.as_strided(dq, (M, 3 * N), (3 * N, 1), dq.storage_offset())     # the attention backward's fused buffer
+        else:
+            dY = torch.cat([dq, dk, dv], 1)
+        V = gemm(dY, Bbt, alpha=scale)                                  # [M, 3r] = s * dY B_blk
+        dx = gemm(dY, w.Wb, U=V, Bl=At) if ctx.needs_input_grad[0] else None
+        r3 = V.shape[1]
+        r = r3 // 3
+        sink = LoraGradSink.active
+        grads = [(a.grad, b.grad) for a, b in ctx.refs]
+        direct = all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for pair in grads for g in pair)
+        if sink is not None and direct and sink.side is None:
+            K = x.shape[1]
+            rpb, ns = LoraGradSink.plan(M, K)
+            wsA = LoraGradSink.workspace(ctx.refs[0][0], ns * 3)        # slab [3r, K] per row block
+            check(lib().cvft_lora_rank_partial(dt(x), M, K, r3, ptr(x), x.stride(0), ptr(V), V.stride(0), ptr(wsA), 0, rpb,
+                                               stream()), "cvft_lora_rank_partial")
+            for i, (gA, _) in enumerate(grads):
+                sink.add_block(wsA.data_ptr() + i * r * K * 4, gA, r, K, K, r3 * K, ns)
+            rpb, ns = LoraGradSink.plan(M, 3 * N)
+            wsB = LoraGradSink.workspace(ctx.refs[0][1], ns * 9)        # slab [3N, 3r] per row block
+            check(lib().cvft_lora_rank_partial(dt(dY), M, 3 * N, r3, ptr(dY), dY.stride(0), ptr(U), U.stride(0), ptr(wsB), 1,
+                                               rpb, stream()), "cvft_lora_rank_partial")
+            for i, (_, gB) in enumerate(grads):
+                sink.add_block(wsB.data_ptr() + (i * N * r3 + i * r) * 4, gB, N, r, r3, 3 * N * r3, ns)
+            out = [None] * 6
+        else:
+            out = []
+            for i, (gA, gB) in enumerate(grads):
+                tA = gA if direct else torch.zeros((r, x.shape[1]), dtype=torch.float32, device=x.device)
+                tB = gB if direct else torch.zeros((N, r), dtype=torch.float32, device=x.device)
+                rank_accum(x, V[:, i * r:(i + 1) * r], tA, False)
+                rank_accum(dY[:, i * N:(i + 1) * N], U[:, i * r:(i + 1) * r], tB, True)
+                out += [None, None] if direct else [tA, tB]
+        return (dx, *out, None, None, None)
+
+
 class FeedForwardFn(torch.autograd.Function):
     """y = W2 act(W1 x + b1) + b2 (+ residual), both linears with optional LoRA.  Backward applies act'(z) in the
     epilogue of W2's dgrad launch (no separate activation-backward pass over the [M, hidden] tensor)."""
@@ -510,9 +589,42 @@ def lora_linear(x, pack: LinearPack, A=None, B=None, scale: float = 1.0, act: Op
     return LinearFn.apply(x, A, B, residual, pack, scale, act)
 
 
+_QKV_STACKS = {}
+QKV_STACKING = _os.environ.get("CVFT_QKV_STACK", "1") != "0"
+
+
+def _qkv_stacked_operands(x, packs, loras, scales):
+    """(QKVStack, stacked LoRA operands) when the stacked bf16 path applies, else None."""
+    if not QKV_STACKING or x.dtype != torch.bfloat16 or any(a is None or b is None for a, b in loras):
+        return None
+    (Aq, Bq), (Ak, Bk), (Av, Bv) = loras
+    if not (scales[0] == scales[1] == scales[2] and Aq.shape == Ak.shape == Av.shape and Bq.shape == Bk.shape == Bv.shape
+            and Aq.shape[0] == 16 and packs[0].N == packs[1].N == packs[2].N and packs[0].N % 8 == 0 and packs[0].K % 8 == 0):
+        return None
+    ref = getattr(Aq, "_cvft_opt", None)
+    opt = ref() if ref is not None else None
+    if opt is None:
+        return None
+    for P in (Aq, Bq, Ak, Bk, Av, Bv):                    # masters edited in place since the last shadow refresh
+        if getattr(P, "_cvft_shadow_ver", -1) != P._version:
+            return None
+    ops = opt.stack_for((Aq, Ak, Av), (Bq, Bk, Bv))
+    if ops is None:
+        return None
+    key = tuple(id(p) for p in packs)
+    ws = _QKV_STACKS.get(key)
+    if ws is None:
+        ws = QKVStack(packs)
+        _QKV_STACKS[key] = ws
+    return ws, ops
+
+
 def lora_linear_qkv(x, packs, loras, scales):
     """(q, k, v) = three LoRA linears of x; loras = ((Aq, Bq), (Ak, Bk), (Av, Bv)) with None entries for plain layers."""
     (Aq, Bq), (Ak, Bk), (Av, Bv) = loras
+    st = _qkv_stacked_operands(x, packs, loras, scales)
+    if st is not None:
+        return LinearQKVStackedFn.apply(x, Aq, Bq, Ak, Bk, Av, Bv, st[0], st[1], scales[0])
     return LinearQKVFn.apply(x, Aq, Bq, Ak, Bk, Av, Bv, tuple(packs), tuple(scales))
 
 

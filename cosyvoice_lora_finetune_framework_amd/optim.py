@@ -9,6 +9,7 @@ by torch.nn.utils.clip_grad_norm_ (checked in tests/test_ops_gpu.py::test_adamw_
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Iterable, List, Optional
 
 import torch
@@ -46,22 +47,26 @@ class FlatAdamW:
             p.grad = self.flat_g[off:off + k].view(p.shape)
             off += k
         # compute-dtype shadows (bf16 copy + transposed bf16 copy) of every adapter, refreshed by ONE kernel per
-        # optimiser step; LinearFn picks them up through P._cvft_shadow
+        # optimiser step; LinearFn picks them up through P._cvft_shadow.  Stacked q|k|v operand sets (see
+        # hipops.functional.QKVStack) add their own destination tiles to the same launch.
         self.flat_c = torch.empty(n, dtype=torch.bfloat16, device=dev)
         self.flat_t = torch.empty(n, dtype=torch.bfloat16, device=dev)
-        tiles = []
+        self._offsets = {}
+        self._tile_rows = []
+        self._stacks = {}
         off = 0
+        es = self.flat_c.element_size()
         for p in self.params:
             k = p.numel()
             rows = p.shape[0]
             cols = k // rows
+            self._offsets[id(p)] = off
+            p._cvft_opt = weakref.ref(self)
             if p.dim() == 2:
                 p._cvft_shadow = (self.flat_c[off:off + k].view(rows, cols), self.flat_t[off:off + k].view(cols, rows))
-            for tr in range(-(-rows // 32)):
-                for tc in range(-(-cols // 32)):
-                    tiles.append((off, rows, cols, (tr << 16) | tc))
+            self._add_tiles(off, rows, cols, self.flat_c.data_ptr() + off * es, cols, self.flat_t.data_ptr() + off * es, rows)
             off += k
-        self.tiles = torch.tensor(tiles, dtype=torch.int32, device=dev).contiguous()
+        self.tiles = None
         self.base_lr, self.wd, self.betas, self.eps, self.max_grad_norm = lr, weight_decay, betas, eps, max_grad_norm
         self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -69,9 +74,46 @@ class FlatAdamW:
         self.step_count = 0
         self.refresh_shadows()
 
+    def _add_tiles(self, src_off: int, rows: int, cols: int, dst_ptr: int, dst_pitch: int, dstt_ptr: int, dstt_pitch: int):
+        for tr in range(-(-rows // 32)):
+            for tc in range(-(-cols // 32)):
+                self._tile_rows.append((src_off, dst_ptr, dstt_ptr, rows | (cols << 32), tr | (tc << 32),
+                                        dst_pitch | (dstt_pitch << 32)))
+        self.tiles = None
+
+    def stack_for(self, As, Bs):
+        """Stacked / block-diagonal bf16 operands of three adapters that share their input (q|k|v):
+        A [3r, K] and A^T [K, 3r];  B_blk [3N, 3r] (block i = B_i) and B_blk^T [3r, 3N].  Filled by the same
+        per-step shadow launch as the per-parameter shadows.  Returns None when the parameters are not ours."""
+        key = tuple(id(p) for p in (*As, *Bs))
+        st = self._stacks.get(key)
+        if st is not None:
+            return st
+        if any(id(p) not in self._offsets for p in (*As, *Bs)):
+            return None
+        r, K = As[0].shape
+        N = Bs[0].shape[0]
+        g = len(As)
+        dev = self.flat_p.device
+        A = torch.zeros((g * r, K), dtype=torch.bfloat16, device=dev)
+        At = torch.zeros((K, g * r), dtype=torch.bfloat16, device=dev)
+        Bb = torch.zeros((g * N, g * r), dtype=torch.bfloat16, device=dev)
+        Bbt = torch.zeros((g * r, g * N), dtype=torch.bfloat16, device=dev)
+        es = 2
+        for i, (Ap, Bp) in enumerate(zip(As, Bs)):
+            self._add_tiles(self._offsets[id(Ap)], r, K, A.data_ptr() + i * r * K * es, K, At.data_ptr() + i * r * es, g * r)
+            self._add_tiles(self._offsets[id(Bp)], N, r, Bb.data_ptr() + (i * N * g * r + i * r) * es, g * r,
+                            Bbt.data_ptr() + (i * r * g * N + i * N) * es, g * N)
+        st = (A, At, Bb, Bbt)
+        self._stacks[key] = st
+        self.refresh_shadows()
+        return st
+
     def refresh_shadows(self):
-        cb.check(cb.lib().cvft_lora_shadow(self.tiles.shape[0], cb.ptr(self.tiles), cb.ptr(self.flat_p), cb.ptr(self.flat_c),
-                                           cb.ptr(self.flat_t), cb.stream()), "cvft_lora_shadow")
+        if self.tiles is None:
+            self.tiles = torch.tensor(self._tile_rows, dtype=torch.int64).to(self.flat_p.device).contiguous()
+        cb.check(cb.lib().cvft_lora_shadow(self.tiles.shape[0], cb.ptr(self.tiles), cb.ptr(self.flat_p), cb.stream()),
+                 "cvft_lora_shadow")
         for p in self.params:            # in-place edits of a master (load_lora_weights, ...) bump _version => on-the-fly cast
             p._cvft_shadow_ver = p._version
 

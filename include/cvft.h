@@ -101,14 +101,19 @@ int cvft_lora_rank_accum(int dtype, int M, int C, int r, const void* Wd, int ldw
                          float* out, int ldo, int transpose_out, void* stream);
 /* Deterministic two-stage form of the same gradients (no atomics): stage 1 writes one fp32 slab per row block
  * (part[s][r][C] or part[s][C][r], s < ceil(M / rows_per_block), rows_per_block 64, 128 or k*256; operands 16-byte
- * aligned, r % 16 == 0); stage 2 is ONE launch for all adapters: tasks int64[ntasks][4] = {slab ptr, grad ptr,
- * numel, nsplit}, grad[i] += sum_s slab[s*numel + i] in fixed order. */
+ * aligned, r % 16 == 0; the bf16 matrix-core path takes r in {16,32,48,64} and any rows_per_block % 32 == 0);
+ * stage 2 is ONE launch for all adapters: tasks int64[ntasks][8] = {slab ptr, grad ptr, rows, cols, slab_pitch,
+ * slab_stride, nsplit, 0}:  grad[i*cols + j] += sum_s slab[s*slab_stride + i*slab_pitch + j]  in fixed order (a task
+ * may address a sub-block of a wider slab: the stacked q|k|v adapters share one slab). */
 int cvft_lora_rank_partial(int dtype, int M, int C, int r, const void* Wd, int ldw, const void* Rk, int ldr,
                            float* part, int transpose_out, int rows_per_block, void* stream);
 int cvft_lora_grad_reduce(int ntasks, const void* tasks, int max_blocks_x, void* stream);
-/* One launch per optimiser step: bf16 copy (flat_c) and transposed bf16 copy (flat_t) of every LoRA master in
- * the flat fp32 buffer.  tiles: int32[ntiles][4] = {offset, rows, cols, tile_row<<16 | tile_col} (32x32 tiles). */
-int cvft_lora_shadow(int ntiles, const void* tiles, const float* flat_p, void* flat_c, void* flat_t, void* stream);
+/* One launch per optimiser step: bf16 copy and transposed bf16 copy of every LoRA master in the flat fp32 buffer.
+ * tiles: int64[ntiles][6] = {src offset (elements of flat_p), dst ptr, dst_t ptr, rows | cols << 32,
+ * tile_row | tile_col << 32, dst_pitch | dst_t_pitch << 32} (32x32 tiles):
+ *   dst[i*dst_pitch + j] = bf16(src[i*cols + j]),  dst_t[j*dst_t_pitch + i] = same.
+ * Destinations are free-form so that the same launch also fills the stacked / block-diagonal q|k|v operands. */
+int cvft_lora_shadow(int ntiles, const void* tiles, const float* flat_p, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * LayerNorm over the channel axis (+ optional ReLU, + optional post-scale).

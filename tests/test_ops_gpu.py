@@ -451,3 +451,45 @@ def test_gemm_fused_lora_side_path(dtype, M, N, K, r):
     uq = q(ur.float(), dtype).double()            # the kernel feeds the rounded U to the extension step
     ref = F.silu(x.double() @ w.double().t() + b.double() + uq @ Bm.double().t())
     assert rel(y, ref) < TOL[dtype]
+
+
+def test_qkv_stacked_matches_separate_projections():
+    """bf16 training path: q|k|v as one stacked projection (block-diagonal LoRA-B, rank 48 slab kernels, sub-block
+    reduce tasks) must give the same outputs, input gradient and six adapter gradients as three LoRALinear modules."""
+    from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
+    from cosyvoice_lora_finetune_framework_amd.modules import hip_qkv
+    from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
+    HF = HFmod()
+    torch.manual_seed(3)
+    K, N, M = 256, 512, 1000
+    mods = [LoRALinear(torch.nn.Linear(K, N), r=16, lora_alpha=32, lora_dropout=0.0).to(DEV) for _ in range(3)]
+    for m in mods:
+        torch.nn.init.normal_(m.lora_B, std=0.05)
+        m.eval()
+    params = [p for m in mods for p in (m.lora_A, m.lora_B)]
+    opt = FlatAdamW(params, lr=1e-3)
+    x = (torch.randn(M, K, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    gq, gk, gv = (torch.randn(M, N, device=DEV).to(torch.bfloat16) for _ in range(3))
+
+    def run(stack: bool):
+        HF.QKV_STACKING = stack
+        opt.zero_grad()
+        x.grad = None
+        with HF.LoraGradSink():
+            q, k, v = hip_qkv(mods[0], mods[1], mods[2], x)
+            fused = torch.cat([gq, gk, gv], 1)          # like the attention backward's dq|dk|dv buffer
+            torch.autograd.backward([q, k, v], [fused[:, :N], fused[:, N:2 * N], fused[:, 2 * N:]])
+        return [t.float().clone() for t in (q, k, v, x.grad)] + [p.grad.clone() for p in params]
+    try:
+        a = run(True)
+        b = run(False)
+    finally:
+        HF.QKV_STACKING = True
+    names = ["q", "k", "v", "dx"] + [f"g{i}" for i in range(6)]
+    for n, u, w in zip(names, a, b):
+        assert rel(u, w) < 2e-2, (n, rel(u, w))
+    # and against plain fp32 torch math
+    for i, m in enumerate(mods):
+        W, bb = m.original_layer.weight.float(), m.original_layer.bias.float()
+        ref = x.detach().float() @ W.t() + bb + m.scaling * (x.detach().float() @ m.lora_A.t()) @ m.lora_B.t()
+        assert rel(a[i], ref) < 2e-2
