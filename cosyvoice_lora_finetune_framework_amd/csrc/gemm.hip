@@ -390,8 +390,12 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
     al = al && (p.R == 0 || (p.vecU && p.vecB)) && bU < lim && bB < lim;
     if (al) {
         if constexpr (sizeof(T) == 2) {
-            // LDS-DMA kernels take every eligible shape (CVFT_GLDS_CFG: -1 = off, > 0 = forced tile; experiments)
+            // LDS-DMA kernels take every eligible shape (CVFT_GLDS_CFG: -1 = off; experiments)
             static const int gcfg = getenv("CVFT_GLDS_CFG") ? atoi(getenv("CVFT_GLDS_CFG")) : 0;
+            if (gcfg >= 0 && p.N <= 64) {
+                int rc = skinny_launch(p, st);
+                if (rc != 1) return rc;
+            }
             if (gcfg >= 0) {
                 int rc = gemm_glds_launch(p, st, gcfg);
                 if (rc != 1) return rc;

@@ -115,3 +115,5 @@ __device__ __forceinline__ void gemm_epilogue_store(const GP<T>& p, const float*
 
 // LDS-DMA (global_load_lds) bf16 kernels for identity-geometry GEMMs; returns 1 when the shape is not eligible.
 int gemm_glds_launch(const GP<bf16_t>& p, hipStream_t st, int cfg);
+// rank-side products C[M, R<=64] = alpha * A W^T without epilogue (skinny.hip); returns 1 when not eligible.
+int skinny_launch(const GP<bf16_t>& p, hipStream_t st);

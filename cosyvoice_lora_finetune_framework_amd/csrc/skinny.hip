@@ -1,0 +1,106 @@
+// skinny.hip -- bf16 rank-side GEMM  C[M, R] = alpha * X[M, K] . A[R, K]^T  with R in {16, 32, 48, 64}  (the LoRA
+// "U = s x A^T" / "V = s dY B" products).  HBM-bound (X is read once, 2*M*K bytes; A is a few KB and L2-resident):
+// a 64x64-tile GEMM kernel gives it M/64 blocks (63 for the estimator) and walks K serially -- pure latency.
+// Here one workgroup owns 32 rows; its 8 wavefronts split K, every wave keeps several k-steps of fragment-shaped
+// loads in flight (16 rows x 64 B per instruction, straight into the MFMA operand registers, no LDS staging), and
+// the eight partial tiles are summed through LDS.  M/32 blocks x 8 waves: 1000+ waves in flight.
+//
+// Replaces (reference): the x @ lora_A.T product of lora.py:71-73 (and its transpose in backward).
+#include "gemm_common.cuh"
+
+template <int RB, int MT, int KS>      // RB = R / 16 column tiles, MT = 16-row tiles per block, KS = k-steps in flight per wave
+__global__ void __launch_bounds__(512) skinny_kernel(int M, int K, const bf16_t* __restrict__ X, int ldx,
+                                                     const bf16_t* __restrict__ A, int lda, float alpha,
+                                                     bf16_t* __restrict__ C, int ldc) {
+    // 8 wavefronts split K; every wave covers all MT row tiles so that each A fragment it loads is used MT times
+    // (at one row tile per block the re-reads of A from L2 exceeded the X stream itself)
+    __shared__ __attribute__((aligned(16))) float red[4][MT][RB][16][17];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
+    const int m0 = blockIdx.x * 16 * MT;
+    const int kper = ((K / 32 + 7) / 8) * 32;                    // this wave's K slice [kb, ke)
+    const int kb = w * kper, ke = min(K, kb + kper);
+    f32x4 acc[MT][RB];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int j = 0; j < RB; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) xp[t] = X + (size_t)min(m0 + t * 16 + l15, M - 1) * ldx + kg * 8;   // clamped: rows >= M never stored
+    const bf16_t* ap = A + (size_t)l15 * lda + kg * 8;
+    for (int k0 = kb; k0 < ke; k0 += 32 * KS) {
+        uint4 xv[KS][MT], av[KS][RB];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = min(k0 + 32 * s, K - 32);              // clamped address, masked below (no branch around a load)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) xv[s][t] = *reinterpret_cast<const uint4*>(xp[t] + k);
+#pragma unroll
+            for (int j = 0; j < RB; ++j) av[s][j] = *reinterpret_cast<const uint4*>(ap + (size_t)j * 16 * lda + k);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const unsigned keep = (k0 + 32 * s < ke) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                uint4 v = av[s][j];
+                v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+                const bf16x8 b = *reinterpret_cast<bf16x8*>(&v);
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&xv[s][t]), b, acc[t][j], 0, 0, 0);
+            }
+        }
+    }
+    // 8 partial tiles -> 4 (waves 4..7 hand theirs to waves 0..3) -> final sum
+    if (w >= 4) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[w - 4][t][j][kg * 4 + r][l15] = acc[t][j][r];
+    }
+    __syncthreads();
+    if (w < 4) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[w][t][j][kg * 4 + r][l15] += acc[t][j][r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * MT * RB * 16; e += 512) {
+        const int r = e / (RB * 16), c = e % (RB * 16);
+        if (m0 + r >= M) continue;
+        const int t = r >> 4, rr = r & 15, j = c >> 4, cc = c & 15;
+        const float s = red[0][t][j][rr][cc] + red[1][t][j][rr][cc] + red[2][t][j][rr][cc] + red[3][t][j][rr][cc];
+        C[(size_t)(m0 + r) * ldc + c] = (bf16_t)(alpha * s);
+    }
+}
+
+// returns 1 when the launch is not a plain skinny product
+int skinny_launch(const GP<bf16_t>& p, hipStream_t st) {
+    const bool ident = p.ntaps == 1 && p.tap_off[0] == 0 && p.in_stride == 1 && p.Tin == p.Tm && !p.in_len && p.Tm == p.M &&
+                       p.out_stride == 1 && p.out_off == 0 && !p.out_len;
+    if (!ident || p.fuse || p.R > 0 || p.bias || p.act || p.preact || p.dact_src || p.residual) return 1;
+    if (p.N > 64 || p.N % 16 != 0 || p.K % 32 != 0 || p.K < 32 || !p.vecA || !p.vecW) return 1;
+    constexpr int MT = 2;
+    dim3 grid((p.M + 16 * MT - 1) / (16 * MT));
+    const int ksteps_per_wave = (p.K / 32 + 7) / 8;
+#define SK_LAUNCH(RBv, KSv) hipLaunchKernelGGL((skinny_kernel<RBv, MT, KSv>), grid, dim3(512), 0, st, p.M, p.K, p.A, p.lda, p.W, p.ldw, \
+                                               p.alpha, p.C, p.ldc)
+#define SK_RB(RBv) do { if (ksteps_per_wave >= 4) SK_LAUNCH(RBv, 4); else if (ksteps_per_wave >= 2) SK_LAUNCH(RBv, 2); else SK_LAUNCH(RBv, 1); } while (0)
+    switch (p.N / 16) {
+        case 1: SK_RB(1); break;
+        case 2: SK_RB(2); break;
+        case 3: SK_RB(3); break;
+        default: SK_RB(4); break;
+    }
+#undef SK_RB
+#undef SK_LAUNCH
+    cvft_set_kernel_label("skinny_kernel<bf16,r%d>", p.N);
+    CVFT_LAUNCH_CHECK("cvft_gemm");
+    return 0;
+}
