@@ -382,6 +382,10 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
                 if (rc != 1) return rc;
             }
         }
+        if (p.R > 16) {
+            cvft_set_error("cvft_gemm: fused LoRA side path with 16 < R <= 48 needs the bf16 LDS-DMA kernel (K %% 64 == 0, identity rows)");
+            return -1;
+        }
         if constexpr (sizeof(T) == 2) {
             if (p.K >= 2048 && t128f >= 256) return gemm_launch_cfg<T, 256, 128, 4, 2, 2, true, true>(p, st);
         }
@@ -424,7 +428,7 @@ extern "C" int cvft_gemm(const cvft_gemm_args* a, void* stream) {
     CVFT_CHECK_ARG(a->A && a->W && a->C, "cvft_gemm: null operand");
     CVFT_CHECK_ARG(a->lda >= a->K && a->ldw >= a->ntaps * a->K && a->ldc >= a->N, "cvft_gemm: bad leading dims");
     if (a->La) {
-        CVFT_CHECK_ARG(a->Bl && a->R > 0 && a->R <= 16 && a->ldla >= a->K && a->ldbl >= a->R, "cvft_gemm: fused LoRA needs 0 < R <= 16");
+        CVFT_CHECK_ARG(a->Bl && a->R > 0 && a->R <= 48 && a->ldla >= a->K && a->ldbl >= a->R, "cvft_gemm: fused LoRA needs 0 < R <= 48");
         CVFT_CHECK_ARG(a->ntaps == 1 && a->Tm == a->Tin && a->in_stride == 1 && a->tap_off[0] == 0 && a->out_stride == 1 &&
                        a->out_off == 0 && a->Tout == a->Tin, "cvft_gemm: fused LoRA side path needs identity row geometry");
     } else if (a->U) {

@@ -18,24 +18,29 @@
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-// FU: the side-path input  U = lora_scale * A . La^T  (La [R <= 16][K]) is produced inside the launch: the La k-tile
-// rides along as 16 more DMA rows, the wn == 0 waves run one extra MFMA per A fragment, the bf16 result goes through a
-// small LDS panel into every wave's extension fragments, and the n-tile-0 blocks publish it to Uout for backward.
+// RT > 0 (fused side path): U = lora_scale * A . La^T  (La [R <= 16*RT][K]) is produced inside the launch: the La k-tile
+// rides along as 16*RT more DMA rows, the wn == 0 waves run RT extra MFMAs per A fragment, the bf16 result goes through
+// a small LDS panel into every wave's extension fragments, and the n-tile-0 blocks publish it to Uout for backward.
 // NS = LDS stages: tiles kt+1 .. kt+NS-1 are in flight while tile kt feeds the MFMAs (counted s_waitcnt vmcnt, raw
 // s_barrier -- __syncthreads() would drain the DMA queue).  These GEMMs are small (1-4 blocks per CU, 4-16 k-tiles):
 // with one tile of lookahead every k-tile cost a full memory round trip (~0.9 us measured in the training step).
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, bool FU, int NS>
+template <int BM, int BN, int WM, int WN, int RT, int NS>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     typedef bf16_t T;
     constexpr int NW = WM * WN, NT = NW * 64, BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
-    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, L_BYTES = FU ? 16 * 128 : 0, BUF = A_BYTES + W_BYTES + L_BYTES;
-    constexpr int UP_OFF = NS * BUF;                              // FU: [BM][16] bf16 panel behind the ring
+    constexpr bool FU = RT > 0;
+    constexpr int RP = 16 * RT;                                   // padded rank of the fused side path
+    constexpr int L_PIECES = 2 * RT;                              // 8-row DMA pieces of the La tile, dealt round-robin to the waves
+    constexpr int LP_MAX = (L_PIECES + NW - 1) / NW;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, L_BYTES = RP * 128, BUF = A_BYTES + W_BYTES + L_BYTES;
+    constexpr int UP_OFF = NS * BUF;                              // FU: [BM][RP] bf16 panel behind the ring
     constexpr int A_INS = BM / 8 / NW, W_INS = BN / 8 / NW;      // DMA wave-instructions per wave per k-tile
-    constexpr int INS = A_INS + W_INS;                            // DMA instructions per wave per tile (waves 0/1: +1 when FU)
-    static_assert(NS >= 2 && (NS - 2) * (INS + 1) < 64, "vmcnt is a 6-bit counter");
+    constexpr int INS = A_INS + W_INS;                            // DMA instructions per wave per tile (+ its La pieces)
+    static_assert(NS >= 2 && (NS - 2) * (INS + LP_MAX) < 64, "vmcnt is a 6-bit counter");
+    static_assert(LP_MAX <= 2, "wait dispatch below handles 0, 1 or 2 La pieces per wave");
     constexpr int CLD = BN + 4;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA pieces per wave");
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
@@ -73,17 +78,25 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         const int n = min(n0 + r, p.N - 1);
         gw[i] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw + gc * 8);
     }
-    const char* gl = nullptr;                                     // FU: waves 0/1 each move 8 of the 16 La rows
+    const char* gl[LP_MAX > 0 ? LP_MAX : 1];                      // FU: wave w moves La pieces w, w + NW, ...
+    const int my_lp = FU ? (wid < L_PIECES ? (L_PIECES - wid + NW - 1) / NW : 0) : 0;     // wave-uniform
     if (FU) {
-        const int r = (wid & 1) * 8 + (lane >> 3);
-        const int gc = (lane & 7) ^ ((r >> 1) & 7);
-        gl = reinterpret_cast<const char*>(p.La + (size_t)min(r, p.R - 1) * p.ldla + gc * 8);
+#pragma unroll
+        for (int i = 0; i < LP_MAX; ++i) {
+            const int r = (wid + i * NW) * 8 + (lane >> 3);
+            const int gc = (lane & 7) ^ ((r >> 1) & 7);
+            gl[i] = reinterpret_cast<const char*>(p.La + (size_t)min(r, p.R - 1) * p.ldla + gc * 8);
+        }
     }
     auto issue = [&](int buf) __attribute__((always_inline)) {
         unsigned char* base = smem + buf * BUF;
-        if (FU && wid < 2) {
-            __builtin_amdgcn_global_load_lds((glb_void_t*)gl, (lds_void_t*)(base + A_BYTES + W_BYTES + wid * 1024), 16, 0, 0);
-            gl += BK * 2;
+        if (FU) {
+#pragma unroll
+            for (int i = 0; i < LP_MAX; ++i)
+                if (i < my_lp) {
+                    __builtin_amdgcn_global_load_lds((glb_void_t*)gl[i], (lds_void_t*)(base + A_BYTES + W_BYTES + (wid + i * NW) * 1024), 16, 0, 0);
+                    gl[i] += BK * 2;
+                }
         }
 #pragma unroll
         for (int i = 0; i < A_INS; ++i) {
@@ -135,10 +148,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     }
 
     f32x4 acc[MI][NI];
-    f32x4 uacc[MI];
+    f32x4 uacc[MI][RT > 0 ? RT : 1];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        uacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < (RT > 0 ? RT : 1); ++t) uacc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -163,9 +177,12 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) Mma<T>::mma(acc[i][j], a[i], b[j]);
             if (FU && wn == 0) {                                  // wave-uniform
-                const bf16x8 la = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + A_BYTES + W_BYTES + rd);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) Mma<T>::mma(uacc[i], a[i], la);
+                for (int t = 0; t < RT; ++t) {
+                    const bf16x8 la = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + A_BYTES + W_BYTES + t * 2048 + rd);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) Mma<T>::mma(uacc[i][t], a[i], la);
+                }
             }
         }
     };
@@ -179,7 +196,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         // this wave's pieces of tile kt have landed once at most the NS-2 younger tiles are still outstanding
         // (loads retire in order; the LoRA fragment loads are older than every tile)
         if (kt + NS - 2 < nk) {
-            if (FU && wid < 2) wait_vmcnt<(NS - 2) * (INS + 1)>(); else wait_vmcnt<(NS - 2) * INS>();
+            if (my_lp == 2) wait_vmcnt<(NS - 2) * (INS + 2)>();
+            else if (my_lp == 1) wait_vmcnt<(NS - 2) * (INS + 1)>();
+            else wait_vmcnt<(NS - 2) * INS>();
         } else {
             wait_vmcnt<0>();                                    // pipeline tail
         }
@@ -196,17 +215,23 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wm * TM + i * 16 + kg * 4 + r;
-                    const bf16_t uv = from_f32<T>(l15 < p.R ? uacc[i][r] * p.lora_scale : 0.f);
-                    Up[row * 16 + l15] = uv;
-                    if (n0 == 0 && p.Uout && m0 + row < p.M && l15 < p.R) p.Uout[(size_t)(m0 + row) * p.ldu + l15] = uv;
-                }
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = wm * TM + i * 16 + kg * 4 + r, col = t * 16 + l15;
+                        const bf16_t uv = from_f32<T>(col < p.R ? uacc[i][t][r] * p.lora_scale : 0.f);
+                        Up[row * RP + col] = uv;
+                        if (n0 == 0 && p.Uout && m0 + row < p.M && col < p.R) p.Uout[(size_t)(m0 + row) * p.ldu + col] = uv;
+                    }
         }
         __syncthreads();
-        if (kg < 2) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) ua[0][i] = *reinterpret_cast<const uint4*>(Up + (wm * TM + i * 16 + l15) * 16 + kg * 8);
+        for (int s = 0; s < RS; ++s) {
+            const int kk = s * 32 + kg * 8;
+            if (kk < RP) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) ua[s][i] = *reinterpret_cast<const uint4*>(Up + (wm * TM + i * 16 + l15) * RP + kk);
+            }
         }
     }
 #pragma unroll
@@ -244,12 +269,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     gemm_epilogue_store<T, BM, BN, NT>(p, Cs, m0, n0, tid);
 }
 
-template <int BM, int BN, int WM, int WN, bool FU = false, int NS = 2>
+template <int BM, int BN, int WM, int WN, int RT = 0, int NS = 2>
 static int glds_launch_cfg(const GP<bf16_t>& p, hipStream_t st) {
-    size_t ring = (size_t)NS * (BM + BN + (FU ? 16 : 0)) * 128 + (FU ? BM * 32 : 0);
+    constexpr bool FU = RT > 0;
+    size_t ring = (size_t)NS * (BM + BN + 16 * RT) * 128 + (size_t)BM * 32 * RT;
     size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
     size_t sm = ring > cs ? ring : cs;
-    auto kern = gemm_glds_kernel<BM, BN, WM, WN, FU, NS>;
+    auto kern = gemm_glds_kernel<BM, BN, WM, WN, RT, NS>;
     static bool attr_set = false;             // per instantiation; a host call per launch is visible in eager mode
     if (sm > 48 * 1024 && !attr_set) {
         attr_set = true;
@@ -261,7 +287,8 @@ static int glds_launch_cfg(const GP<bf16_t>& p, hipStream_t st) {
     }
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, p);
-    cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d>%s", BM, BN, WM, WN, NS, FU ? ",fusedU" : "");
+    if (FU) cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d>,fusedU%d", BM, BN, WM, WN, NS, 16 * RT);
+    else cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d>", BM, BN, WM, WN, NS);
     CVFT_LAUNCH_CHECK("cvft_gemm");
     return 0;
 }
@@ -284,23 +311,33 @@ int gemm_glds_launch(const GP<bf16_t>& p, hipStream_t st, int /*cfg*/) {
         else ns = blocks <= 512 ? 4 : (blocks <= 768 ? 3 : 2);
     }
     if (ns_env) ns = ns_env;
-    if (p.fuse) {     // gemm_launch has already checked the La / Bl alignment; R <= 16 by the ABI contract
-        if (p.R < 1 || p.R > 16 || p.Tm != p.M || p.out_stride != 1 || p.out_off != 0) return 1;
-        if (big) {
-            if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, true, 3>(p, st);
-            return glds_launch_cfg<128, 64, 4, 2, true, 2>(p, st);
+    if (p.fuse) {     // gemm_launch has already checked the La / Bl alignment
+        if (p.R < 1 || p.R > 48 || p.Tm != p.M || p.out_stride != 1 || p.out_off != 0) return 1;
+        if (p.R > 16) {                                          // stacked q|k|v adapters: three rank tiles
+            if (p.R % 8 != 0) return 1;
+            if (big) {
+                if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, 3, 3>(p, st);
+                return glds_launch_cfg<128, 64, 4, 2, 3, 2>(p, st);
+            }
+            if (ns >= 4) return glds_launch_cfg<64, 64, 2, 2, 3, 4>(p, st);
+            if (ns == 3) return glds_launch_cfg<64, 64, 2, 2, 3, 3>(p, st);
+            return glds_launch_cfg<64, 64, 2, 2, 3, 2>(p, st);
         }
-        if (ns >= 4) return glds_launch_cfg<64, 64, 2, 2, true, 4>(p, st);
-        if (ns == 3) return glds_launch_cfg<64, 64, 2, 2, true, 3>(p, st);
-        return glds_launch_cfg<64, 64, 2, 2, true, 2>(p, st);
+        if (big) {
+            if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, 1, 3>(p, st);
+            return glds_launch_cfg<128, 64, 4, 2, 1, 2>(p, st);
+        }
+        if (ns >= 4) return glds_launch_cfg<64, 64, 2, 2, 1, 4>(p, st);
+        if (ns == 3) return glds_launch_cfg<64, 64, 2, 2, 1, 3>(p, st);
+        return glds_launch_cfg<64, 64, 2, 2, 1, 2>(p, st);
     }
     if (p.R > 0 && (p.R % 8 != 0 || p.R > 64 || !p.vecU || !p.vecB)) return 1;
     // measured on MI355X (tools/sweep_gemm.py): 128x64 x 8 waves once there are >= 4 64x64 tiles per CU, else 64x64
     if (big) {
-        if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, false, 3>(p, st);
-        return glds_launch_cfg<128, 64, 4, 2, false, 2>(p, st);
+        if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, 0, 3>(p, st);
+        return glds_launch_cfg<128, 64, 4, 2, 0, 2>(p, st);
     }
-    if (ns >= 4) return glds_launch_cfg<64, 64, 2, 2, false, 4>(p, st);
-    if (ns == 3) return glds_launch_cfg<64, 64, 2, 2, false, 3>(p, st);
-    return glds_launch_cfg<64, 64, 2, 2, false, 2>(p, st);
+    if (ns >= 4) return glds_launch_cfg<64, 64, 2, 2, 0, 4>(p, st);
+    if (ns == 3) return glds_launch_cfg<64, 64, 2, 2, 0, 3>(p, st);
+    return glds_launch_cfg<64, 64, 2, 2, 0, 2>(p, st);
 }

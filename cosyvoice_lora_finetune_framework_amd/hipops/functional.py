@@ -504,8 +504,12 @@ class LinearQKVStackedFn(torch.autograd.Function):
     def forward(ctx, x, Aq, Bq, Ak, Bk, Av, Bv, wstack: QKVStack, ops, scale: float):
         x = _c(x)
         A, At, Bb, Bbt = ops
-        U = gemm(x, A, alpha=scale)                                     # [M, 3r]
-        Y = gemm(x, wstack.Wf, bias=wstack.bias, U=U, Bl=Bb)           # [M, 3N]
+        if QKV_FUSE_SIDE and x.shape[1] % 64 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
+            U = torch.empty((x.shape[0], A.shape[0]), dtype=x.dtype, device=x.device)     # [M, 3r], written by the launch
+            Y = gemm(x, wstack.Wf, bias=wstack.bias, La=A, lora_scale=scale, Uout=U, Bl=Bb)
+        else:
+            U = gemm(x, A, alpha=scale)
+            Y = gemm(x, wstack.Wf, bias=wstack.bias, U=U, Bl=Bb)       # [M, 3N]
         ctx.w, ctx.ops, ctx.scale, ctx.refs = wstack, ops, scale, ((Aq, Bq), (Ak, Bk), (Av, Bv))
         ctx.save_for_backward(x, U)
         N = wstack.N
@@ -522,8 +526,13 @@ class LinearQKVStackedFn(torch.autograd.Function):
             dY = torch.as_strided(dq, (M, 3 * N), (3 * N, 1), dq.storage_offset())     # the attention backward's fused buffer
         else:
             dY = torch.cat([dq, dk, dv], 1)
-        V = gemm(dY, Bbt, alpha=scale)                                  # [M, 3r] = s * dY B_blk
-        dx = gemm(dY, w.Wb, U=V, Bl=At) if ctx.needs_input_grad[0] else None
+        if (QKV_FUSE_SIDE and ctx.needs_input_grad[0] and dY.shape[1] % 64 == 0 and dY.stride(0) % 8 == 0
+                and dY.data_ptr() % 16 == 0):
+            V = torch.empty((M, Bbt.shape[0]), dtype=dY.dtype, device=dY.device)
+            dx = gemm(dY, w.Wb, La=Bbt, lora_scale=scale, Uout=V, Bl=At)   # V = s * dY B_blk produced by the same launch
+        else:
+            V = gemm(dY, Bbt, alpha=scale)                              # [M, 3r] = s * dY B_blk
+            dx = gemm(dY, w.Wb, U=V, Bl=At) if ctx.needs_input_grad[0] else None
         r3 = V.shape[1]
         r = r3 // 3
         sink = LoraGradSink.active
@@ -591,6 +600,9 @@ def lora_linear(x, pack: LinearPack, A=None, B=None, scale: float = 1.0, act: Op
 
 _QKV_STACKS = {}
 QKV_STACKING = _os.environ.get("CVFT_QKV_STACK", "1") != "0"
+# rank-48 side products inside the main launches: measured slower than the dedicated skinny kernel (39.7 vs 39.0 ms/step:
+# the extra MFMAs land on half of the block's waves), kept selectable
+QKV_FUSE_SIDE = _os.environ.get("CVFT_QKV_FUSE", "0") != "0"
 
 
 def _qkv_stacked_operands(x, packs, loras, scales):

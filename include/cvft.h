@@ -76,7 +76,7 @@ typedef struct {
     const void* dact_src; int ldd; int dact;   /* or NULL */
     const void* residual; int ldr;       /* or NULL */
     void* C; int ldc;
-    /* fused side path (optional; R <= 16, identity row geometry, 16-byte aligned operands): when La != NULL the
+    /* fused side path (optional; R <= 16 -- bf16 with K % 64 == 0: R <= 48 --, identity row geometry, 16-byte aligned operands): when La != NULL the
      * launch itself computes  Uf = lora_scale * A . La^T  (La [R][ldla]) from the A tiles it streams anyway, uses it
      * in place of U for the rank-R extension, and writes it to Uout [M][ldu] (may be NULL).  `U` is ignored. */
     const void* La; int ldla; float lora_scale; void* Uout;

@@ -453,7 +453,8 @@ def test_gemm_fused_lora_side_path(dtype, M, N, K, r):
     assert rel(y, ref) < TOL[dtype]
 
 
-def test_qkv_stacked_matches_separate_projections():
+@pytest.mark.parametrize("fuse_side", [False, True])
+def test_qkv_stacked_matches_separate_projections(fuse_side):
     """bf16 training path: q|k|v as one stacked projection (block-diagonal LoRA-B, rank 48 slab kernels, sub-block
     reduce tasks) must give the same outputs, input gradient and six adapter gradients as three LoRALinear modules."""
     from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
@@ -473,6 +474,7 @@ def test_qkv_stacked_matches_separate_projections():
 
     def run(stack: bool):
         HF.QKV_STACKING = stack
+        HF.QKV_FUSE_SIDE = fuse_side
         opt.zero_grad()
         x.grad = None
         with HF.LoraGradSink():
@@ -485,6 +487,7 @@ def test_qkv_stacked_matches_separate_projections():
         b = run(False)
     finally:
         HF.QKV_STACKING = True
+        HF.QKV_FUSE_SIDE = False
     names = ["q", "k", "v", "dx"] + [f"g{i}" for i in range(6)]
     for n, u, w in zip(names, a, b):
         assert rel(u, w) < 2e-2, (n, rel(u, w))
