@@ -34,6 +34,7 @@ struct GP {
     // fused side path: U = lora_scale * A_tile . La^T is computed inside this launch (La [R][K], R <= 16),
     // fed to the rank-R extension step and written to Uout [M][ldu] by the n-tile-0 blocks
     const T* La; int ldla; unsigned bytesL; float lora_scale; T* Uout; int fuse;
+    int direct_epi;               // LDS-DMA kernels: register epilogue allowed (set by gemm_glds_launch)
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -111,6 +112,48 @@ __device__ __forceinline__ void gemm_epilogue_store(const GP<T>& p, const float*
             }
         }
     }
+}
+
+// Register epilogue for kernels whose accumulators hold 4 CONSECUTIVE output columns per lane (MFMA issued with the
+// operands swapped: lane (kg, l15) owns C[m = l15][n = 4*kg .. 4*kg+3] of a 16x16 tile): the whole
+// bias/act/act'/residual/mask chain runs on that 4-vector and every global access is one 8-byte (bf16) access -- no
+// fp32 staging tile in LDS, no barriers.  Caller guarantees m < M, n + 3 < N and 8-byte alignment of all row pitches.
+__device__ __forceinline__ void gemm_epilogue_direct4(const GP<bf16_t>& p, const f32x4& a, int m, int n) {
+    int b = 0, to = m;
+    if (!((p.Tm == p.M) && p.out_stride == 1 && p.out_off == 0)) {
+        b = m / p.Tm;
+        to = (m - b * p.Tm) * p.out_stride + p.out_off;
+        if (to >= p.Tout) return;
+    }
+    const size_t orow = (size_t)b * p.Tout + to;
+    const bool live = p.out_len ? (to < p.out_len[b]) : true;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = a[e] * p.alpha;
+    if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    if (p.preact) {
+        bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(&p.preact[orow * p.ldp + n]) = t;
+    }
+    if (p.act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(p.act, v[e]);
+    }
+    if (p.dact_src) {
+        const bf16x4 d = *reinterpret_cast<const bf16x4*>(&p.dact_src[orow * p.ldd + n]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= act_grad(p.dact, (float)d[e]);
+    }
+    if (p.residual) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(&p.residual[orow * p.ldr + n]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+    }
+    bf16x4 o = {(bf16_t)(live ? v[0] : 0.f), (bf16_t)(live ? v[1] : 0.f), (bf16_t)(live ? v[2] : 0.f), (bf16_t)(live ? v[3] : 0.f)};
+    *reinterpret_cast<bf16x4*>(&p.C[orow * p.ldc + n]) = o;
 }
 
 // LDS-DMA (global_load_lds) bf16 kernels for identity-geometry GEMMs; returns 1 when the shape is not eligible.

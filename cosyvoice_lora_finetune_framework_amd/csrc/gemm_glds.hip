@@ -24,9 +24,18 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // NS = LDS stages: tiles kt+1 .. kt+NS-1 are in flight while tile kt feeds the MFMAs (counted s_waitcnt vmcnt, raw
 // s_barrier -- __syncthreads() would drain the DMA queue).  These GEMMs are small (1-4 blocks per CU, 4-16 k-tiles):
 // with one tile of lookahead every k-tile cost a full memory round trip (~0.9 us measured in the training step).
+// register epilogue (gemm_epilogue_direct4) is legal: 8-byte aligned bf16 rows everywhere, 16-byte aligned bias
+__host__ __device__ inline bool glds_direct_epilogue(const GP<bf16_t>& p) {
+    return p.direct_epi && (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 7) == 0) &&
+           (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
+           (!p.preact || ((p.ldp % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.preact) & 7) == 0))) &&
+           (!p.dact_src || ((p.ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.dact_src) & 7) == 0))) &&
+           (!p.residual || ((p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 7) == 0)));
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int RT, int NS>
+template <int BM, int BN, int WM, int WN, int RT, int NS, bool DE>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     typedef bf16_t T;
     constexpr int NW = WM * WN, NT = NW * 64, BK = 64;
@@ -173,9 +182,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Wb + j * 2048 + rd);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) Mma<T>::mma(acc[i][j], a[i], b[j]);
+                for (int i = 0; i < MI; ++i) Mma<T>::mma(acc[i][j], b[j], a[i]);     // swapped: lane owns 4 consecutive n
             if (FU && wn == 0) {                                  // wave-uniform
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
@@ -254,28 +263,42 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) Mma<T>::mma(acc[i][j], fa[i], fb[j]);
+                for (int j = 0; j < NI; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
         }
 
-    __syncthreads();                                            // operand ring is dead: reuse it for the fp32 tile
+    // acc[i][j][r] = C[m0 + wm*TM + i*16 + l15][n0 + wn*TN + j*16 + 4*kg + r]
+    // DE (register epilogue) is a separate instantiation: with both epilogues in one kernel the LDS path lost ~6 %
+    // (accumulators left the AGPRs, twice the code)
+    if constexpr (DE) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * TM + i * 16 + l15;
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * TN + j * 16 + 4 * kg;
+                if (m < p.M && n < p.N) gemm_epilogue_direct4(p, acc[i][j], m, n);
+            }
+        }
+    } else {
+        __syncthreads();                                        // operand ring is dead: reuse it for the fp32 tile
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Cs[(wm * TM + i * 16 + (lane >> 4) * 4 + r) * CLD + wn * TN + j * 16 + (lane & 15)] = acc[i][j][r];
-    __syncthreads();
-    gemm_epilogue_store<T, BM, BN, NT>(p, Cs, m0, n0, tid);
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)    // one ds_write_b128 per tile: rows 272 B apart -> 16 lanes hit 16 distinct 16-byte slots
+                *reinterpret_cast<float4*>(&Cs[(wm * TM + i * 16 + l15) * CLD + wn * TN + j * 16 + 4 * kg]) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        __syncthreads();
+        gemm_epilogue_store<T, BM, BN, NT>(p, Cs, m0, n0, tid);
+    }
 }
 
-template <int BM, int BN, int WM, int WN, int RT = 0, int NS = 2>
-static int glds_launch_cfg(const GP<bf16_t>& p, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int RT, int NS, bool DE>
+static int glds_launch_de(const GP<bf16_t>& p, hipStream_t st) {
     constexpr bool FU = RT > 0;
     size_t ring = (size_t)NS * (BM + BN + 16 * RT) * 128 + (size_t)BM * 32 * RT;
-    size_t cs = (size_t)BM * (BN + 4) * sizeof(float);
+    size_t cs = DE ? 0 : (size_t)BM * (BN + 4) * sizeof(float);        // fp32 staging tile only for the LDS epilogue
     size_t sm = ring > cs ? ring : cs;
-    auto kern = gemm_glds_kernel<BM, BN, WM, WN, RT, NS>;
+    auto kern = gemm_glds_kernel<BM, BN, WM, WN, RT, NS, DE>;
     static bool attr_set = false;             // per instantiation; a host call per launch is visible in eager mode
     if (sm > 48 * 1024 && !attr_set) {
         attr_set = true;
@@ -287,14 +310,24 @@ static int glds_launch_cfg(const GP<bf16_t>& p, hipStream_t st) {
     }
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, p);
-    if (FU) cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d>,fusedU%d", BM, BN, WM, WN, NS, 16 * RT);
-    else cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d>", BM, BN, WM, WN, NS);
+    if (FU) cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d,%s>,fusedU%d", BM, BN, WM, WN, NS, DE ? "regepi" : "ldsepi", 16 * RT);
+    else cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d,%s>", BM, BN, WM, WN, NS, DE ? "regepi" : "ldsepi");
     CVFT_LAUNCH_CHECK("cvft_gemm");
     return 0;
 }
 
+template <int BM, int BN, int WM, int WN, int RT = 0, int NS = 2>
+static int glds_launch_cfg(const GP<bf16_t>& p, hipStream_t st) {
+    if (glds_direct_epilogue(p)) return glds_launch_de<BM, BN, WM, WN, RT, NS, true>(p, st);
+    return glds_launch_de<BM, BN, WM, WN, RT, NS, false>(p, st);
+}
+
 // Returns 1 when the launch is not eligible (the caller falls back to gemm.hip's register-staged kernel).
-int gemm_glds_launch(const GP<bf16_t>& p, hipStream_t st, int /*cfg*/) {
+int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
+    static const int direct_mode = getenv("CVFT_GLDS_DIRECT") ? atoi(getenv("CVFT_GLDS_DIRECT")) : 2;   // 0 off, 1 only plain epilogues, 2 whenever legal
+    GP<bf16_t> p = p_in;
+    const bool simple = !p.preact && !p.dact_src && !p.residual;
+    p.direct_epi = direct_mode == 2 || (direct_mode == 1 && simple);
     const bool ident = p.ntaps == 1 && p.tap_off[0] == 0 && p.in_stride == 1 && p.Tin == p.Tm && !p.in_len;
     if (!ident || p.K % 64 != 0 || !p.vecA || !p.vecW || p.N <= 32) return 1;
     const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
