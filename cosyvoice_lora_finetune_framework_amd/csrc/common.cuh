@@ -124,6 +124,27 @@ __device__ __forceinline__ float act_grad(int act, float x) {
     }
 }
 
+// vector forms with the activation switch OUTSIDE the element loop (one branch per vector, not per element: the
+// per-element form unrolled 8x inside the GEMM epilogues was most of those kernels' code size)
+template <int N> __device__ __forceinline__ void act_apply_vec(int act, float (&v)[N]) {
+    switch (act) {
+#define CVFT_ACT_CASE(A) case A: _Pragma("unroll") for (int e = 0; e < N; ++e) v[e] = act_apply(A, v[e]); break;
+        CVFT_ACT_CASE(CVFT_ACT_RELU) CVFT_ACT_CASE(CVFT_ACT_SILU) CVFT_ACT_CASE(CVFT_ACT_GELU_ERF)
+        CVFT_ACT_CASE(CVFT_ACT_GELU_TANH) CVFT_ACT_CASE(CVFT_ACT_MISH)
+#undef CVFT_ACT_CASE
+        default: break;
+    }
+}
+template <int N> __device__ __forceinline__ void act_grad_mul_vec(int act, float (&v)[N], const float (&src)[N]) {
+    switch (act) {
+#define CVFT_ACT_CASE(A) case A: _Pragma("unroll") for (int e = 0; e < N; ++e) v[e] *= act_grad(A, src[e]); break;
+        CVFT_ACT_CASE(CVFT_ACT_RELU) CVFT_ACT_CASE(CVFT_ACT_SILU) CVFT_ACT_CASE(CVFT_ACT_GELU_ERF)
+        CVFT_ACT_CASE(CVFT_ACT_GELU_TANH) CVFT_ACT_CASE(CVFT_ACT_MISH)
+#undef CVFT_ACT_CASE
+        default: break;
+    }
+}
+
 // ---------------------------------------------------------------- reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -80,13 +80,14 @@ __device__ __forceinline__ void gemm_epilogue_store(const GP<T>& p, const float*
                 for (int e = 0; e < VEC; ++e) tmp[e] = from_f32<T>(v[e]);
                 *reinterpret_cast<uint4*>(&p.preact[orow * p.ldp + nb]) = *reinterpret_cast<uint4*>(tmp);
             }
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] = act_apply(p.act, v[e]);
+            act_apply_vec<VEC>(p.act, v);
             if (p.dact_src) {
                 uint4 dv = *reinterpret_cast<const uint4*>(&p.dact_src[orow * p.ldd + nb]);
                 const T* de = reinterpret_cast<const T*>(&dv);
+                float ds[VEC];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] *= act_grad(p.dact, to_f32(de[e]));
+                for (int e = 0; e < VEC; ++e) ds[e] = to_f32(de[e]);
+                act_grad_mul_vec<VEC>(p.dact, v, ds);
             }
             if (p.residual) {
                 uint4 rv = *reinterpret_cast<const uint4*>(&p.residual[orow * p.ldr + nb]);
@@ -138,14 +139,11 @@ __device__ __forceinline__ void gemm_epilogue_direct4(const GP<bf16_t>& p, const
         bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
         *reinterpret_cast<bf16x4*>(&p.preact[orow * p.ldp + n]) = t;
     }
-    if (p.act) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(p.act, v[e]);
-    }
+    act_apply_vec<4>(p.act, v);
     if (p.dact_src) {
         const bf16x4 d = *reinterpret_cast<const bf16x4*>(&p.dact_src[orow * p.ldd + n]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= act_grad(p.dact, (float)d[e]);
+        float ds[4] = {(float)d[0], (float)d[1], (float)d[2], (float)d[3]};
+        act_grad_mul_vec<4>(p.dact, v, ds);
     }
     if (p.residual) {
         const bf16x4 r = *reinterpret_cast<const bf16x4*>(&p.residual[orow * p.ldr + n]);
