@@ -173,24 +173,30 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* Ab = smem + buf * BUF + (wm * TM) * 128;
         const unsigned char* Wb = smem + buf * BUF + A_BYTES + (wn * TN) * 128;
+        // all fragment reads of the k-tile are issued before its first MFMA: the second k-step's reads complete under
+        // the first k-step's MFMAs (hipcc places the partial lgkmcnt waits)
+        bf16x8 a[2][MI], b[2][NI];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int rd = ks ? rd1 : rd0;
-            bf16x8 a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 2048 + rd);
+            for (int i = 0; i < MI; ++i) a[ks][i] = *reinterpret_cast<const bf16x8*>(Ab + i * 2048 + rd);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Wb + j * 2048 + rd);
+            for (int j = 0; j < NI; ++j) b[ks][j] = *reinterpret_cast<const bf16x8*>(Wb + j * 2048 + rd);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rd = ks ? rd1 : rd0;
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) Mma<T>::mma(acc[i][j], b[j], a[i]);     // swapped: lane owns 4 consecutive n
+                for (int i = 0; i < MI; ++i) Mma<T>::mma(acc[i][j], b[ks][j], a[ks][i]);     // swapped: lane owns 4 consecutive n
             if (FU && wn == 0) {                                  // wave-uniform
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
                     const bf16x8 la = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + A_BYTES + W_BYTES + t * 2048 + rd);
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) Mma<T>::mma(uacc[i][t], a[i], la);
+                    for (int i = 0; i < MI; ++i) Mma<T>::mma(uacc[i][t], a[ks][i], la);
                 }
             }
         }
@@ -366,6 +372,18 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     }
     if (p.R > 0 && (p.R % 8 != 0 || p.R > 64 || !p.vecU || !p.vecB)) return 1;
     // measured on MI355X (tools/sweep_gemm.py): 128x64 x 8 waves once there are >= 4 64x64 tiles per CU, else 64x64
+    static const int big_env = getenv("CVFT_GLDS_BIG") ? atoi(getenv("CVFT_GLDS_BIG")) : 0;     // experiment hook
+    if (big && big_env && nk >= 8 && t64 >= 2048) {
+        switch (big_env) {
+            case 1: return glds_launch_cfg<128, 128, 2, 2, 0, 3>(p, st);
+            case 2: return glds_launch_cfg<128, 128, 2, 2, 0, 4>(p, st);
+            case 3: return glds_launch_cfg<128, 128, 2, 4, 0, 3>(p, st);
+            case 4: return glds_launch_cfg<256, 128, 4, 2, 0, 2>(p, st);
+            case 5: return glds_launch_cfg<256, 128, 4, 2, 0, 3>(p, st);
+            case 6: return glds_launch_cfg<128, 128, 2, 2, 0, 2>(p, st);
+            default: break;
+        }
+    }
     if (big) {
         if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, 0, 3>(p, st);
         return glds_launch_cfg<128, 64, 4, 2, 0, 2>(p, st);
