@@ -112,6 +112,21 @@ def cpu_baseline(jm, workload, T, seconds_budget=30.0):
                       f"(oracle/ref_math.py), same random-init weights; optimiser step excluded (negligible)"}
 
 
+def pmc_traffic(kernel: str):
+    """HBM-side bytes per launch of `kernel` from the committed PMC run of this same command (rocprofv3 --pmc cannot
+    run inside the bench process): profiles/*pmc_traffic.json, written by tools/pmc_traffic.py.  None when the file's
+    kernel is not the one that dominates this run."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel") == kernel:
+            return d["traffic_bytes_per_launch"], os.path.join("profiles", os.path.basename(f))
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,17 +223,20 @@ def main():
         torch.cuda.synchronize()
         groups = {}
         for rec in HF.PROFILE:
-            g = groups.setdefault(rec["kernel"], {"ms": 0.0, "flop": 0.0, "n": 0})
+            g = groups.setdefault(rec["kernel"], {"ms": 0.0, "flop": 0.0, "n": 0, "bytes": 0.0})
             g["ms"] += rec["start"].elapsed_time(rec["end"])
             g["flop"] += rec["flop"]
+            g["bytes"] += rec.get("bytes", 0.0)
             g["n"] += 1
         HF.PROFILE = None
         if groups:
             name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
             peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = g["flop"] / (g["ms"] * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(name)
             roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    "frac": ach / peak, "traffic": None, "launches_per_step": g["n"],
+                    "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                    "alg_bytes_per_launch": g["bytes"] / g["n"], "launches_per_step": g["n"],
                     "avg_launch_us": g["ms"] * 1e3 / g["n"], "alg_gflop_per_launch": g["flop"] / g["n"] / 1e9,
                     "all_gemm_kernels": {k: {"ms": v["ms"], "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12, "n": v["n"]}
                                          for k, v in groups.items()}}

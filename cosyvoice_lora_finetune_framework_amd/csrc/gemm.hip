@@ -349,7 +349,7 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
     p.bias = a->bias; p.alpha = a->alpha; p.act = a->act;
     p.preact = (T*)a->preact; p.ldp = a->ldp; p.dact_src = (const T*)a->dact_src; p.ldd = a->ldd; p.dact = a->dact;
     p.residual = (const T*)a->residual; p.ldr = a->ldr; p.C = (T*)a->C; p.ldc = a->ldc;
-    p.La = (const T*)a->La; p.ldla = a->ldla; p.lora_scale = a->lora_scale; p.Uout = (T*)a->Uout; p.fuse = a->La != nullptr; p.direct_epi = 0;
+    p.La = (const T*)a->La; p.ldla = a->ldla; p.lora_scale = a->lora_scale; p.Uout = (T*)a->Uout; p.fuse = a->La != nullptr; p.direct_epi = 0; p.xcd_nsplit = 1;
     p.bytesL = 0;
     if (p.fuse) { p.R = a->R; p.U = nullptr; }
     p.vecA = (a->K % VEC == 0) && (a->lda % VEC == 0) && al16<T>(a->A);

@@ -35,6 +35,7 @@ struct GP {
     // fed to the rank-R extension step and written to Uout [M][ldu] by the n-tile-0 blocks
     const T* La; int ldla; unsigned bytesL; float lora_scale; T* Uout; int fuse;
     int direct_epi;               // LDS-DMA kernels: register epilogue allowed (set by gemm_glds_launch)
+    int xcd_nsplit;               // LDS-DMA kernels: XCDs across N (1 = linear tile ranges; 2/4/8 = rectangles, see kernel)
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;

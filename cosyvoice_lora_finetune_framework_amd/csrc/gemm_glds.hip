@@ -62,12 +62,29 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     const int wm = wid / WN, wn = wid % WN;
     const int tiles_n = (p.N + BN - 1) / BN;
     int bid = blockIdx.x;
-    {   // XCD-aware bijective remap (see gemm.hip)
+    int m0, n0;
+    if (p.xcd_nsplit > 1) {
+        // Wide-N launches (W larger than an XCD's 4 MB L2): with linear tile ranges every XCD streams ALL of W once per
+        // row panel (PMC: 325 MB of L2 misses for 19 MB of operands at 5328x4096x1024).  Give each XCD a rectangle --
+        // xcd_nsplit column groups x 8/xcd_nsplit row groups -- so its W slice stays L2-resident while it walks its
+        // row panels (m slow, n fast).  Workgroups are dealt round-robin to the XCDs (id & 7); the grid is padded to
+        // 8 x the largest rectangle and surplus blocks leave before any barrier.
+        const int tiles_m = (p.M + BM - 1) / BM;
+        const int cx = p.xcd_nsplit, cy = 8 / cx;
+        const int xcd = bid & 7, loc = bid >> 3;
+        const int tn_per = (tiles_n + cx - 1) / cx, tm_per = (tiles_m + cy - 1) / cy;
+        const int tn0 = (xcd % cx) * tn_per, tm0 = (xcd / cx) * tm_per;
+        const int rn = min(tn_per, tiles_n - tn0), rmm = min(tm_per, tiles_m - tm0);
+        if (rn <= 0 || rmm <= 0 || loc >= rn * rmm) return;
+        m0 = (tm0 + loc / rn) * BM;
+        n0 = (tn0 + loc % rn) * BN;
+    } else {
+        // XCD-aware bijective remap (see gemm.hip): contiguous tile ranges per XCD, n fastest
         const int nwg = gridDim.x, q = nwg >> 3, rm = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+        m0 = (bid / tiles_n) * BM;
+        n0 = (bid % tiles_n) * BN;
     }
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
 
     // DMA sources: lane -> (row piece*8 + lane/8, slot lane%8); rows past the edge are clamped (their outputs are
     // never stored), the chunk is XOR-ed so the LDS image comes out swizzled
@@ -314,8 +331,26 @@ static int glds_launch_de(const GP<bf16_t>& p, hipStream_t st) {
             return -2;
         }
     }
-    long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, p);
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    long tiles = (long)tiles_m * tiles_n;
+    GP<bf16_t> q = p;
+    q.xcd_nsplit = 1;
+    {   // rectangle mapping when W does not fit an XCD's L2 and the split balances (see kernel)
+        static const int rect_on = getenv("CVFT_GLDS_RECT") ? atoi(getenv("CVFT_GLDS_RECT")) : 1;
+        const size_t wbytes = (size_t)p.N * p.K * 2;
+        if (rect_on && wbytes > (size_t)3 << 20) {
+            int cx = 2;
+            while (cx < 8 && wbytes / cx > ((size_t)2 << 20) + ((size_t)1 << 18)) cx *= 2;
+            const int cy = 8 / cx;
+            const long tn_per = (tiles_n + cx - 1) / cx, tm_per = (tiles_m + cy - 1) / cy;
+            const long padded = 8 * tn_per * tm_per;
+            if (tiles_m >= cy && padded * 100 <= tiles * 108) {          // <= 8 % idle slots
+                q.xcd_nsplit = cx;
+                tiles = padded;
+            }
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, q);
     if (FU) cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d,%s>,fusedU%d", BM, BN, WM, WN, NS, DE ? "regepi" : "ldsepi", 16 * RT);
     else cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d,%s>", BM, BN, WM, WN, NS, DE ? "regepi" : "ldsepi");
     CVFT_LAUNCH_CHECK("cvft_gemm");

@@ -111,7 +111,10 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
         r_eff = a.R if (U is not None or La is not None) else 0
         PROFILE.append({"kernel": lib().cvft_gemm_last_kernel().decode(),
                         "start": e0, "end": e1, "shape": (a.M, N, K, ntaps, a.R if (U is not None or La is not None) else 0),
-                        "flop": 2.0 * a.M * N * (ntaps * K + r_eff) + (2.0 * a.M * K * a.R if La is not None else 0.0)})
+                        "flop": 2.0 * a.M * N * (ntaps * K + r_eff) + (2.0 * a.M * K * a.R if La is not None else 0.0),
+                        # algorithmic bytes: every operand and result once
+                        "bytes": x.element_size() * (x.shape[0] * K + N * ntaps * K + a.M * N * (1 + (preact is not None) + (dact_src is not None) + (residual is not None))
+                                                     + (a.M + N) * r_eff + (a.R * K if La is not None else 0))})
         return out
     check(lib().cvft_gemm(C.byref(a), stream()), "cvft_gemm")
     return out
