@@ -23,6 +23,10 @@ struct AP {
 };
 
 #define NEG_INF (-__builtin_inff())
+// The per-wave LDS regions (Gw skew buffer, P / dS tiles) are written and read by the SAME wavefront: a wave's LDS
+// operations complete in order, so draining its own LDS queue is enough -- no workgroup barrier (the rel-pos dK/dV
+// kernel had ten s_barrier per tile, two of them real).
+#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // ------------------------------------------------------------------------ forward
 template <typename T, bool REL>
@@ -112,7 +116,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
             for (int nt = 0; nt < 5; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Gw[((lane >> 4) * 4 + r) * LDG + nt * 16 + (lane & 15)] = g[nt][r];
-            __syncthreads();
+            WAVE_LDS_SYNC();
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -159,7 +163,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Pw[((lane >> 4) * 4 + r) * LDK + nt * 16 + (lane & 15)] = from_f32<T>(s[nt][r]);
-        __syncthreads();
+        WAVE_LDS_SYNC();
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             Frag a = FragLd<T, T>::kc(Pw, LDK, 0, ks * MM::K, lane);
@@ -286,7 +290,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
             for (int nt = 0; nt < 5; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Gw[((lane >> 4) * 4 + r) * LDG + nt * 16 + (lane & 15)] = g[nt][r];
-            __syncthreads();
+            WAVE_LDS_SYNC();
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -294,9 +298,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
                     int row = (lane >> 4) * 4 + r;
                     s[nt][r] += Gw[row * LDG + 15 - row + nt * 16 + (lane & 15)];
                 }
-            __syncthreads();
+            WAVE_LDS_SYNC();
             for (int e = lane; e < 16 * KB; e += 64) Gw[(e / KB) * LDG + (e % KB)] = 0.f;
-            __syncthreads();
+            WAVE_LDS_SYNC();
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -319,7 +323,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) {
                 if (REL) Gw[row * LDG + 15 - row + nt * 16 + (lane & 15)] = ds;
             }
         }
-        __syncthreads();
+        WAVE_LDS_SYNC();
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             Frag a = FragLd<T, T>::kc(Dw, LDK, 0, ks * MM::K, lane);
@@ -462,12 +466,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) {
                     g[0] = f32x4{0.f, 0.f, 0.f, 0.f};
                     g[1] = f32x4{0.f, 0.f, 0.f, 0.f};
                     mma_regA_kc<T, 2>(g, av, Pb, LDK, (48 - 16 * mt) + 16 * w, lane);
-                    __syncthreads();   // previous mt's skew reads done
+                    WAVE_LDS_SYNC();   // previous mt's skew reads done
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) Gw[((lane >> 4) * 4 + r) * LDG + nt * 16 + (lane & 15)] = g[nt][r];
-                    __syncthreads();
+                    WAVE_LDS_SYNC();
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         int row = (lane >> 4) * 4 + r;
@@ -494,7 +498,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) {
                     csum += ds;
                 }
             }
-            __syncthreads();
+            WAVE_LDS_SYNC();
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 Frag ap = FragLd<T, T>::kc(Pw, LDK, 0, ks * MM::K, lane);
