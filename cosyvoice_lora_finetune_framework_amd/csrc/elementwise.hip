@@ -478,3 +478,54 @@ extern "C" int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, voi
     CVFT_LAUNCH_CHECK("cvft_cast_f32_to_bf16");
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------
+// Inverted dropout with an optional residual add:  y = residual + keep(x) / (1 - p).
+// (nn.Dropout call sites of the encoders: subsampling.py:84, embedding.py:285-288, encoder_layer.py:95-104 / 205-234,
+//  positionwise_feed_forward.py:54.)  The keep mask is a pure function of (*seed, site, element index) -- SplitMix64
+// finaliser on a 64-bit counter, 4 x 32 random bits per group of 4 elements -- so backward re-derives it instead of
+// storing a mask tensor, and a captured hipGraph gets fresh masks on every replay because *seed lives on the device.
+// Not torch's Philox stream: equality with the reference is statistical (keep rate, scale), as for any RNG change.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long cvft_mix64(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ void dropout_add_kernel(size_t n, const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, float p,
+                                   const long long* __restrict__ seed, unsigned site) {
+    const unsigned long long key = cvft_mix64((unsigned long long)seed[0] ^ ((unsigned long long)site << 32));
+    const unsigned thr = (unsigned)fminf(4294967295.f, p * 4294967296.f);     // keep when u32 >= thr
+    const float scale = 1.f / (1.f - p);
+    const size_t n4 = (n + 3) / 4;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long r0 = cvft_mix64(key + 2 * g), r1 = cvft_mix64(key + 2 * g + 1);
+        const unsigned u[4] = {(unsigned)r0, (unsigned)(r0 >> 32), (unsigned)r1, (unsigned)(r1 >> 32)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const size_t i = 4 * g + e;
+            if (i >= n) break;
+            float v = u[e] >= thr ? to_f32(x[i]) * scale : 0.f;
+            if (res) v += to_f32(res[i]);
+            y[i] = from_f32<T>(v);
+        }
+    }
+}
+extern "C" int cvft_dropout_add(int dtype, int64_t n, const void* x, const void* residual, void* y, float p,
+                                const int64_t* seed, unsigned site, void* stream) {
+    CHECK_DTYPE("cvft_dropout_add", dtype);
+    CVFT_CHECK_ARG(n >= 0 && x && y && seed && p >= 0.f && p < 1.f, "cvft_dropout_add: bad args (0 <= p < 1)");
+    if (n == 0) return 0;
+    const size_t n4 = ((size_t)n + 3) / 4;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((dropout_add_kernel<float>), dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (size_t)n, (const float*)x,
+                           (const float*)residual, (float*)y, p, (const long long*)seed, site);
+    else
+        hipLaunchKernelGGL((dropout_add_kernel<bf16_t>), dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (size_t)n, (const bf16_t*)x,
+                           (const bf16_t*)residual, (bf16_t*)y, p, (const long long*)seed, site);
+    CVFT_LAUNCH_CHECK("cvft_dropout_add");
+    return 0;
+}

@@ -68,6 +68,7 @@ SIGNATURES = {
     "cvft_time_embed": [_i, _i, _i, _p, _p, _f, _p, _p],
     "cvft_act_fwd": [_i, _i64, _i, _p, _p, _p],
     "cvft_act_bwd": [_i, _i64, _i, _p, _p, _p, _p],
+    "cvft_dropout_add": [_i, _i64, _p, _p, _p, _f, _p, C.c_uint, _p],
     "cvft_cfm_prepare": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p],
     "cvft_masked_mse_fwd": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "cvft_masked_mse_bwd": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p],

@@ -140,6 +140,55 @@ def act_bwd(z: torch.Tensor, dy: torch.Tensor, act: str) -> torch.Tensor:
     return dz
 
 
+# ---------------------------------------------------------------------------------
+# dropout (training mode of the encoders)
+# ---------------------------------------------------------------------------------
+_DROPOUT = {"seed": None, "site": 0}
+
+
+def dropout_begin_step() -> None:
+    """Advance the device-side dropout seed (a captured op: every hipGraph replay draws new masks) and restart the
+    call-site numbering.  JointLLMFlowModel.forward calls it once per training forward."""
+    if _DROPOUT["seed"] is None:
+        _DROPOUT["seed"] = torch.full((1,), int(torch.initial_seed()) & 0x7fffffffffff, dtype=torch.int64, device="cuda")
+    _DROPOUT["seed"].add_(1)
+    _DROPOUT["site"] = 0
+
+
+class DropoutAddFn(torch.autograd.Function):
+    """y = residual + dropout(x, p) (inverted dropout; residual optional); the mask is re-derived in backward."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p: float, site: int):
+        x = _c(x)
+        y = torch.empty_like(x)
+        res = None if residual is None else _c(residual)
+        check(lib().cvft_dropout_add(dt(x), x.numel(), ptr(x), ptr(res), ptr(y), float(p), ptr(_DROPOUT["seed"]), site, stream()),
+              "cvft_dropout_add")
+        ctx.p, ctx.site, ctx.has_res = float(p), site, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            check(lib().cvft_dropout_add(dt(dy), dy.numel(), ptr(dy), None, ptr(dx), ctx.p, ptr(_DROPOUT["seed"]), ctx.site, stream()),
+                  "cvft_dropout_add")
+        return dx, (dy if ctx.has_res and ctx.needs_input_grad[1] else None), None, None
+
+
+def dropout_add(x, p: float, residual=None):
+    """residual + dropout(x, p); p == 0 degenerates to a plain add / identity."""
+    if p <= 0.0:
+        return x if residual is None else x + residual
+    if _DROPOUT["seed"] is None:
+        dropout_begin_step()
+    _DROPOUT["site"] += 1
+    return DropoutAddFn.apply(x, residual, p, _DROPOUT["site"])
+
+
 class ActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act: str):

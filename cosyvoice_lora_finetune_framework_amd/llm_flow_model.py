@@ -14,6 +14,7 @@ from .config import JOINT_TRAINING_CONFIG, MEL_MEAN, MEL_STD, PRETRAINED_MODEL_D
 from .flow_model import build_flow_model
 from .llm_model import build_llm_model
 from .lora import apply_lora_to_model
+from .hipops import functional as HF
 from .modules import Numerics
 
 
@@ -39,6 +40,8 @@ class JointLLMFlowModel(nn.Module):
     def forward(self, batch: dict, device, draws: Optional[dict] = None) -> Dict[str, Any]:
         """llm_flow_model.py:77-107.  `draws` (optional) injects the CFM random draws."""
         losses: Dict[str, Any] = {}
+        if self.training:
+            HF.dropout_begin_step()       # new dropout masks per step (device-side seed: also across hipGraph replays)
         if self.training_mode in ('joint', 'llm_only'):
             r = self._forward_llm(batch, device)
             losses['llm_loss'] = r['loss'] * self.llm_loss_weight

@@ -15,6 +15,7 @@ matcha/models/components/{decoder,transformer}.py (vendored); cosyvoice/transfor
 from __future__ import annotations
 
 import math
+import warnings
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -439,6 +440,7 @@ class LinearNoSubsampling(nn.Module):
 
 class RelPositionMultiHeadedAttention(nn.Module):
     """attention.py:200-330 parameters; compute = fused rel-pos flash kernel."""
+    _warned = False
 
     def __init__(self, n_head, n_feat, dropout_rate, key_bias=True):
         super().__init__()
@@ -457,11 +459,17 @@ class RelPositionMultiHeadedAttention(nn.Module):
         nn.init.xavier_uniform_(self.pos_bias_u)
         nn.init.xavier_uniform_(self.pos_bias_v)
 
-    def forward(self, y, residual, pos_emb, B, L, length, causal):
+    def forward(self, y, residual, pos_emb, B, L, length, causal, out_dropout: float = 0.0):
         q, k, v = hip_qkv(self.linear_q, self.linear_k, self.linear_v, y)
         p = hip_linear(self.linear_pos, pos_emb)
+        if self.training and self.dropout_rate > 0 and not RelPositionMultiHeadedAttention._warned:
+            RelPositionMultiHeadedAttention._warned = True
+            warnings.warn("attention-probability dropout (attention.py:118, rate %.2f) is not applied by the fused attention "
+                          "kernel; all other encoder dropouts are" % self.dropout_rate)
         o = HF.attn_relpos(q, k, v, p, _f32(self.pos_bias_u), _f32(self.pos_bias_v), B, self.h, L, length, causal,
                            1.0 / math.sqrt(self.d_k))
+        if out_dropout > 0:       # x = residual + dropout(linear_out(.))  (encoder_layer.py:95 / 205)
+            return HF.dropout_add(hip_linear(self.linear_out, o), out_dropout, residual)
         return hip_linear(self.linear_out, o, residual=residual)
 
 
@@ -470,9 +478,14 @@ class PositionwiseFeedForward(nn.Module):
         super().__init__()
         self.w_1 = nn.Linear(idim, hidden_units)
         self.activation = activation          # "relu" | "silu"
+        self.dropout_rate = dropout_rate
         self.w_2 = nn.Linear(hidden_units, idim)
 
-    def forward(self, y, residual):
+    def forward(self, y, residual, out_dropout: float = 0.0):
+        if self.training and (self.dropout_rate > 0 or out_dropout > 0):
+            # w_2(dropout(act(w_1 x)))  (positionwise_feed_forward.py:54), then residual + dropout(.) (encoder_layer.py:104 / 234)
+            h = HF.dropout_add(hip_linear(self.w_1, y, act=self.activation), self.dropout_rate)
+            return HF.dropout_add(hip_linear(self.w_2, h), out_dropout, residual)
         return hip_ffn(self.w_1, self.w_2, y, self.activation, residual=residual)
 
 
@@ -480,11 +493,12 @@ class EncoderLayer(nn.Module):
     """TransformerEncoderLayer (encoder_layer.py:27-106: norm1/norm2) or ConformerEncoderLayer without
     macaron / cnn module (encoder_layer.py:109-236: norm_mha/norm_ff), pre-norm."""
 
-    def __init__(self, size, self_attn, feed_forward, conformer: bool, eps: float):
+    def __init__(self, size, self_attn, feed_forward, conformer: bool, eps: float, dropout_rate: float = 0.0):
         super().__init__()
         self.self_attn = self_attn
         self.feed_forward = feed_forward
         self.conformer = conformer
+        self.dropout_rate = dropout_rate
         if conformer:
             self.norm_ff = nn.LayerNorm(size, eps=eps)
             self.norm_mha = nn.LayerNorm(size, eps=eps)
@@ -494,10 +508,11 @@ class EncoderLayer(nn.Module):
 
     def forward(self, x, pos_emb, B, L, length, causal, eps):
         n_att, n_ff = (self.norm_mha, self.norm_ff) if self.conformer else (self.norm1, self.norm2)
+        pd = self.dropout_rate if self.training else 0.0
         x, y = hip_layernorm_fork(n_att, x, eps)
-        x = self.self_attn(y, x, pos_emb, B, L, length, causal)
+        x = self.self_attn(y, x, pos_emb, B, L, length, causal, out_dropout=pd)
         x, y = hip_layernorm_fork(n_ff, x, eps)
-        return self.feed_forward(y, x)
+        return self.feed_forward(y, x, out_dropout=pd)
 
 
 class RelPosEncoder(nn.Module):
@@ -521,7 +536,7 @@ class RelPosEncoder(nn.Module):
             EncoderLayer(output_size,
                          RelPositionMultiHeadedAttention(attention_heads, output_size, attention_dropout_rate, key_bias),
                          PositionwiseFeedForward(output_size, linear_units, dropout_rate, act),
-                         conformer=(kind == "conformer"), eps=ln_eps)
+                         conformer=(kind == "conformer"), eps=ln_eps, dropout_rate=dropout_rate)
             for _ in range(num_blocks)])
 
     def output_size(self) -> int:
@@ -534,6 +549,12 @@ class RelPosEncoder(nn.Module):
         x = hip_linear(self.embed.out[0], xs, dtype=num.dtype)
         x = hip_layernorm(self.embed.out[1], x, relu=self.embed.legacy, post_scale=math.sqrt(d) if num.xscale else 1.0)
         pos_emb = self.embed.pos_enc.table(L, x.device, num.dtype)
+        if self.training:
+            # Dropout after the input LayerNorm (subsampling.py:84) and the two of the positional encoding
+            # (embedding.py:285-288: on x*sqrt(d) and on pos_emb); ReLU / the sqrt(d) scale commute with the masks
+            x = HF.dropout_add(x, self.embed.out[2].p)
+            x = HF.dropout_add(x, self.embed.pos_enc.dropout_rate)
+            pos_emb = HF.dropout_add(pos_emb, self.embed.pos_enc.dropout_rate)
         for layer in self.encoders:
             x = layer(x, pos_emb, B, L, length, causal, num.enc_ln_eps)
         return hip_layernorm(self.after_norm, x)

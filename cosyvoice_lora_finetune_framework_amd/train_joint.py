@@ -121,8 +121,9 @@ class Trainer:
 
     def __init__(self, max_epochs: int = 100, accumulate_grad_batches: int = 1, gradient_clip_val: float = 1.0,
                  callbacks: Optional[list] = None, default_root_dir: str = OUTPUT_DIR, log_every_n_steps: int = 10,
-                 draws_fn=None, save_checkpoints: bool = True):
+                 draws_fn=None, save_checkpoints: bool = True, train_mode: bool = True):
         self.max_epochs, self.accum, self.clip = max_epochs, max(1, accumulate_grad_batches), gradient_clip_val
+        self.train_mode = train_mode       # pl.Trainer.fit puts the module tree in .train() (dropouts active); False keeps the caller's mode
         self.callbacks = callbacks or []
         self.root, self.log_every, self.draws_fn, self.save_ckpt = default_root_dir, log_every_n_steps, draws_fn, save_checkpoints
         self.callback_metrics: Dict[str, float] = {}
@@ -160,6 +161,8 @@ class Trainer:
     # -- fit ------------------------------------------------------------------------------
     def fit(self, module: JointLightningModule, dataloader, ckpt_path: Optional[str] = None):
         module.setup()
+        if self.train_mode:
+            module.model.train()
         dev = module.device
         nb = len(dataloader)
         total_steps = self.max_epochs * math.ceil(nb / self.accum)          # trainer.estimated_stepping_batches

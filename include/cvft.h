@@ -194,6 +194,12 @@ int cvft_time_embed(int dtype, int B, int dim, const float* t, const float* freq
 int cvft_act_fwd(int dtype, int64_t n, int act, const void* x, void* y, void* stream);
 /* dz = dy * act'(z) elementwise */
 int cvft_act_bwd(int dtype, int64_t n, int act, const void* z, const void* dy, void* dz, void* stream);
+/* Inverted dropout (+ optional residual add), nn.Dropout call sites of the encoders (subsampling.py:84,
+ * embedding.py:285-288, encoder_layer.py:95-104 / 205-234, positionwise_feed_forward.py:54):
+ *   y[i] = residual[i] + (keep(i) ? x[i] / (1 - p) : 0),  keep = f(*seed (device int64), site, i) -- counter-based, so the
+ * backward pass calls the same entry point on dy with the same (seed, site) instead of storing a mask. */
+int cvft_dropout_add(int dtype, int64_t n, const void* x, const void* residual, void* y, float p,
+                     const int64_t* seed, unsigned site, void* stream);
 /* CFM prepare (flow_matching.py:173-186 == flow_model.py:143-161), channel-last:
  *   feat raw log-mel [B][T][80] fp32, z [B][T][80] fp32, t_raw [B], cfg_keep [B] (0/1), mu [B][T][80],
  *   spk [B][80], cond (or NULL = zeros)  ->  xin [B][T][320] = [y | mu*keep | spk*keep | cond*keep],  u [B][T][80] (fp32), t [B]. */

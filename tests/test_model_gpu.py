@@ -223,13 +223,13 @@ def test_checkpoint_roundtrip_lightning_layout(tiny_meta, tmp_path):
                                     numerics=num)
     batches = [synth_batch([20 + i], text_lens=[5], token_lens=[9 + i], seed=i, text_vocab=100, speech_vocab=50) for i in range(2)]
     mod = make()
-    tr = Trainer(max_epochs=1, accumulate_grad_batches=1, default_root_dir=str(tmp_path), log_every_n_steps=1)
+    tr = Trainer(max_epochs=1, accumulate_grad_batches=1, default_root_dir=str(tmp_path), log_every_n_steps=1, train_mode=False)
     tr.fit(mod, batches)
     ck = torch.load(str(tmp_path / "joint_joint_last.ckpt"), map_location="cpu")
     assert all(k.startswith("model.llm.") or k.startswith("model.flow.") for k in ck["state_dict"])
     assert ck["global_step"] == 2
     mod2 = make()
-    tr2 = Trainer(max_epochs=1, default_root_dir=str(tmp_path), save_checkpoints=False)
+    tr2 = Trainer(max_epochs=1, default_root_dir=str(tmp_path), save_checkpoints=False, train_mode=False)
     mod2.setup()
     opt2 = mod2.configure_optimizers()
     tr2.load_checkpoint(mod2, opt2, str(tmp_path / "joint_joint_last.ckpt"))

@@ -496,3 +496,54 @@ def test_qkv_stacked_matches_separate_projections(fuse_side):
         W, bb = m.original_layer.weight.float(), m.original_layer.bias.float()
         ref = x.detach().float() @ W.t() + bb + m.scaling * (x.detach().float() @ m.lora_A.t()) @ m.lora_B.t()
         assert rel(a[i], ref) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_add_statistics_and_backward_mask(dtype):
+    """cvft_dropout_add: keep rate ~ 1-p, kept values scaled by 1/(1-p), residual passes through, backward re-derives the
+    SAME mask from (seed, site); a new step (seed + 1) draws a different mask."""
+    HF = HFmod()
+    n, p = 1 << 18, 0.1
+    HF.dropout_begin_step()
+    x = torch.ones(n, device=DEV, dtype=dtype, requires_grad=True)
+    res = torch.full((n,), 3.0, device=DEV, dtype=dtype, requires_grad=True)
+    y = HF.dropout_add(x, p, res)
+    kept = (y.float() - 3.0)
+    rate = float((kept > 0).float().mean())
+    assert abs(rate - (1 - p)) < 5e-3, rate
+    assert torch.allclose(kept[kept > 0], torch.full_like(kept[kept > 0], 1 / (1 - p)), rtol=1e-2 if dtype == torch.float32 else 3e-2)
+    y.sum().backward()
+    assert torch.equal((x.grad.float() > 0), (kept > 0))                 # same mask in backward
+    assert torch.allclose(res.grad.float(), torch.ones_like(res.grad.float()))
+    y2 = HF.dropout_add(x.detach(), p)                                   # next call site, same step: different mask
+    assert not torch.equal(y2 > 0, kept > 0)
+    HF.dropout_begin_step()
+    assert HF.dropout_add(x.detach(), 0.0) is not None
+
+
+def test_encoder_train_mode_applies_dropout(tiny_meta=None):
+    """RelPosEncoder in .train(): output differs from eval, differs between steps, p = 0 reproduces eval exactly."""
+    HF = HFmod()
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics, RelPosEncoder
+    torch.manual_seed(0)
+    enc = RelPosEncoder(24, output_size=128, attention_heads=2, linear_units=256, num_blocks=2, dropout_rate=0.1,
+                        positional_dropout_rate=0.1, attention_dropout_rate=0.0, kind="conformer").to(DEV)
+    num = Numerics(dtype=torch.float32)
+    B, L = 2, 37
+    xs = torch.randn(B * L, 24, device=DEV, requires_grad=True)
+    ln = torch.tensor([37, 30], device=DEV, dtype=torch.int32)
+    enc.eval()
+    y_eval = enc.forward_cl(xs, B, L, ln, num)
+    enc.train()
+    HF.dropout_begin_step()
+    y1 = enc.forward_cl(xs, B, L, ln, num)
+    y1.sum().backward()
+    assert torch.isfinite(xs.grad).all()
+    HF.dropout_begin_step()
+    y2 = enc.forward_cl(xs, B, L, ln, num)
+    assert rel(y1, y_eval) > 1e-2 and rel(y1, y2) > 1e-2
+    for m in enc.modules():
+        if hasattr(m, "dropout_rate"):
+            m.dropout_rate = 0.0
+    enc.embed.out[2].p = 0.0
+    assert rel(enc.forward_cl(xs, B, L, ln, num), y_eval) < 1e-6

@@ -28,7 +28,7 @@ def test_training_curve_matches_reference(tiny_meta):
                                   weight_decay=hp["wd"], model=jm, numerics=num)
     batches = [synth_batch([T], text_lens=[Lx], token_lens=[Lt], seed=100 + i, text_vocab=100, speech_vocab=50)
                for i, (T, Lx, Lt) in enumerate(log["lens"])]
-    tr = Trainer(max_epochs=hp["epochs"], accumulate_grad_batches=hp["accum"], gradient_clip_val=hp["clip"],
+    tr = Trainer(max_epochs=hp["epochs"], accumulate_grad_batches=hp["accum"], gradient_clip_val=hp["clip"], train_mode=False,
                  log_every_n_steps=1, save_checkpoints=False,
                  draws_fn=lambda ep, bi, b: cfm_draws(1, b["speech_feat"].shape[1], 1000 * ep + bi))
     tr.fit(module, batches)
