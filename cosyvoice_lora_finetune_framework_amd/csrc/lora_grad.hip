@@ -26,11 +26,22 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* lo, const unsign
 
 // RB = r / 16.  Block = 4 wavefronts = 4 x 64 columns; blockIdx.y = slab; each wave walks its slab's rows in
 // 32-row chunks (MFMA k = 32), double-buffered in a private LDS region.
+struct RankProb {             // one gradient product: slabs of  Rk^T Wd  ([r, Cn], or [Cn, r] when transpose_out)
+    int Cn; const bf16_t* Wd; int ldw; const bf16_t* Rk; int ldr; float* out; int ldo; int transpose_out;
+    size_t part_stride; int rows_per_block;
+};
+struct RankPair { RankProb p[2]; };
+
+// blockIdx.z selects the problem: a LoRA layer's dA and dB (same row count M, same rank) go out as ONE launch.
 template <int RB>
-__global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, int Cn, const bf16_t* __restrict__ Wd, int ldw,
-                                                             const bf16_t* __restrict__ Rk, int ldr,
-                                                             float* __restrict__ out, int ldo, int transpose_out,
-                                                             size_t part_stride, int rows_per_block) {
+__global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, RankPair prob_pair) {
+    const RankProb& pr = prob_pair.p[blockIdx.z];
+    const int Cn = pr.Cn, ldw = pr.ldw, ldr = pr.ldr, ldo = pr.ldo, transpose_out = pr.transpose_out;
+    const int rows_per_block = pr.rows_per_block;
+    const bf16_t* __restrict__ Wd = pr.Wd;
+    const bf16_t* __restrict__ Rk = pr.Rk;
+    float* __restrict__ out = pr.out;
+    const size_t part_stride = pr.part_stride;
     constexpr int R = RB * 16;
     constexpr int WD_BYTES = 32 * 128;               // 32 rows x 64 columns
     constexpr int RK_BYTES = 32 * R * 2;
@@ -44,6 +55,7 @@ __global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, int Cn, cons
     const int c0 = (blockIdx.x * 4 + wid) * 64;
     if (c0 >= Cn) return;                            // whole wave (no barriers in this kernel)
     const int mb = blockIdx.y * rows_per_block;
+    if (mb >= M) return;                             // the grid is sized for the problem with more slabs / columns
     const int me = min(M, mb + rows_per_block);
     const int nchunk = (me - mb + 31) >> 5;
     unsigned char* my = smem + wid * 2 * BUF;
@@ -150,16 +162,25 @@ __global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, int Cn, cons
         }
 }
 
-// Slab mode only (part_stride = r * Cn): returns 1 when the operands are not eligible.
-int lora_rank_mfma_launch(int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, float* part,
-                          int transpose_out, int rows_per_block, hipStream_t st) {
-    const bool ok = (r == 16 || r == 32 || r == 48 || r == 64) && Cn % 8 == 0 && ldw % 8 == 0 && ldr % 8 == 0 &&
-                    (reinterpret_cast<uintptr_t>(Wd) & 15) == 0 && (reinterpret_cast<uintptr_t>(Rk) & 15) == 0 &&
-                    rows_per_block % 32 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
-    if (!ok) return 1;
-    const int ldo = transpose_out ? r : Cn;
-    const size_t part_stride = (size_t)r * Cn;
-    dim3 grid((Cn + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
+static bool rank_ok(int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, const float* part, int rows_per_block) {
+    return (r == 16 || r == 32 || r == 48 || r == 64) && Cn % 8 == 0 && ldw % 8 == 0 && ldr % 8 == 0 &&
+           (reinterpret_cast<uintptr_t>(Wd) & 15) == 0 && (reinterpret_cast<uintptr_t>(Rk) & 15) == 0 &&
+           rows_per_block > 0 && rows_per_block % 32 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+}
+static RankProb make_prob(int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, float* part, int transpose_out,
+                          int rows_per_block) {
+    RankProb q;
+    q.Cn = Cn; q.Wd = (const bf16_t*)Wd; q.ldw = ldw; q.Rk = (const bf16_t*)Rk; q.ldr = ldr; q.out = part;
+    q.ldo = transpose_out ? r : Cn; q.transpose_out = transpose_out; q.part_stride = (size_t)r * Cn; q.rows_per_block = rows_per_block;
+    return q;
+}
+static void rank_launch(int M, int r, const RankPair& pp, int nprob, hipStream_t st) {
+    int gx = 0, gy = 0;
+    for (int i = 0; i < nprob; ++i) {
+        gx = max(gx, (pp.p[i].Cn + 255) / 256);
+        gy = max(gy, (M + pp.p[i].rows_per_block - 1) / pp.p[i].rows_per_block);
+    }
+    dim3 grid(gx, gy, nprob);
     const size_t sm = (size_t)4 * 2 * (32 * 128 + 32 * r * 2);
 #define RM_LAUNCH(RBv)                                                                                                   \
     do {                                                                                                                 \
@@ -169,10 +190,35 @@ int lora_rank_mfma_launch(int M, int Cn, int r, const void* Wd, int ldw, const v
             attr_set = true;                                                                                             \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
         }                                                                                                                \
-        hipLaunchKernelGGL(kern, grid, dim3(256), sm, st, M, Cn, (const bf16_t*)Wd, ldw, (const bf16_t*)Rk, ldr, part,    \
-                           ldo, transpose_out, part_stride, rows_per_block);                                            \
+        hipLaunchKernelGGL(kern, grid, dim3(256), sm, st, M, pp);                                                        \
     } while (0)
     if (r == 16) RM_LAUNCH(1); else if (r == 32) RM_LAUNCH(2); else if (r == 48) RM_LAUNCH(3); else RM_LAUNCH(4);
 #undef RM_LAUNCH
+}
+
+// Slab mode only (part_stride = r * Cn): returns 1 when the operands are not eligible.
+int lora_rank_mfma_launch(int M, int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, float* part,
+                          int transpose_out, int rows_per_block, hipStream_t st) {
+    if (!rank_ok(Cn, r, Wd, ldw, Rk, ldr, part, rows_per_block)) return 1;
+    RankPair pp;
+    pp.p[0] = make_prob(Cn, r, Wd, ldw, Rk, ldr, part, transpose_out, rows_per_block);
+    pp.p[1] = pp.p[0];
+    rank_launch(M, r, pp, 1, st);
+    return 0;
+}
+
+// dA and dB of one LoRA layer in one launch (bf16, slab mode):
+//   partA[s] [r, K]  = V^T X  over row block s of size rpbA;   partB[s] [N, r] = dY^T U  over row block s of size rpbB
+extern "C" int cvft_lora_rank_partial_pair(int M, int r, int K, const void* X, int ldx, const void* V, int ldv, float* partA,
+                                           int rpbA, int N, const void* dY, int ldy, const void* U, int ldu, float* partB,
+                                           int rpbB, void* stream) {
+    CVFT_CHECK_ARG(M > 0 && X && V && partA && dY && U && partB, "cvft_lora_rank_partial_pair: bad args");
+    CVFT_CHECK_ARG(rank_ok(K, r, X, ldx, V, ldv, partA, rpbA) && rank_ok(N, r, dY, ldy, U, ldu, partB, rpbB),
+                   "cvft_lora_rank_partial_pair: bf16 operands must be 16-byte aligned, widths %% 8 == 0, r in {16,32,48,64}, rows_per_block %% 32 == 0");
+    RankPair pp;
+    pp.p[0] = make_prob(K, r, X, ldx, V, ldv, partA, 0, rpbA);
+    pp.p[1] = make_prob(N, r, dY, ldy, U, ldu, partB, 1, rpbB);
+    rank_launch(M, r, pp, 2, (hipStream_t)stream);
+    CVFT_LAUNCH_CHECK("cvft_lora_rank_partial_pair");
     return 0;
 }

@@ -50,6 +50,7 @@ SIGNATURES = {
     "cvft_tn_accum": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "cvft_lora_rank_accum": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "cvft_lora_rank_partial": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
+    "cvft_lora_rank_partial_pair": [_i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "cvft_lora_grad_reduce": [_i, _p, _i, _p],
     "cvft_lora_shadow": [_i, _p, _p, _p],
     "cvft_layernorm_fwd": [_i, _i, _i, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p],

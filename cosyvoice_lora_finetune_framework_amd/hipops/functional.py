@@ -446,12 +446,23 @@ def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_d
                 sink.side.wait_stream(cur)
                 sink.keep.append((x, V, dz, U))
             with ctxm:
-                for Wd, Rk, P, g, tr in ((x, V, A, gA, False), (dz, U, B, gB, True)):
-                    rpb, ns = LoraGradSink.plan(M, Wd.shape[1])
-                    ws = LoraGradSink.workspace(P, ns)
-                    check(lib().cvft_lora_rank_partial(dt(Wd), M, Wd.shape[1], r, ptr(Wd), Wd.stride(0), ptr(Rk),
-                                                       Rk.stride(0), ptr(ws), int(tr), rpb, stream()), "cvft_lora_rank_partial")
-                    sink.add(ws, g, P.numel(), ns)
+                if x.dtype == torch.bfloat16 and r in (16, 32, 48, 64):
+                    # dA and dB in one launch (matrix-core slab kernel)
+                    rpa, nsa = LoraGradSink.plan(M, x.shape[1])
+                    rpb_, nsb = LoraGradSink.plan(M, dz.shape[1])
+                    wsA, wsB = LoraGradSink.workspace(A, nsa), LoraGradSink.workspace(B, nsb)
+                    check(lib().cvft_lora_rank_partial_pair(M, r, x.shape[1], ptr(x), x.stride(0), ptr(V), V.stride(0), ptr(wsA), rpa,
+                                                            dz.shape[1], ptr(dz), dz.stride(0), ptr(U), U.stride(0), ptr(wsB), rpb_,
+                                                            stream()), "cvft_lora_rank_partial_pair")
+                    sink.add(wsA, gA, A.numel(), nsa)
+                    sink.add(wsB, gB, B.numel(), nsb)
+                else:
+                    for Wd, Rk, P, g, tr in ((x, V, A, gA, False), (dz, U, B, gB, True)):
+                        rpb, ns = LoraGradSink.plan(M, Wd.shape[1])
+                        ws = LoraGradSink.workspace(P, ns)
+                        check(lib().cvft_lora_rank_partial(dt(Wd), M, Wd.shape[1], r, ptr(Wd), Wd.stride(0), ptr(Rk),
+                                                           Rk.stride(0), ptr(ws), int(tr), rpb, stream()), "cvft_lora_rank_partial")
+                        sink.add(ws, g, P.numel(), ns)
         else:
             rank_accum(x, V, gA, False)                               # dA[r,K] += V^T x
             rank_accum(dz, U, gB, True)                               # dB[N,r] += dz^T U
@@ -592,18 +603,17 @@ class LinearQKVStackedFn(torch.autograd.Function):
         direct = all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for pair in grads for g in pair)
         if sink is not None and direct and sink.side is None:
             K = x.shape[1]
-            rpb, ns = LoraGradSink.plan(M, K)
-            wsA = LoraGradSink.workspace(ctx.refs[0][0], ns * 3)        # slab [3r, K] per row block
-            check(lib().cvft_lora_rank_partial(dt(x), M, K, r3, ptr(x), x.stride(0), ptr(V), V.stride(0), ptr(wsA), 0, rpb,
-                                               stream()), "cvft_lora_rank_partial")
+            rpa, nsa = LoraGradSink.plan(M, K)
+            rpb_, nsb = LoraGradSink.plan(M, 3 * N)
+            wsA = LoraGradSink.workspace(ctx.refs[0][0], nsa * 3)       # slab [3r, K] per row block
+            wsB = LoraGradSink.workspace(ctx.refs[0][1], nsb * 9)       # slab [3N, 3r] per row block
+            check(lib().cvft_lora_rank_partial_pair(M, r3, K, ptr(x), x.stride(0), ptr(V), V.stride(0), ptr(wsA), rpa,
+                                                    3 * N, ptr(dY), dY.stride(0), ptr(U), U.stride(0), ptr(wsB), rpb_, stream()),
+                  "cvft_lora_rank_partial_pair")
             for i, (gA, _) in enumerate(grads):
-                sink.add_block(wsA.data_ptr() + i * r * K * 4, gA, r, K, K, r3 * K, ns)
-            rpb, ns = LoraGradSink.plan(M, 3 * N)
-            wsB = LoraGradSink.workspace(ctx.refs[0][1], ns * 9)        # slab [3N, 3r] per row block
-            check(lib().cvft_lora_rank_partial(dt(dY), M, 3 * N, r3, ptr(dY), dY.stride(0), ptr(U), U.stride(0), ptr(wsB), 1,
-                                               rpb, stream()), "cvft_lora_rank_partial")
+                sink.add_block(wsA.data_ptr() + i * r * K * 4, gA, r, K, K, r3 * K, nsa)
             for i, (_, gB) in enumerate(grads):
-                sink.add_block(wsB.data_ptr() + (i * N * r3 + i * r) * 4, gB, N, r, r3, 3 * N * r3, ns)
+                sink.add_block(wsB.data_ptr() + (i * N * r3 + i * r) * 4, gB, N, r, r3, 3 * N * r3, nsb)
             out = [None] * 6
         else:
             out = []

@@ -107,6 +107,10 @@ int cvft_lora_rank_accum(int dtype, int M, int C, int r, const void* Wd, int ldw
  * may address a sub-block of a wider slab: the stacked q|k|v adapters share one slab). */
 int cvft_lora_rank_partial(int dtype, int M, int C, int r, const void* Wd, int ldw, const void* Rk, int ldr,
                            float* part, int transpose_out, int rows_per_block, void* stream);
+/* bf16 matrix-core form, dA and dB of one LoRA layer in ONE launch:  partA[s][r][K] = V^T X,  partB[s][N][r] = dY^T U
+ * (row blocks of rpbA / rpbB rows, multiples of 32; operands 16-byte aligned, K % 8 == N % 8 == 0, r in {16,32,48,64}). */
+int cvft_lora_rank_partial_pair(int M, int r, int K, const void* X, int ldx, const void* V, int ldv, float* partA, int rpbA,
+                                int N, const void* dY, int ldy, const void* U, int ldu, float* partB, int rpbB, void* stream);
 int cvft_lora_grad_reduce(int ntasks, const void* tasks, int max_blocks_x, void* stream);
 /* One launch per optimiser step: bf16 copy and transposed bf16 copy of every LoRA master in the flat fp32 buffer.
  * tiles: int64[ntiles][6] = {src offset (elements of flat_p), dst ptr, dst_t ptr, rows | cols << 32,
