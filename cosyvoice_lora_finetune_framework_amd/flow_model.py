@@ -55,6 +55,52 @@ class ConditionalCFM(nn.Module):
         denom = (length.sum() * pred.shape[1]).to(torch.float32)
         return HF.masked_mse(pred, u, length, denom, B, T), xin
 
+    @torch.no_grad()
+    def forward(self, mu, mask, n_timesteps, temperature=1.0, spks=None, cond=None, prompt_len=0, cache=None,
+                noise: Optional[torch.Tensor] = None, num: Optional[Numerics] = None):
+        """CFM sampler (flow_model.py:74-98): cosine t-span Euler ODE with classifier-free guidance.
+        mu,cond (1,80,T), mask (1,1,T), spks (1,80) -> (mel (1,80,T) fp32, new_cache).  `noise` (optional) injects the
+        initial z (the reference draws `randn_like(mu) * temperature`)."""
+        z = (torch.randn_like(mu) if noise is None else noise.to(mu.device, mu.dtype)) * temperature
+        if cache is not None and cache.shape[2] != 0:
+            cache_size = cache.shape[2]
+            z[:, :, :cache_size] = cache[:, :, :, 0]
+            mu[:, :, :cache_size] = cache[:, :, :, 1]
+        z_cache = torch.concat([z[:, :, :prompt_len], z[:, :, -34:]], dim=2) if prompt_len > 0 else z[:, :, -34:]
+        mu_cache = torch.concat([mu[:, :, :prompt_len], mu[:, :, -34:]], dim=2) if prompt_len > 0 else mu[:, :, -34:]
+        new_cache = torch.stack([z_cache, mu_cache], dim=-1)
+        t_span = torch.linspace(0, 1, n_timesteps + 1, device=mu.device, dtype=mu.dtype)
+        t_span = 1 - torch.cos(t_span * 0.5 * 3.14159265359)
+        return self.solve_euler(z, t_span, mu, mask, spks, cond, num), new_cache
+
+    @torch.no_grad()
+    def solve_euler(self, x, t_span, mu, mask, spks, cond, num: Optional[Numerics] = None):
+        """flow_model.py:100-135: the batch-of-2 trick -- row 0 conditional, row 1 unconditional (zero mu / spk /
+        cond) -- one estimator forward (HIP kernels) per step, guidance (1+w) v_c - w v_u."""
+        num = num or Numerics(dtype=x.dtype)
+        t, dt = t_span[0].unsqueeze(0), t_span[1] - t_span[0]
+        T = x.size(2)
+        x_in = torch.zeros([2, 80, T], device=x.device, dtype=x.dtype)
+        mask_in = torch.zeros([2, 1, T], device=x.device, dtype=x.dtype)
+        mu_in = torch.zeros([2, 80, T], device=x.device, dtype=x.dtype)
+        t_in = torch.zeros([2], device=x.device, dtype=x.dtype)
+        spks_in = torch.zeros([2, 80], device=x.device, dtype=x.dtype)
+        cond_in = torch.zeros([2, 80, T], device=x.device, dtype=x.dtype)
+        for step in range(1, len(t_span)):
+            x_in[:] = x
+            mask_in[:] = mask
+            mu_in[0] = mu
+            t_in[:] = t.unsqueeze(0)
+            spks_in[0] = spks
+            cond_in[0] = cond
+            d = self.estimator(x_in, mask_in, mu_in, t_in, spks_in, cond_in, dtype=num.dtype, gelu=num.gelu)
+            d, d_u = torch.split(d, [x.size(0), x.size(0)], dim=0)
+            x = x + dt * ((1.0 + self.inference_cfg_rate) * d - self.inference_cfg_rate * d_u)
+            t = t + dt
+            if step < len(t_span) - 1:
+                dt = t_span[step + 1] - t
+        return x.float()
+
     def compute_loss(self, x1, mask, mu, spks=None, cond=None, prompt_lens=None, draws=None, num: Optional[Numerics] = None):
         """Reference signature: x1,mu,cond (B,80,T) normalised mel; mask (B,1,T); spks (B,80)."""
         if prompt_lens:

@@ -314,6 +314,26 @@ def cfm_prepare(x1, t_raw, z, sigma_min: float):
     return t, y, u
 
 
+def cfm_sample(sd, p: str, z, mu, mask, spks, cond, n_timesteps: int, cfg: OracleConfig, inference_cfg_rate: float = 0.7):
+    """flow_model.py:74-135 (ConditionalCFM.forward + solve_euler, no cache): cosine t-span, batch-of-2 CFG Euler steps.
+    z,mu,cond (1,80,T); mask (1,1,T); spks (1,80) -> (1,80,T) fp32."""
+    t_span = torch.linspace(0, 1, n_timesteps + 1, dtype=mu.dtype)
+    t_span = 1 - torch.cos(t_span * 0.5 * 3.14159265359)
+    x, t, dt = z, t_span[0].unsqueeze(0), t_span[1] - t_span[0]
+    for step in range(1, len(t_span)):
+        x_in = torch.cat([x, x], 0)
+        mask_in = torch.cat([mask, mask], 0)
+        mu_in = torch.cat([mu, torch.zeros_like(mu)], 0)
+        spks_in = torch.cat([spks, torch.zeros_like(spks)], 0)
+        cond_in = torch.cat([cond, torch.zeros_like(cond)], 0)
+        d = estimator(sd, p, x_in, mask_in, mu_in, t.expand(2), spks_in, cond_in, cfg)
+        x = x + dt * ((1.0 + inference_cfg_rate) * d[:1] - inference_cfg_rate * d[1:])
+        t = t + dt
+        if step < len(t_span) - 1:
+            dt = t_span[step + 1] - t
+    return x.float()
+
+
 def flow_forward(sd, batch, draws, cfg: OracleConfig, return_all: bool = False):
     """llm_flow_model.py:181-229 (_forward_flow, no-prompt) ->
     ConditionalCFM.compute_loss (flow_matching.py:154-193).

@@ -237,3 +237,15 @@ def test_checkpoint_roundtrip_lightning_layout(tiny_meta, tmp_path):
     for k, v in mod2.model.named_parameters():
         assert torch.equal(v.detach().cpu(), a[k].detach().cpu()), k
     assert torch.equal(opt2.m.cpu(), tr.optimizer.m.cpu()) and opt2.step_count == 2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 5e-2)])
+def test_cfm_sampler_matches_reference(tiny_meta, dtype, tol):
+    """the CFM Euler sampler (flow_model.py:74-135) on the HIP estimator vs the reference's output."""
+    g = load_npz("sampler_tiny.npz")
+    m = build_flow_product(tiny_meta["flow"], DEV, _numerics("vendored", dtype))
+    out, cache = m.decoder(g["mu"].to(DEV), g["mask"].to(DEV), n_timesteps=5, temperature=1.0, spks=g["spks"].to(DEV),
+                           cond=g["cond"].to(DEV), prompt_len=10, noise=g["z"], num=_numerics("vendored", dtype))
+    assert out.dtype == torch.float32 and tuple(out.shape) == tuple(g["out"].shape)
+    assert rel(out, g["out"]) < tol, rel(out, g["out"])
+    assert rel(cache, g["cache"]) < 1e-6

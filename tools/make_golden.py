@@ -209,6 +209,30 @@ def gen_tiny():
         json.dump(meta, f, indent=0)
 
 
+def gen_sampler():
+    """CFM sampler fixture: reference ConditionalCFM.forward on the tiny vendored flow model."""
+    torch.manual_seed(0)
+    m = build_ref_flow('vendored', **TINY_FLOW)
+    wrap_and_fill(m, r=4, alpha=8, targets=FLOW_TARGETS, seed=3)
+    m.eval()
+    g = torch.Generator().manual_seed(41)
+    T = 44
+    mu = torch.randn(1, 80, T, generator=g) * 0.5
+    spks = torch.randn(1, 80, generator=g) * 0.3
+    cond = torch.zeros(1, 80, T)
+    cond[:, :, :10] = torch.randn(1, 80, 10, generator=g)          # a 10-frame prompt
+    mask = torch.ones(1, 1, T)
+    z = torch.randn(1, 80, T, generator=g)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: z.clone().to(t.dtype)    # pin the sampler's initial noise
+    try:
+        out, cache = m.decoder(mu.clone(), mask, n_timesteps=5, temperature=1.0, spks=spks, cond=cond, prompt_len=10)
+    finally:
+        torch.randn_like = orig
+    print(f"sampler: out mean {out.mean().item():.6f} std {out.std().item():.6f} cache {tuple(cache.shape)}")
+    npz_save(os.path.join(GOLD, "sampler_tiny.npz"), mu=mu, spks=spks, cond=cond, mask=mask, z=z, out=out, cache=cache)
+
+
 def run_flow_nograd(model, batch, seed):
     jm = ref_joint.JointLLMFlowModel(nn.Identity(), model, 'flow_only')
     torch.manual_seed(seed)
@@ -388,6 +412,8 @@ if __name__ == "__main__":
         gen_ops()
     if a.only in ("all", "tiny"):
         gen_tiny()
+    if a.only in ("all", "sampler"):
+        gen_sampler()
     if a.only in ("all", "train"):
         gen_train()
     if a.only in ("all", "full"):
