@@ -406,6 +406,56 @@ def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residu
     return y, U, z, ops
 
 
+def _lora_param_grads(x, U, V, dz, A_ref, B_ref, ops):
+    """dA[r,K] += V^T x,  dB[N,r] += dz^T U  (V = s dz B, U = s x A^T): into the parameters' flat .grad buffers -- through the
+    active LoraGradSink (deterministic slabs + one reduce) when there is one, else fp32 atomics -- or returned."""
+    dA = dB = None
+    A, B = A_ref, B_ref
+    gA, gB = A.grad, B.grad
+    direct = gA is not None and gB is not None and gA.dtype == torch.float32 and gA.is_contiguous() \
+        and gB.is_contiguous() and gA.dim() == 2 and gB.dim() == 2
+    if not direct:
+        gA = torch.zeros(ops[0].shape, dtype=torch.float32, device=x.device)
+        gB = torch.zeros(ops[2].shape, dtype=torch.float32, device=x.device)
+    sink = LoraGradSink.active
+    r = V.shape[1]
+    vec = 8 if x.dtype == torch.bfloat16 else 4
+    if (sink is not None and direct and r % 16 == 0 and x.shape[1] % vec == 0 and dz.shape[1] % vec == 0
+            and x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0):
+        M = x.shape[0]
+        # the slab kernels are off the critical path (nothing downstream in backward reads them): launch them
+        # on the sink's side stream so they overlap the latency-bound dgrad chain; joined in sink.flush()
+        cur = torch.cuda.current_stream()
+        ctxm = torch.cuda.stream(sink.side) if sink.side is not None else contextlib.nullcontext()
+        if sink.side is not None:
+            sink.side.wait_stream(cur)
+            sink.keep.append((x, V, dz, U))
+        with ctxm:
+            if x.dtype == torch.bfloat16 and r in (16, 32, 48, 64):
+                # dA and dB in one launch (matrix-core slab kernel)
+                rpa, nsa = LoraGradSink.plan(M, x.shape[1])
+                rpb_, nsb = LoraGradSink.plan(M, dz.shape[1])
+                wsA, wsB = LoraGradSink.workspace(A, nsa), LoraGradSink.workspace(B, nsb)
+                check(lib().cvft_lora_rank_partial_pair(M, r, x.shape[1], ptr(x), x.stride(0), ptr(V), V.stride(0), ptr(wsA), rpa,
+                                                        dz.shape[1], ptr(dz), dz.stride(0), ptr(U), U.stride(0), ptr(wsB), rpb_,
+                                                        stream()), "cvft_lora_rank_partial_pair")
+                sink.add(wsA, gA, A.numel(), nsa)
+                sink.add(wsB, gB, B.numel(), nsb)
+            else:
+                for Wd, Rk, P, g, tr in ((x, V, A, gA, False), (dz, U, B, gB, True)):
+                    rpb, ns = LoraGradSink.plan(M, Wd.shape[1])
+                    ws = LoraGradSink.workspace(P, ns)
+                    check(lib().cvft_lora_rank_partial(dt(Wd), M, Wd.shape[1], r, ptr(Wd), Wd.stride(0), ptr(Rk),
+                                                       Rk.stride(0), ptr(ws), int(tr), rpb, stream()), "cvft_lora_rank_partial")
+                    sink.add(ws, g, P.numel(), ns)
+    else:
+        rank_accum(x, V, gA, False)                               # dA[r,K] += V^T x
+        rank_accum(dz, U, gB, True)                               # dB[N,r] += dz^T U
+    if not direct:
+        dA, dB = gA, gB
+    return dA, dB
+
+
 def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_dx: bool, need_dAB: bool,
              dx_residual=None, dact_src=None, dact: Optional[str] = None):
     """Backward of one LoRA linear given dz = gradient at its pre-activation output.
@@ -425,49 +475,7 @@ def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_d
     if need_dx and dx is None:
         dx = gemm(dz, pack.Wb, U=V, Bl=None if V is None else ops[1], dact_src=dact_src, dact=dact, residual=dx_residual)
     if has_lora and need_dAB:
-        A, B = A_ref, B_ref
-        gA, gB = A.grad, B.grad
-        direct = gA is not None and gB is not None and gA.dtype == torch.float32 and gA.is_contiguous() \
-            and gB.is_contiguous() and gA.dim() == 2 and gB.dim() == 2
-        if not direct:
-            gA = torch.zeros(ops[0].shape, dtype=torch.float32, device=x.device)
-            gB = torch.zeros(ops[2].shape, dtype=torch.float32, device=x.device)
-        sink = LoraGradSink.active
-        r = V.shape[1]
-        vec = 8 if x.dtype == torch.bfloat16 else 4
-        if (sink is not None and direct and r % 16 == 0 and x.shape[1] % vec == 0 and dz.shape[1] % vec == 0
-                and x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0):
-            M = x.shape[0]
-            # the slab kernels are off the critical path (nothing downstream in backward reads them): launch them
-            # on the sink's side stream so they overlap the latency-bound dgrad chain; joined in sink.flush()
-            cur = torch.cuda.current_stream()
-            ctxm = torch.cuda.stream(sink.side) if sink.side is not None else contextlib.nullcontext()
-            if sink.side is not None:
-                sink.side.wait_stream(cur)
-                sink.keep.append((x, V, dz, U))
-            with ctxm:
-                if x.dtype == torch.bfloat16 and r in (16, 32, 48, 64):
-                    # dA and dB in one launch (matrix-core slab kernel)
-                    rpa, nsa = LoraGradSink.plan(M, x.shape[1])
-                    rpb_, nsb = LoraGradSink.plan(M, dz.shape[1])
-                    wsA, wsB = LoraGradSink.workspace(A, nsa), LoraGradSink.workspace(B, nsb)
-                    check(lib().cvft_lora_rank_partial_pair(M, r, x.shape[1], ptr(x), x.stride(0), ptr(V), V.stride(0), ptr(wsA), rpa,
-                                                            dz.shape[1], ptr(dz), dz.stride(0), ptr(U), U.stride(0), ptr(wsB), rpb_,
-                                                            stream()), "cvft_lora_rank_partial_pair")
-                    sink.add(wsA, gA, A.numel(), nsa)
-                    sink.add(wsB, gB, B.numel(), nsb)
-                else:
-                    for Wd, Rk, P, g, tr in ((x, V, A, gA, False), (dz, U, B, gB, True)):
-                        rpb, ns = LoraGradSink.plan(M, Wd.shape[1])
-                        ws = LoraGradSink.workspace(P, ns)
-                        check(lib().cvft_lora_rank_partial(dt(Wd), M, Wd.shape[1], r, ptr(Wd), Wd.stride(0), ptr(Rk),
-                                                           Rk.stride(0), ptr(ws), int(tr), rpb, stream()), "cvft_lora_rank_partial")
-                        sink.add(ws, g, P.numel(), ns)
-        else:
-            rank_accum(x, V, gA, False)                               # dA[r,K] += V^T x
-            rank_accum(dz, U, gB, True)                               # dB[N,r] += dz^T U
-        if not direct:
-            dA, dB = gA, gB
+        dA, dB = _lora_param_grads(x, U, V, dz, A_ref, B_ref, ops)
     return dx, dA, dB
 
 
@@ -654,6 +662,37 @@ class FeedForwardFn(torch.autograd.Function):
             dx, dA1, dB1 = _lin_bwd(x, U1, ops1, A1, B1, pack1, s1, dz, need_dx, need1)
         dres = dy if ctx.needs_input_grad[5] else None
         return dx, dA1, dB1, dA2, dB2, dres, None, None, None, None, None
+
+
+class LoraSideFn(torch.autograd.Function):
+    """y = base + scale * (xd A^T) B^T -- the LoRA side path on its own input (training with lora_dropout > 0, where
+    xd = dropout(x) differs from the main path's x; lora.py:70-73).  Two rank-r products, no zero-weight main GEMM."""
+
+    @staticmethod
+    def forward(ctx, xd, A, B, base, scale: float):
+        xd = _c(xd)
+        ops = (*_lora_operands(A, xd.dtype), *_lora_operands(B, xd.dtype))
+        U = gemm(xd, ops[0], alpha=scale)                       # [M, r]
+        y = gemm(U, ops[2], residual=_c(base))                  # [M, N], K = r
+        ctx.ops, ctx.scale, ctx.refs = ops, scale, (A, B)
+        ctx.save_for_backward(xd, U)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xd, U = ctx.saved_tensors
+        Ac, At, Bc, Bt = ctx.ops
+        dy = _rowc(dy)
+        V = gemm(dy, Bt, alpha=ctx.scale)                       # [M, r] = s dy B
+        dxd = gemm(V, At) if ctx.needs_input_grad[0] else None  # [M, K]
+        dA = dB = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dA, dB = _lora_param_grads(xd, U, V, dy, ctx.refs[0], ctx.refs[1], ctx.ops)
+        return dxd, dA, dB, (dy if ctx.needs_input_grad[3] else None), None
+
+
+def lora_side(xd, A, B, base, scale: float):
+    return LoraSideFn.apply(xd, A, B, base, scale)
 
 
 def lora_linear(x, pack: LinearPack, A=None, B=None, scale: float = 1.0, act: Optional[str] = None, residual=None):

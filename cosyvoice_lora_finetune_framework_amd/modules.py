@@ -108,23 +108,14 @@ def hip_ffn(m1: nn.Module, m2: nn.Module, x: torch.Tensor, act: str, residual: O
 
 
 def _lora_dropout_path(x, pack, A, Bm, scale, drop, act, residual):
-    # y = act(x W^T + b + s * (drop(x) A^T) B^T): main GEMM without side path + separate rank-r GEMMs
-    assert act is None, "LoRA dropout with a fused activation is not supported"
-    y = HF.lora_linear(x, pack, None, None, 1.0, None, residual)
-    xd = drop(x)
-    zero_pack = _ZeroPack.get(pack.N, pack.K, x.dtype, x.device)
-    return HF.lora_linear(xd, zero_pack, A, Bm, scale, None, y)
-
-
-class _ZeroPack:
-    _cache = {}
-
-    @staticmethod
-    def get(N, K, dtype, device):
-        key = (N, K, dtype, str(device))
-        if key not in _ZeroPack._cache:
-            _ZeroPack._cache[key] = HF.LinearPack(torch.zeros(N, K, device=device), None, dtype)
-        return _ZeroPack._cache[key]
+    """y = act(x W^T + b + s * (drop(x) A^T) B^T) (+ residual)  (lora.py:64-76 with lora_dropout active): main GEMM
+    without side path, then the rank-r side path on the dropped input (HF.LoraSideFn), then the activation."""
+    if act is None:
+        y = HF.lora_linear(x, pack, None, None, 1.0, None, residual)
+        return HF.lora_side(drop(x), A, Bm, y, scale)
+    z = HF.lora_side(drop(x), A, Bm, HF.lora_linear(x, pack, None, None, 1.0, None, None), scale)
+    h = HF.ActFn.apply(z, act)
+    return h if residual is None else h + residual
 
 
 def conv_pack(mod: nn.Module, dtype) -> HF.ConvPack:

@@ -20,7 +20,7 @@ from typing import Dict, Iterable, List, Optional
 import torch
 
 from . import dp
-from .config import JOINT_TRAINING_CONFIG, MI355X_CONFIG, OUTPUT_DIR, PRETRAINED_MODEL_DIR, TRAIN_CONFIG
+from .config import DATA_DIR, JOINT_TRAINING_CONFIG, MI355X_CONFIG, OUTPUT_DIR, PRETRAINED_MODEL_DIR, TRAIN_CONFIG
 from .hipops.functional import LoraGradSink
 from .modules import Numerics
 from .optim import FlatAdamW, lr_lambda
@@ -182,6 +182,8 @@ class Trainer:
             ep_cnt = 0
             t0 = time.time()
             for bi, batch in enumerate(dataloader):
+                if batch is None:                      # collate_fn: every sample of this batch failed to decode
+                    continue
                 draws = self.draws_fn(epoch, bi, batch) if self.draws_fn else None
                 losses = module.training_step(batch, bi, draws)
                 w = dp.loss_weights(_batch_denoms(batch), dev) if self.world > 1 else None
@@ -262,6 +264,7 @@ def main():
     ap.add_argument('--batch-size', type=int, default=None)
     ap.add_argument('--lr', type=float, default=None)
     ap.add_argument('--synthetic', type=int, default=0, help='train on N synthetic batches per epoch (no dataset needed)')
+    ap.add_argument('--data-dir', type=str, default=None, help='directory with data.list / *.parquet (default: config.DATA_DIR)')
     ap.add_argument('--frames', type=int, default=500)
     ap.add_argument('--dtype', type=str, default=MI355X_CONFIG['compute_dtype'], choices=['bf16', 'fp32'])
     a = ap.parse_args()
@@ -276,9 +279,17 @@ def main():
     module = JointLightningModule(a.mode, learning_rate=lr, min_lr=TRAIN_CONFIG['min_learning_rate'],
                                   warmup_steps=TRAIN_CONFIG['warmup_steps'], weight_decay=TRAIN_CONFIG['weight_decay'],
                                   numerics=num)
-    if a.synthetic <= 0:
-        raise SystemExit("the parquet data path (reference dataset.py) is a SURVEY 8(f) 'next' item; use --synthetic N")
-    loader = SyntheticLoader(a.synthetic, bs, a.frames, rank=rank, ragged=True)
+    if a.synthetic > 0:
+        loader = SyntheticLoader(a.synthetic, bs, a.frames, rank=rank, ragged=True)
+    else:
+        # parquet shards written by prepare_joint_data.py (train_joint.py:283-298); rank-strided shards under DP
+        from .dataset import create_dataloader
+        data_dir = a.data_dir or DATA_DIR
+        if not os.path.isdir(data_dir):
+            raise SystemExit(f"no dataset at {data_dir} (prepare_joint_data.py output); pass --data-dir or --synthetic N")
+        loader = create_dataloader(data_dir, batch_size=bs, num_workers=0, rank=rank, world=world)
+        if len(loader) == 0:
+            raise SystemExit(f"{data_dir} holds fewer than {bs * world} usable utterances")
     trainer = Trainer(max_epochs=epochs, accumulate_grad_batches=jc['accumulate_grad_batches'],
                       gradient_clip_val=TRAIN_CONFIG['gradient_clip_val'],
                       callbacks=[EarlyStopping(), LossThresholdCallback(llm_loss_threshold=1.5, flow_loss_threshold=0.3)])

@@ -172,3 +172,56 @@ def test_callbacks_follow_reference_rules():
         t2.callback_metrics = {"train_loss_epoch": v}
         es.on_train_epoch_end(t2)
     assert t2.should_stop
+
+
+def test_data_path_matches_reference_dataset():
+    """parquet shard -> samples -> batch dict.  The fixture holds what the reference's dataset.py
+    produced from tests/golden/data_shard under random.seed(7) / torch.manual_seed(7) (tools/make_golden.py gen_data):
+    data.list resolution of a foreign absolute path, flattened-mel decoding, augmentation draw order, cross-sample
+    prompts, proportional truncation, padding values, text_token only when every utterance has one."""
+    import os
+    import random
+    from conftest import GOLD, load_npz
+    from cosyvoice_lora_finetune_framework_amd import dataset as D
+    g = load_npz("data_path.npz")
+    d = os.path.join(GOLD, "data_shard")
+    D.ANTI_LEAKAGE_CONFIG = {'cross_sample_enabled': True, 'cross_sample_prob': 0.5}
+    ds = D.FlowFinetuneDataset(d, augmentation=True, verbose=False)
+    ds.cross_sample_enabled, ds.cross_sample_prob = True, 0.5
+    assert len(ds) == 6
+    random.seed(7)
+    torch.manual_seed(7)
+    items = [ds[i] for i in range(len(ds))]
+    for i, it in enumerate(items):
+        for k, v in it.items():
+            key = f"item{i}/{k}"
+            if v is None:
+                assert key not in g, key
+            else:
+                assert key in g and v.shape == g[key].shape, key
+                assert torch.equal(v, g[key]) if v.dtype == torch.long else torch.allclose(v, g[key], atol=1e-6), key
+    for name, idx, lim in (("b0", [0, 1, 2], 50), ("b1", [3, 4], 50), ("b2", [0, 5], 1000)):
+        out = D.collate_fn([{k: (v.clone() if torch.is_tensor(v) else v) for k, v in items[i].items()} for i in idx], lim)
+        ref = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith(name + "/")}
+        assert set(out) == set(ref), (name, set(out) ^ set(ref))
+        for k in ref:
+            assert out[k].shape == ref[k].shape and out[k].dtype == ref[k].dtype, (name, k)
+            assert torch.allclose(out[k].double(), ref[k].double(), atol=1e-6), (name, k)
+    assert "text_token" in {k.split("/")[1] for k in g if k.startswith("b0/")} and "b1/text_token" not in g
+    ds2 = D.FlowFinetuneDataset(d, augmentation=False, verbose=False)
+    ds2.cross_sample_enabled = False
+    it = ds2[2]
+    for k, v in it.items():
+        if v is not None:
+            assert torch.allclose(v.double(), g[f"plain2/{k}"].double()), k
+
+
+def test_shard_sampler_partitions_whole_global_batches():
+    from cosyvoice_lora_finetune_framework_amd.dataset import ShardSampler
+    parts = [list(ShardSampler(23, batch_size=2, rank=r, world=4, seed=5)) for r in range(4)]
+    assert all(len(p) == 4 for p in parts)                       # 23 // (2*4) = 2 steps x 2 per rank
+    flat = [i for p in parts for i in p]
+    assert len(set(flat)) == len(flat) == 16
+    s = ShardSampler(23, 2, 0, 4, seed=5)
+    s.set_epoch(1)
+    assert list(s) != parts[0]

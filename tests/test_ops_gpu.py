@@ -547,3 +547,41 @@ def test_encoder_train_mode_applies_dropout(tiny_meta=None):
             m.dropout_rate = 0.0
     enc.embed.out[2].p = 0.0
     assert rel(enc.forward_cl(xs, B, L, ln, num), y_eval) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [None, "silu"])
+def test_lora_dropout_side_path_matches_torch(dtype, act):
+    """lora.py:64-76 in train mode: y = act(x W^T + b + s * (drop(x) A^T) B^T) + residual, with a FIXED dropout mask so
+    that the HIP path (main GEMM + LoraSideFn) can be compared with torch autograd, forward and all gradients."""
+    from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
+    from cosyvoice_lora_finetune_framework_amd.modules import hip_linear
+    HF = HFmod()
+    torch.manual_seed(11)
+    M, K, N = 200, 64, 96
+    mod = LoRALinear(torch.nn.Linear(K, N), r=16, lora_alpha=32, lora_dropout=0.25).to(DEV)
+    torch.nn.init.normal_(mod.lora_B, std=0.1)
+    mask = (torch.rand(M, K, device=DEV) > 0.25).float() / 0.75
+
+    class Fixed(torch.nn.Dropout):
+        def forward(self, x):
+            return x * mask.to(x.dtype)
+    mod.lora_dropout = Fixed(0.25)
+    mod.train()
+    x = (torch.randn(M, K, device=DEV) * 0.5).to(dtype).requires_grad_(True)
+    res = torch.randn(M, N, device=DEV).to(dtype).requires_grad_(True)
+    gy = torch.randn(M, N, device=DEV).to(dtype)
+    y = hip_linear(mod, x, act=act, residual=res)
+    y.backward(gy)
+    got = [y.float(), x.grad.float(), res.grad.float(), mod.lora_A.grad.clone(), mod.lora_B.grad.clone()]
+    for t in (x, res, mod.lora_A, mod.lora_B):
+        t.grad = None
+    xf, rf = x.detach().float().requires_grad_(True), res.detach().float().requires_grad_(True)
+    W, b = mod.original_layer.weight.float(), mod.original_layer.bias.float()
+    z = xf @ W.t() + b + mod.scaling * ((xf * mask) @ mod.lora_A.t()) @ mod.lora_B.t()
+    yr = (torch.nn.functional.silu(z) if act else z) + rf
+    yr.backward(gy.float())
+    ref = [yr, xf.grad, rf.grad, mod.lora_A.grad, mod.lora_B.grad]
+    tol = 3e-2 if dtype == torch.bfloat16 else 1e-4
+    for name, u, w in zip(("y", "dx", "dres", "dA", "dB"), got, ref):
+        assert rel(u, w) < tol, (name, rel(u, w))

@@ -233,6 +233,53 @@ def gen_sampler():
     npz_save(os.path.join(GOLD, "sampler_tiny.npz"), mu=mu, spks=spks, cond=cond, mask=mask, z=z, out=out, cache=cache)
 
 
+def gen_data():
+    """On-disk data path fixture: a small shard in the schema prepare_joint_data.py writes
+    (275-284, 365-372) + what the reference's dataset.py makes of it under fixed seeds."""
+    import random
+    import pandas as pd
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    import dataset as ref_ds
+    d = os.path.join(GOLD, "data_shard")
+    os.makedirs(os.path.join(d, "parquet"), exist_ok=True)
+    g = torch.Generator().manual_seed(99)
+    rows = []
+    for i, T in enumerate([61, 40, 75, 33, 52, 58]):
+        mel = torch.randn(T, 80, generator=g) * 2 - 6
+        n_tok = int(T * 50 * 256 / 22050)
+        emb = torch.randn(192, generator=g).tolist()
+        rows.append({'utt': f'utt{i}', 'text': f'text {i}', 'text_token': torch.randint(0, 500, (5 + i,), generator=g).tolist(),
+                     'speech_token': torch.randint(0, 4096, (n_tok,), generator=g).tolist(),
+                     'speech_feat': mel.flatten().tolist(), 'speech_feat_shape': (T, 80),
+                     'utt_embedding': emb, 'spk_embedding': emb})
+    rows[3]['text_token'] = None                                   # one utterance without text
+    pq.write_table(pa.Table.from_pandas(pd.DataFrame(rows)), os.path.join(d, "parquet", "data_000000.parquet"))
+    with open(os.path.join(d, "data.list"), "w", encoding="utf-8") as f:
+        f.write("D:\\out\\parquet\\data_000000.parquet\n")   # a path from the machine that wrote it
+    ref_ds.ANTI_LEAKAGE_CONFIG = {'cross_sample_enabled': True, 'cross_sample_prob': 0.5}
+    ds = ref_ds.FlowFinetuneDataset(d, augmentation=True)
+    ds.cross_sample_enabled, ds.cross_sample_prob = True, 0.5
+    arr = {}
+    random.seed(7)
+    torch.manual_seed(7)
+    items = [ds[i] for i in range(len(ds))]
+    for i, it in enumerate(items):
+        for k, v in it.items():
+            if v is not None:
+                arr[f"item{i}/{k}"] = v
+    for name, idx, lim in (("b0", [0, 1, 2], 50), ("b1", [3, 4], 50), ("b2", [0, 5], 1000)):
+        out = ref_ds.collate_fn([{k: (v.clone() if torch.is_tensor(v) else v) for k, v in items[i].items()} for i in idx], lim)
+        for k, v in out.items():
+            arr[f"{name}/{k}"] = v
+    ds2 = ref_ds.FlowFinetuneDataset(d, augmentation=False)
+    ds2.cross_sample_enabled = False
+    for k, v in ds2[2].items():
+        if v is not None:
+            arr[f"plain2/{k}"] = v
+    npz_save(os.path.join(GOLD, "data_path.npz"), **arr)
+
+
 def run_flow_nograd(model, batch, seed):
     jm = ref_joint.JointLLMFlowModel(nn.Identity(), model, 'flow_only')
     torch.manual_seed(seed)
@@ -414,6 +461,8 @@ if __name__ == "__main__":
         gen_tiny()
     if a.only in ("all", "sampler"):
         gen_sampler()
+    if a.only in ("all", "data"):
+        gen_data()
     if a.only in ("all", "train"):
         gen_train()
     if a.only in ("all", "full"):
