@@ -52,7 +52,7 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def build(workload, dtype, device, r, alpha):
+def build(workload, dtype, device, r, alpha, dropout=False):
     from cosyvoice_lora_finetune_framework_amd.flow_model import build_flow_model
     from cosyvoice_lora_finetune_framework_amd.llm_flow_model import JointLLMFlowModel
     from cosyvoice_lora_finetune_framework_amd.llm_model import build_llm_model
@@ -65,14 +65,19 @@ def build(workload, dtype, device, r, alpha):
         flow = build_flow_model(None, 'cpu', numerics=num)
         llm = build_llm_model(None, 'cpu', numerics=num) if workload != 'flow_only' else torch.nn.Identity()
         if workload in ('joint', 'flow_only'):
-            apply_lora_to_model(flow, r=r, lora_alpha=alpha, lora_dropout=0.0, target_modules=JC['flow_lora']['target_modules'])
+            apply_lora_to_model(flow, r=r, lora_alpha=alpha, lora_dropout=JC['flow_lora']['lora_dropout'] if dropout else 0.0,
+                                target_modules=JC['flow_lora']['target_modules'])
         if workload in ('joint', 'llm_only'):
-            apply_lora_to_model(llm, r=r, lora_alpha=alpha, lora_dropout=0.0, target_modules=JC['llm_lora']['target_modules'])
+            apply_lora_to_model(llm, r=r, lora_alpha=alpha, lora_dropout=JC['llm_lora']['lora_dropout'] if dropout else 0.0,
+                                target_modules=JC['llm_lora']['target_modules'])
         if workload == 'llm_only':
             flow.requires_grad_(False)
         jm = JointLLMFlowModel(llm, flow, workload, llm_loss_weight=JC['llm_loss_weight'],
                                flow_loss_weight=JC['flow_loss_weight'])
-    return jm.to(device).eval()      # eval(): dropout off (synthetic throughput run; LoRA dropout p=0)
+    jm = jm.to(device)
+    # default: eval(), dropout off, like the parity fixtures and the CPU baseline; --dropout 1 = the reference's training
+    # regularisation (LoRA dropout 0.15 / 0.05, encoder dropouts 0.1) through the un-fused train-mode path
+    return jm.train() if dropout else jm.eval()
 
 
 def cpu_baseline(jm, workload, T, seconds_budget=30.0):
@@ -138,6 +143,7 @@ def main():
     ap.add_argument("--rank-lora", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", type=int, default=1, help="capture fwd+bwd in a hipGraph (0 = eager launches)")
+    ap.add_argument("--dropout", type=int, default=0, help="1 = train() mode with the reference's LoRA / encoder dropouts (slower, un-fused path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -153,7 +159,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    jm = build(a.workload, dtype, dev, a.rank_lora, 2 * a.rank_lora)
+    jm = build(a.workload, dtype, dev, a.rank_lora, 2 * a.rank_lora, bool(a.dropout))
     opt = FlatAdamW([p for p in jm.parameters() if p.requires_grad], lr=2e-4, weight_decay=0.01, max_grad_norm=1.0)
     B, T = a.batch, a.frames
     batch = jm.prepare_batch(synth_batch([T] * B, seed=1234 + rank), dev)
@@ -259,7 +265,7 @@ def main():
                                    f"CosyVoice-300M dims random-init, {T}-frame x 80-mel clips, "
                                    f"{int(T * 50 * 256 / 22050)} speech tokens, 40 text tokens",
                        "per_gpu_batch": B, "global_batch": world * B, "frames": T, "lora_r": a.rank_lora,
-                       "parallelism": f"dp{world}", "launch": "hipGraph" if graph is not None else "eager",
+                       "parallelism": f"dp{world}", "launch": "hipGraph" if graph is not None else "eager", "dropout": bool(a.dropout),
                        "final_loss": final_loss},
             "roofline": roof, "cpu_baseline": cpu,
         }

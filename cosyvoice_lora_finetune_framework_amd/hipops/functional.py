@@ -270,6 +270,7 @@ class LoraGradSink:
             # ~4 ms / step); with the matrix-core slab kernels at ~3 us the serial order is faster
             side_stream = _os.environ.get('CVFT_SINK_SIDE', '0') != '0'
         self.tasks = []
+        self.streams = {}                 # streams that received slab launches (the LLM / Flow branches may run on two)
         self.keep = []                    # operands of side-stream launches stay alive until the join
         self.side = None
         if side_stream:
@@ -308,19 +309,30 @@ class LoraGradSink:
             P._cvft_part = ws
         return ws
 
+    def _note_stream(self):
+        st = torch.cuda.current_stream()
+        self.streams[st.cuda_stream] = st
+
     def add(self, part: torch.Tensor, grad: torch.Tensor, numel: int, nsplit: int):
         """grad (contiguous, numel) += sum of nsplit contiguous slabs."""
+        self._note_stream()
         self.tasks.append((part.data_ptr(), grad.data_ptr(), 1, numel, numel, numel, nsplit, 0))
 
     def add_block(self, part_ptr: int, grad: torch.Tensor, rows: int, cols: int, pitch: int, stride: int, nsplit: int):
         """grad [rows, cols] += sum over slabs of the [rows, cols] sub-block at part_ptr (row pitch / slab stride in floats)."""
+        self._note_stream()
         self.tasks.append((part_ptr, grad.data_ptr(), rows, cols, pitch, stride, nsplit, 0))
 
     def flush(self):
         if not self.tasks:
             return
+        cur = torch.cuda.current_stream()
         if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            cur.wait_stream(self.side)
+        for h, st in self.streams.items():        # backward of a branch runs on the stream its forward used: join them
+            if h != cur.cuda_stream:
+                cur.wait_stream(st)
+        self.streams = {}
         self.keep = []
         key = tuple(self.tasks)
         ent = LoraGradSink._cache.get(key)

@@ -5,6 +5,9 @@ contract (dict of 0-d tensors ``loss / llm_loss / flow_loss / llm_acc``) and los
 The two sub-model forwards run on the HIP path (llm_model.py / flow_model.py)."""
 from __future__ import annotations
 
+import contextlib
+import os
+
 from typing import Any, Dict, Optional
 
 import torch
@@ -18,7 +21,11 @@ from .hipops import functional as HF
 from .modules import Numerics
 
 
+BRANCH_STREAMS = os.environ.get("CVFT_BRANCH_STREAMS", "1") != "0"      # LLM branch on a second stream (joint mode): 35.9 -> 30.1 ms/step
+
+
 class JointLLMFlowModel(nn.Module):
+    _side = None
     def __init__(self, llm: nn.Module, flow: nn.Module, training_mode: str = 'joint', llm_loss_weight: float = 1.0,
                  flow_loss_weight: float = 1.0, no_prompt_training: bool = True):
         super().__init__()
@@ -42,14 +49,27 @@ class JointLLMFlowModel(nn.Module):
         losses: Dict[str, Any] = {}
         if self.training:
             HF.dropout_begin_step()       # new dropout masks per step (device-side seed: also across hipGraph replays)
+        side = None
+        if self.training_mode == 'joint' and BRANCH_STREAMS and torch.cuda.is_available():
+            # The LLM and the Flow branch share nothing until the loss sum: run the LLM branch on a second stream so its
+            # kernels overlap the estimator's under-filled ones (252-block GEMMs on 256 CUs).  autograd replays each
+            # branch's backward on the stream its forward ran on, so the overlap holds for the whole step; inside a
+            # captured hipGraph this is one fork and one join per direction.
+            if JointLLMFlowModel._side is None:
+                JointLLMFlowModel._side = torch.cuda.Stream()
+            side = JointLLMFlowModel._side
+            side.wait_stream(torch.cuda.current_stream())
         if self.training_mode in ('joint', 'llm_only'):
-            r = self._forward_llm(batch, device)
-            losses['llm_loss'] = r['loss'] * self.llm_loss_weight
-            if 'acc' in r:
-                losses['llm_acc'] = r['acc']
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                r = self._forward_llm(batch, device)
+                losses['llm_loss'] = r['loss'] * self.llm_loss_weight
+                if 'acc' in r:
+                    losses['llm_acc'] = r['acc']
         if self.training_mode in ('joint', 'flow_only'):
             r = self._forward_flow(batch, device, draws)
             losses['flow_loss'] = r['loss'] * self.flow_loss_weight
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         if self.training_mode == 'joint':
             losses['loss'] = losses['llm_loss'] + losses['flow_loss']
         elif self.training_mode == 'llm_only':
