@@ -21,11 +21,12 @@ from .hipops import functional as HF
 from .modules import Numerics
 
 
+BATCH_SPLIT = int(os.environ.get("CVFT_BATCH_SPLIT", "1"))            # sub-batches per branch, each chain on its own stream
 BRANCH_STREAMS = os.environ.get("CVFT_BRANCH_STREAMS", "1") != "0"      # LLM branch on a second stream (joint mode): 35.9 -> 30.1 ms/step
 
 
 class JointLLMFlowModel(nn.Module):
-    _side = None
+    _streams: list = []
     def __init__(self, llm: nn.Module, flow: nn.Module, training_mode: str = 'joint', llm_loss_weight: float = 1.0,
                  flow_loss_weight: float = 1.0, no_prompt_training: bool = True):
         super().__init__()
@@ -45,31 +46,57 @@ class JointLLMFlowModel(nn.Module):
                 m.numerics = num
 
     def forward(self, batch: dict, device, draws: Optional[dict] = None) -> Dict[str, Any]:
-        """llm_flow_model.py:77-107.  `draws` (optional) injects the CFM random draws."""
+        """llm_flow_model.py:77-107.  `draws` (optional) injects the CFM random draws.
+
+        Execution (results unchanged): the LLM and the Flow branch share nothing until the loss sum, and utterances share
+        nothing but the loss denominators -- so the step runs as 2 x BATCH_SPLIT independent chains on separate HIP
+        streams (LLM / Flow x sub-batches).  Most kernels of a chain under-fill the chip (the estimator's GEMMs are 252
+        blocks on 256 CUs) and are latency-bound; concurrent chains fill it.  autograd replays every chain's backward on
+        the stream its forward ran on, so the overlap holds for the whole step, and inside a captured hipGraph it costs
+        one fork and one join per chain and direction.  Sub-batch losses are recombined with their share of the global
+        denominators (frames for the CFM loss, target tokens for the CE loss): the reference's global-batch means."""
         losses: Dict[str, Any] = {}
         if self.training:
             HF.dropout_begin_step()       # new dropout masks per step (device-side seed: also across hipGraph replays)
-        side = None
-        if self.training_mode == 'joint' and BRANCH_STREAMS and torch.cuda.is_available():
-            # The LLM and the Flow branch share nothing until the loss sum: run the LLM branch on a second stream so its
-            # kernels overlap the estimator's under-filled ones (252-block GEMMs on 256 CUs).  autograd replays each
-            # branch's backward on the stream its forward ran on, so the overlap holds for the whole step; inside a
-            # captured hipGraph this is one fork and one join per direction.
-            if JointLLMFlowModel._side is None:
-                JointLLMFlowModel._side = torch.cuda.Stream()
-            side = JointLLMFlowModel._side
-            side.wait_stream(torch.cuda.current_stream())
-        if self.training_mode in ('joint', 'llm_only'):
-            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                r = self._forward_llm(batch, device)
-                losses['llm_loss'] = r['loss'] * self.llm_loss_weight
-                if 'acc' in r:
-                    losses['llm_acc'] = r['acc']
-        if self.training_mode in ('joint', 'flow_only'):
-            r = self._forward_flow(batch, device, draws)
-            losses['flow_loss'] = r['loss'] * self.flow_loss_weight
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+        parts = batch.get('_parts')
+        if parts is None:
+            B = batch['speech_token'].shape[0]
+            n = min(BATCH_SPLIT, B) if torch.cuda.is_available() else 1
+            parts = self._split_parts(batch, device, n) if n > 1 else [dict(batch, _w_llm=1.0, _w_flow=1.0)]
+        do_llm = self.training_mode in ('joint', 'llm_only')
+        do_flow = self.training_mode in ('joint', 'flow_only')
+        chains = [('llm', k) for k in range(len(parts))] * do_llm + [('flow', k) for k in range(len(parts))] * do_flow
+        use_streams = BRANCH_STREAMS and torch.cuda.is_available() and len(chains) > 1
+        cur = torch.cuda.current_stream() if use_streams else None
+        results = {}
+        for ci, (kind, k) in enumerate(reversed(chains)):          # the last chain (flow part 0 ... ) stays on the caller's stream
+            st = None
+            if use_streams and ci < len(chains) - 1:
+                while len(JointLLMFlowModel._streams) <= ci:
+                    JointLLMFlowModel._streams.append(torch.cuda.Stream())
+                st = JointLLMFlowModel._streams[ci]
+                st.wait_stream(cur)
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                part = parts[k]
+                if kind == 'llm':
+                    r = self._forward_llm(part, device)
+                    results[(kind, k)] = (r['loss'] * part['_w_llm'], r['acc'] * part['_w_llm'] if 'acc' in r else None)
+                else:
+                    d = None if draws is None else {n_: v[part['_rows']] if '_rows' in part else v for n_, v in draws.items()}
+                    r = self._forward_flow(part, device, d)
+                    results[(kind, k)] = (r['loss'] * part['_w_flow'], None)
+            if st is not None:
+                results[(kind, k)] = (results[(kind, k)], st)
+        for key, v in list(results.items()):                       # join
+            if isinstance(v[0], tuple):
+                cur.wait_stream(v[1])
+                results[key] = v[0]
+        if do_llm:
+            losses['llm_loss'] = sum(results[('llm', k)][0] for k in range(len(parts))) * self.llm_loss_weight
+            if results[('llm', 0)][1] is not None:
+                losses['llm_acc'] = sum(results[('llm', k)][1] for k in range(len(parts)))
+        if do_flow:
+            losses['flow_loss'] = sum(results[('flow', k)][0] for k in range(len(parts))) * self.flow_loss_weight
         if self.training_mode == 'joint':
             losses['loss'] = losses['llm_loss'] + losses['flow_loss']
         elif self.training_mode == 'llm_only':
@@ -78,15 +105,39 @@ class JointLLMFlowModel(nn.Module):
             losses['loss'] = losses['flow_loss']
         return losses
 
-    def prepare_batch(self, batch: dict, device) -> dict:
-        """Move a collated batch to `device` and attach the host-computed LLM index maps, so that the
-        training step itself performs no host<->device transfers (hipGraph-capturable)."""
+    def _prepare_one(self, batch: dict, device) -> dict:
         out = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
         for k in ('speech_token_len', 'speech_feat_len', 'text_token_len'):
             if k in out:
                 out[k] = out[k].to(torch.int32)
-        if self.training_mode in ('joint', 'llm_only') and hasattr(self.llm, 'prepare_batch'):
+        if self.training_mode in ('joint', 'llm_only') and hasattr(self.llm, 'prepare_batch') and 'text_token' in batch:
             out.update(self.llm.prepare_batch(batch, device))
+        return out
+
+    def _split_parts(self, batch: dict, device, nparts: int):
+        """Host side: contiguous sub-batches + their share of the global loss denominators (frames / target tokens)."""
+        B = batch['speech_token'].shape[0]
+        bounds = [round(i * B / nparts) for i in range(nparts + 1)]
+        feat_len = batch['speech_feat_len'].detach().cpu().double()
+        tgt_len = batch['speech_token_len'].detach().cpu().double() + 1.0          # speech tokens + EOS (llm.py:88-95 targets)
+        parts = []
+        for i in range(nparts):
+            sl = slice(bounds[i], bounds[i + 1])
+            sub = {k: (v[sl] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v)
+                   for k, v in batch.items() if not k.startswith('_')}
+            part = self._prepare_one(sub, device)
+            part['_rows'] = sl
+            part['_w_flow'] = float(feat_len[sl].sum() / feat_len.sum())
+            part['_w_llm'] = float(tgt_len[sl].sum() / tgt_len.sum())
+            parts.append(part)
+        return parts
+
+    def prepare_batch(self, batch: dict, device) -> dict:
+        """Move a collated batch to `device` and attach the host-computed LLM index maps (and the sub-batch split), so
+        that the training step itself performs no host<->device transfers (hipGraph-capturable)."""
+        out = self._prepare_one(batch, device)
+        n = min(BATCH_SPLIT, batch['speech_token'].shape[0])
+        out['_parts'] = self._split_parts(batch, device, n) if n > 1 else [dict(out, _w_llm=1.0, _w_flow=1.0)]
         return out
 
     def _forward_llm(self, batch: dict, device) -> Dict[str, Any]:

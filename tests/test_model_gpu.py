@@ -249,3 +249,33 @@ def test_cfm_sampler_matches_reference(tiny_meta, dtype, tol):
     assert out.dtype == torch.float32 and tuple(out.shape) == tuple(g["out"].shape)
     assert rel(out, g["out"]) < tol, rel(out, g["out"])
     assert rel(cache, g["cache"]) < 1e-6
+
+
+def test_sub_batch_chains_reproduce_global_batch_means(tiny_meta):
+    """JointLLMFlowModel can run LLM / Flow x sub-batches as independent chains on separate streams; the recombined
+    losses (weighted by each part's share of frames / target tokens) and the LoRA gradients equal the one-chain step."""
+    from cosyvoice_lora_finetune_framework_amd import llm_flow_model as J
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    num = Numerics(dtype=torch.float32)
+    flow = build_flow_product(tiny_meta["flow"], DEV, num)
+    llm = build_llm_product(tiny_meta["llm"], DEV, num)
+    jm = J.JointLLMFlowModel(llm, flow, 'joint', 2.0, 1.0).to(DEV).eval()
+    batch = synth_batch([24, 17, 21], text_lens=[7, 5, 6], token_lens=[13, 9, 11], seed=11, text_vocab=100, speech_vocab=50)
+    draws = cfm_draws(3, 24, seed=5)
+    outs = []
+    for split in (1, 2):
+        J.BATCH_SPLIT = split
+        try:
+            for p in jm.parameters():
+                p.grad = None
+            out = jm(batch, DEV, draws)
+            out['loss'].backward()
+            outs.append(([float(out[k]) for k in ('loss', 'llm_loss', 'flow_loss', 'llm_acc')],
+                         {n: p.grad.clone() for n, p in jm.named_parameters() if p.grad is not None}))
+        finally:
+            J.BATCH_SPLIT = 1
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (outs[0][0], outs[1][0])
+    assert set(outs[0][1]) == set(outs[1][1])
+    assert max(rel(outs[1][1][k], outs[0][1][k]) for k in outs[0][1]) < 1e-4
