@@ -376,7 +376,8 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     // (16 / 24 KB per stage), measured on cold operands (tools/bench_cold.py): <= 2 blocks per CU and >= 4 k-tiles ->
     // 4 stages (64x64) / 3 (128x64); a third block per CU -> 3; beyond that 2.  CVFT_GLDS_NS overrides (experiments).
     static const int ns_env = getenv("CVFT_GLDS_NS") ? atoi(getenv("CVFT_GLDS_NS")) : 0;
-    const bool big = t64 >= 1024;
+    static const long big_thr = getenv("CVFT_GLDS_BIG_T64") ? atol(getenv("CVFT_GLDS_BIG_T64")) : 1000;
+    const bool big = t64 >= big_thr;
     const long blocks = big ? (long)((p.M + 127) / 128) * ((p.N + 63) / 64) : t64;
     const int nk = p.K / 64;
     int ns = 2;

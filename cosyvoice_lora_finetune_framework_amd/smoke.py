@@ -38,7 +38,7 @@ def run(device) -> None:
         m.load_state_dict(det_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed))
     sd_flow = {k: v.clone() for k, v in flow.state_dict().items()}
     sd_llm = {k: v.clone() for k, v in llm.state_dict().items()}
-    jm = JointLLMFlowModel(llm, flow, 'joint', llm_loss_weight=2.0, flow_loss_weight=1.0).to(device)
+    jm = JointLLMFlowModel(llm, flow, 'joint', llm_loss_weight=2.0, flow_loss_weight=1.0).to(device).eval()   # dropout off: the oracle has none
     batch = synth_batch([24, 17], text_lens=[7, 5], token_lens=[13, 9], seed=11, text_vocab=100, speech_vocab=50)
     draws = cfm_draws(2, 24, seed=77)
     opt = FlatAdamW([p for p in jm.parameters() if p.requires_grad], lr=1e-3)
