@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) ce_fwd_kernel(int n, int V, const T* __re
     __syncthreads();
     const int amax = min(min(smi[0], smi[1]), min(smi[2], smi[3]));
     float s = 0.f;
-    for (int c = threadIdx.x; c < V; c += 256) s += expf(to_f32(x[c]) - gmx);
+    for (int c = threadIdx.x; c < V; c += 256) s += __expf(to_f32(x[c]) - gmx);
     s = block_sum(s, sm);
     if (threadIdx.x == 0) {
         const float lse = gmx + logf(s);
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) ce_bwd_kernel(int n, int V, const T* __re
     }
     const float g = gscale[0], lse = row_lse[row];
     for (int c = threadIdx.x; c < V; c += 256) {
-        float pr = expf(to_f32(x[c]) - lse);
+        float pr = __expf(to_f32(x[c]) - lse);
         d[c] = from_f32<T>(g * (pr - (c == tg ? 1.f : 0.f)));
     }
 }

@@ -83,15 +83,18 @@ template <> struct Mma<float> {
 __device__ __forceinline__ float act_apply(int act, float x) {
     switch (act) {
         case CVFT_ACT_RELU: return x > 0.f ? x : 0.f;
-        case CVFT_ACT_SILU: return x / (1.f + expf(-x));
+        case CVFT_ACT_SILU: return x / (1.f + __expf(-x));
         case CVFT_ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
         case CVFT_ACT_GELU_TANH: {
             const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
             return 0.5f * x * (1.f + tanhf(k0 * (x + k1 * x * x * x)));
         }
         case CVFT_ACT_MISH: {
-            float sp = x > 20.f ? x : log1pf(expf(x));
-            return x * tanhf(sp);
+            // x * tanh(softplus(x)) with tanh(log(1+e)) = ((1+e)^2 - 1) / ((1+e)^2 + 1) = n / (n + 2), n = e*(e + 2):
+            // one v_exp_f32 instead of expf + log1pf + tanhf (the GroupNorm kernels were VALU-bound on those)
+            if (x > 20.f) return x;
+            const float e = __expf(x), n = e * (e + 2.f);
+            return x * (n / (n + 2.f));
         }
         default: return x;
     }
@@ -100,12 +103,12 @@ __device__ __forceinline__ float act_grad(int act, float x) {
     switch (act) {
         case CVFT_ACT_RELU: return x > 0.f ? 1.f : 0.f;
         case CVFT_ACT_SILU: {
-            float s = 1.f / (1.f + expf(-x));
+            float s = 1.f / (1.f + __expf(-x));
             return s * (1.f + x * (1.f - s));
         }
         case CVFT_ACT_GELU_ERF: {
             float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-            float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+            float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
             return cdf + x * pdf;
         }
         case CVFT_ACT_GELU_TANH: {
@@ -115,9 +118,9 @@ __device__ __forceinline__ float act_grad(int act, float x) {
             return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x2);
         }
         case CVFT_ACT_MISH: {
-            float sp = x > 20.f ? x : log1pf(expf(x));
-            float th = tanhf(sp);
-            float sg = 1.f / (1.f + expf(-x));
+            if (x > 20.f) return 1.f;
+            const float e = __expf(x), n = e * (e + 2.f);
+            const float th = n / (n + 2.f), sg = e / (1.f + e);
             return th + x * (1.f - th * th) * sg;
         }
         default: return 1.f;
