@@ -21,7 +21,26 @@ struct AP {
     T* o; int ldo; float* lse;
     const T* d_o; const float* delta;
     T *dq, *dk, *dv; int ldg;
+    // attention-probability dropout (attention.py:118 `self.dropout(attn)`; DROP instantiations only)
+    float drop_p; const long long* seed; unsigned site;
 };
+
+// keep-scale of score (b, h, i, j): 1/(1-p) or 0.  Counter-based (SplitMix64 finaliser, same as cvft_dropout_add), so
+// forward and both backward kernels re-derive the same mask from (*seed, site, element index).
+__device__ __forceinline__ float attn_keep_scale(unsigned long long key, unsigned long long idx, unsigned thr, float inv) {
+    unsigned long long z = key + idx + 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    return (unsigned)z >= thr ? inv : 0.f;
+}
+__device__ __forceinline__ unsigned long long attn_drop_key(const long long* seed, unsigned site) {
+    unsigned long long z = (unsigned long long)seed[0] ^ ((unsigned long long)site << 32);
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
 
 #define NEG_INF (-__builtin_inff())
 // The per-wave LDS regions (Gw skew buffer, P / dS tiles) are written and read by the SAME wavefront: a wave's LDS
@@ -30,7 +49,7 @@ struct AP {
 #define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // ------------------------------------------------------------------------ forward
-template <typename T, bool REL>
+template <typename T, bool REL, bool DROP = false>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
     typedef AttnCfg<T> A;
     typedef Mma<T> MM;
@@ -53,6 +72,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
     const T* vg = p.v + rowbase * p.ld + h * 64;
     const T* pg = REL ? p.p + h * 64 : nullptr;
     const int lb = p.len ? p.len[b] : L;
+    unsigned long long dkey = 0;
+    unsigned dthr = 0;
+    float dinv = 1.f;
+    if (DROP) {
+        dkey = attn_drop_key(p.seed, p.site);
+        dthr = (unsigned)fminf(4294967295.f, p.drop_p * 4294967296.f);
+        dinv = 1.f / (1.f - p.drop_p);
+    }
 
     int jmax;
     if (REL) {
@@ -163,7 +190,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Pw[((lane >> 4) * 4 + r) * LDK + nt * 16 + (lane & 15)] = from_f32<T>(s[nt][r]);
+            for (int r = 0; r < 4; ++r) {
+                float pv = s[nt][r];
+                if (DROP) {     // the softmax denominator keeps the undropped sum; only the PV operand is masked
+                    const unsigned long long i = q0 + 16 * w + (lane >> 4) * 4 + r, j = j0 + nt * 16 + (lane & 15);
+                    pv *= attn_keep_scale(dkey, (((unsigned long long)b * p.H + h) * L + i) * L + j, dthr, dinv);
+                }
+                Pw[((lane >> 4) * 4 + r) * LDK + nt * 16 + (lane & 15)] = from_f32<T>(pv);
+            }
         WAVE_LDS_SYNC();
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
@@ -189,7 +223,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
 }
 
 // ------------------------------------------------------------------------ backward: dQ
-template <typename T, bool REL>
+template <typename T, bool REL, bool DROP = false>
 __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
     typedef AttnCfg<T> A;
     typedef Mma<T> MM;
@@ -215,6 +249,14 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
     const T* dog = p.d_o + rowbase * p.ldo + h * 64;
     const T* pg = REL ? p.p + h * 64 : nullptr;
     const int lb = p.len ? p.len[b] : L;
+    unsigned long long dkey = 0;
+    unsigned dthr = 0;
+    float dinv = 1.f;
+    if (DROP) {
+        dkey = attn_drop_key(p.seed, p.site);
+        dthr = (unsigned)fminf(4294967295.f, p.drop_p * 4294967296.f);
+        dinv = 1.f / (1.f - p.drop_p);
+    }
 
     int jmax;
     if (REL) {
@@ -319,7 +361,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
                     x += (j < lb ? 0.f : -1.0e10f);
                 }
                 const float pv = valid ? __expf(x - lse_r[r]) : 0.f;
-                const float ds = pv * (dp[nt][r] - del_r[r]) * p.scale;
+                float dpe = dp[nt][r];
+                if (DROP) dpe *= attn_keep_scale(dkey, (((unsigned long long)b * p.H + h) * L + i) * L + j, dthr, dinv);
+                const float ds = pv * (dpe - del_r[r]) * p.scale;
                 Dw[row * LDK + nt * 16 + (lane & 15)] = from_f32<T>(ds);
                 if (REL) Gw[row * LDG + 15 - row + nt * 16 + (lane & 15)] = ds;
             }
@@ -355,10 +399,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
 }
 
 // ------------------------------------------------------------------------ backward: dK, dV
-template <typename T, bool REL>
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) { attn_bwd_dq_body<T, REL>(p, blockIdx.x); }
+template <typename T, bool REL, bool DROP = false>
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) { attn_bwd_dq_body<T, REL, DROP>(p, blockIdx.x); }
 
-template <typename T, bool REL>
+template <typename T, bool REL, bool DROP = false>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AP<T>& p, const int bx) {
     typedef AttnCfg<T> A;
     typedef Mma<T> MM;
@@ -389,6 +433,14 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AP<T>& p, const int bx) 
     const T* dog = p.d_o + rowbase * p.ldo + h * 64;
     const T* pg = REL ? p.p + h * 64 : nullptr;
     const int lb = p.len ? p.len[b] : L;
+    unsigned long long dkey = 0;
+    unsigned dthr = 0;
+    float dinv = 1.f;
+    if (DROP) {
+        dkey = attn_drop_key(p.seed, p.site);
+        dthr = (unsigned)fminf(4294967295.f, p.drop_p * 4294967296.f);
+        dinv = 1.f / (1.f - p.drop_p);
+    }
     const int lb_eff = REL ? min(L, lb) : ((lb >= 1) ? min(L, lb) : L);
     const int jw = j0 + 16 * w;
 
@@ -496,8 +548,10 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AP<T>& p, const int bx) 
                         x += (j < lb ? 0.f : -1.0e10f);
                     }
                     const float pv = valid ? __expf(x - lse_s[il]) : 0.f;
-                    const float ds = pv * (dp[r] - del_s[il]) * p.scale;
-                    Pw[(lane & 15) * LDK + il] = from_f32<T>(pv);
+                    float ks = 1.f;
+                    if (DROP) ks = attn_keep_scale(dkey, (((unsigned long long)b * p.H + h) * L + i) * L + j, dthr, dinv);
+                    const float ds = pv * (dp[r] * ks - del_s[il]) * p.scale;
+                    Pw[(lane & 15) * LDK + il] = from_f32<T>(pv * ks);
                     Dw[(lane & 15) * LDK + il] = from_f32<T>(ds);
                     csum += ds;
                 }
@@ -541,8 +595,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AP<T>& p, const int bx) 
     }
 }
 
-template <typename T, bool REL>
-__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) { attn_bwd_dkv_body<T, REL>(p, blockIdx.x); }
+template <typename T, bool REL, bool DROP = false>
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) { attn_bwd_dkv_body<T, REL, DROP>(p, blockIdx.x); }
 
 // ------------------------------------------------------------------------ host side
 template <typename T> static size_t smem_fwd(bool rel) {
@@ -582,8 +636,16 @@ static int set_smem(K kernel, size_t bytes, const char* name) {
 template <typename T, bool REL>
 static int launch_fwd(const AP<T>& p, hipStream_t st) {
     size_t sm = smem_fwd<T>(REL);
-    if (set_smem(attn_fwd_kernel<T, REL>, sm, "attn_fwd")) return -2;
     dim3 grid((p.L + 63) / 64, p.H, p.B);
+    if constexpr (REL) {
+        if (p.drop_p > 0.f) {
+            if (set_smem(attn_fwd_kernel<T, true, true>, sm, "attn_fwd")) return -2;
+            hipLaunchKernelGGL((attn_fwd_kernel<T, true, true>), grid, dim3(256), sm, st, p);
+            CVFT_LAUNCH_CHECK("attn_fwd");
+            return 0;
+        }
+    }
+    if (set_smem(attn_fwd_kernel<T, REL>, sm, "attn_fwd")) return -2;
     hipLaunchKernelGGL((attn_fwd_kernel<T, REL>), grid, dim3(256), sm, st, p);
     CVFT_LAUNCH_CHECK("attn_fwd");
     return 0;
@@ -596,9 +658,20 @@ static int launch_bwd(const AP<T>& p, float* delta, const T* o, hipStream_t st) 
     CVFT_LAUNCH_CHECK("attn_delta");
     size_t s1 = smem_dq<T>(REL), s2 = smem_dkv<T>(REL);
     // (one merged launch for both roles was measured slower than two launches: 36.8 vs 36.5 ms/step)
+    dim3 grid((p.L + 63) / 64, p.H, p.B);
+    if constexpr (REL) {
+        if (p.drop_p > 0.f) {
+            if (set_smem(attn_bwd_dq_kernel<T, true, true>, s1, "attn_bwd_dq")) return -2;
+            if (set_smem(attn_bwd_dkv_kernel<T, true, true>, s2, "attn_bwd_dkv")) return -2;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, true, true>), grid, dim3(256), s1, st, p);
+            CVFT_LAUNCH_CHECK("attn_bwd_dq");
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true, true>), grid, dim3(256), s2, st, p);
+            CVFT_LAUNCH_CHECK("attn_bwd_dkv");
+            return 0;
+        }
+    }
     if (set_smem(attn_bwd_dq_kernel<T, REL>, s1, "attn_bwd_dq")) return -2;
     if (set_smem(attn_bwd_dkv_kernel<T, REL>, s2, "attn_bwd_dkv")) return -2;
-    dim3 grid((p.L + 63) / 64, p.H, p.B);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, REL>), grid, dim3(256), s1, st, p);
     CVFT_LAUNCH_CHECK("attn_bwd_dq");
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, REL>), grid, dim3(256), s2, st, p);
@@ -624,6 +697,7 @@ static AP<T> make_ap(int B, int H, int L, const void* q, const void* k, const vo
     a.B = B; a.H = H; a.L = L; a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.ld = ld;
     a.p = (const T*)pp; a.ldp = ldp; a.bu = bu; a.bv = bv; a.len = len; a.causal = causal; a.scale = scale;
     a.o = nullptr; a.ldo = 0; a.lse = nullptr; a.d_o = nullptr; a.delta = nullptr; a.dq = a.dk = a.dv = nullptr; a.ldg = 0;
+    a.drop_p = 0.f; a.seed = nullptr; a.site = 0;
     return a;
 }
 
@@ -664,8 +738,9 @@ extern "C" int cvft_attn_bias_bwd(int dtype, int B, int H, int T_, const void* q
 extern "C" int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
                                     const void* pp, int ldp, const float* bias_u, const float* bias_v,
                                     const int32_t* len, int causal, float scale, void* o, int ldo, float* lse,
-                                    void* stream) {
+                                    float drop_p, const int64_t* drop_seed, unsigned drop_site, void* stream) {
     if (check_common("cvft_attn_relpos_fwd", dtype, B, H, L, ld, ldo, q, k, v)) return -1;
+    CVFT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || drop_seed), "cvft_attn_relpos_fwd: bad dropout args");
     int vec = dtype == CVFT_BF16 ? 8 : 4;
     CVFT_CHECK_ARG(pp && bias_u && bias_v && o && lse && ldp >= H * 64 && ldp % vec == 0 && (((uintptr_t)pp) & 15) == 0,
                    "cvft_attn_relpos_fwd: bad args");
@@ -673,10 +748,12 @@ extern "C" int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* 
     if (dtype == CVFT_F32) {
         AP<float> a = make_ap<float>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
         a.o = (float*)o; a.ldo = ldo; a.lse = lse;
+        a.drop_p = drop_p; a.seed = (const long long*)drop_seed; a.site = drop_site;
         return launch_fwd<float, true>(a, st);
     }
     AP<bf16_t> a = make_ap<bf16_t>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
     a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse;
+    a.drop_p = drop_p; a.seed = (const long long*)drop_seed; a.site = drop_site;
     return launch_fwd<bf16_t, true>(a, st);
 }
 
@@ -684,8 +761,9 @@ extern "C" int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* 
                                     const void* pp, int ldp, const float* bias_u, const float* bias_v,
                                     const int32_t* len, int causal, float scale, const void* o, const void* d_o, int ldo,
                                     const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg, float* dp,
-                                    void* stream) {
+                                    float drop_p, const int64_t* drop_seed, unsigned drop_site, void* stream) {
     if (check_common("cvft_attn_relpos_bwd", dtype, B, H, L, ld, ldo, q, k, v)) return -1;
+    CVFT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || drop_seed), "cvft_attn_relpos_bwd: bad dropout args");
     int vec = dtype == CVFT_BF16 ? 8 : 4;
     CVFT_CHECK_ARG(pp && bias_u && bias_v && ldp >= H * 64 && ldp % vec == 0 && (((uintptr_t)pp) & 15) == 0,
                    "cvft_attn_relpos_bwd: bad p");
@@ -697,10 +775,12 @@ extern "C" int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* 
         AP<float> a = make_ap<float>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
         a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const float*)d_o; a.delta = delta;
         a.dq = (float*)dq; a.dk = (float*)dk; a.dv = (float*)dv; a.ldg = ldg;
+        a.drop_p = drop_p; a.seed = (const long long*)drop_seed; a.site = drop_site;
         return launch_bwd<float, true>(a, delta, (const float*)o, st);
     }
     AP<bf16_t> a = make_ap<bf16_t>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
     a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const bf16_t*)d_o; a.delta = delta;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg;
+    a.drop_p = drop_p; a.seed = (const long long*)drop_seed; a.site = drop_site;
     return launch_bwd<bf16_t, true>(a, delta, (const bf16_t*)o, st);
 }

@@ -985,16 +985,19 @@ def attn_bias(q, k, v, B: int, H: int, T: int, klen, scale: float):
 
 class AttnRelPosFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, p, bias_u, bias_v, B: int, H: int, L: int, length, causal: bool, scale: float):
+    def forward(ctx, q, k, v, p, bias_u, bias_v, B: int, H: int, L: int, length, causal: bool, scale: float,
+                drop_p: float = 0.0, drop_site: int = 0):
         assert q.stride(1) == 1 and q.stride(0) == k.stride(0) == v.stride(0)
         assert p.shape[0] == 2 * L - 1 and p.stride(1) == 1
+        seed = _DROPOUT["seed"] if drop_p > 0 else None
         o = torch.empty((B * L, H * 64), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
         check(lib().cvft_attn_relpos_fwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
                                          ptr(bias_u), ptr(bias_v), ptr(length), int(causal), scale, ptr(o), o.stride(0),
-                                         ptr(lse), stream()), "cvft_attn_relpos_fwd")
+                                         ptr(lse), float(drop_p), ptr(seed), drop_site, stream()), "cvft_attn_relpos_fwd")
         ctx.save_for_backward(q, k, v, p, bias_u, bias_v, o, lse)
         ctx.args = (B, H, L, length, causal, scale)
+        ctx.drop = (float(drop_p), seed, drop_site)
         return o
 
     @staticmethod
@@ -1009,13 +1012,21 @@ class AttnRelPosFn(torch.autograd.Function):
         delta = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
         check(lib().cvft_attn_relpos_bwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
                                          ptr(bu), ptr(bv), ptr(length), int(causal), scale, ptr(o), ptr(do), o.stride(0),
-                                         ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), None, stream()),
+                                         ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), None,
+                                         ctx.drop[0], ptr(ctx.drop[1]), ctx.drop[2], stream()),
               "cvft_attn_relpos_bwd")
-        return dq, dk, dv, None, None, None, None, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None, None, None
 
 
-def attn_relpos(q, k, v, p, bias_u, bias_v, B: int, H: int, L: int, length, causal: bool, scale: float):
-    return AttnRelPosFn.apply(q, k, v, p, bias_u, bias_v, B, H, L, length, causal, scale)
+def attn_relpos(q, k, v, p, bias_u, bias_v, B: int, H: int, L: int, length, causal: bool, scale: float, dropout_p: float = 0.0):
+    """dropout_p > 0: attention-probability dropout (attention.py:118), mask re-derived in backward (device-side seed)."""
+    site = 0
+    if dropout_p > 0:
+        if _DROPOUT["seed"] is None:
+            dropout_begin_step()
+        _DROPOUT["site"] += 1
+        site = _DROPOUT["site"]
+    return AttnRelPosFn.apply(q, k, v, p, bias_u, bias_v, B, H, L, length, causal, scale, dropout_p, site)
 
 
 # ---------------------------------------------------------------------------------

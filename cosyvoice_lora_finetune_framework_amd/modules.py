@@ -430,8 +430,7 @@ class LinearNoSubsampling(nn.Module):
 
 
 class RelPositionMultiHeadedAttention(nn.Module):
-    """attention.py:200-330 parameters; compute = fused rel-pos flash kernel."""
-    _warned = False
+    """attention.py:200-330 parameters; compute = fused rel-pos flash kernel (incl. the attention-probability dropout)."""
 
     def __init__(self, n_head, n_feat, dropout_rate, key_bias=True):
         super().__init__()
@@ -453,12 +452,8 @@ class RelPositionMultiHeadedAttention(nn.Module):
     def forward(self, y, residual, pos_emb, B, L, length, causal, out_dropout: float = 0.0):
         q, k, v = hip_qkv(self.linear_q, self.linear_k, self.linear_v, y)
         p = hip_linear(self.linear_pos, pos_emb)
-        if self.training and self.dropout_rate > 0 and not RelPositionMultiHeadedAttention._warned:
-            RelPositionMultiHeadedAttention._warned = True
-            warnings.warn("attention-probability dropout (attention.py:118, rate %.2f) is not applied by the fused attention "
-                          "kernel; all other encoder dropouts are" % self.dropout_rate)
         o = HF.attn_relpos(q, k, v, p, _f32(self.pos_bias_u), _f32(self.pos_bias_v), B, self.h, L, length, causal,
-                           1.0 / math.sqrt(self.d_k))
+                           1.0 / math.sqrt(self.d_k), dropout_p=self.dropout_rate if self.training else 0.0)
         if out_dropout > 0:       # x = residual + dropout(linear_out(.))  (encoder_layer.py:95 / 205)
             return HF.dropout_add(hip_linear(self.linear_out, o), out_dropout, residual)
         return hip_linear(self.linear_out, o, residual=residual)

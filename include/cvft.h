@@ -172,12 +172,17 @@ int cvft_attn_bias_bwd(int dtype, int B, int H, int T, const void* q, const void
  * ------------------------------------------------------------------------------- */
 int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
                          const void* p, int ldp, const float* bias_u, const float* bias_v,
-                         const int32_t* len, int causal, float scale, void* o, int ldo, float* lse, void* stream);
+                         const int32_t* len, int causal, float scale, void* o, int ldo, float* lse,
+                         float drop_p, const int64_t* drop_seed, unsigned drop_site, void* stream);
+/* drop_p > 0: attention-probability dropout (attention.py:118): the PV operand is masked / scaled by 1/(1-p), the softmax
+ * denominator is not; the mask is a function of (*drop_seed (device int64), drop_site, b, h, i, j) and is re-derived by
+ * the backward entry point given the same three values. */
 int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
                          const void* p, int ldp, const float* bias_u, const float* bias_v,
                          const int32_t* len, int causal, float scale, const void* o, const void* d_o, int ldo,
                          const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg,
-                         float* dp /*[2L-1][H*64] fp32 accum or NULL*/, void* stream);
+                         float* dp /*[2L-1][H*64] fp32 accum or NULL*/,
+                         float drop_p, const int64_t* drop_seed, unsigned drop_site, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Small fused ops.

@@ -585,3 +585,59 @@ def test_lora_dropout_side_path_matches_torch(dtype, act):
     tol = 3e-2 if dtype == torch.bfloat16 else 1e-4
     for name, u, w in zip(("y", "dx", "dres", "dA", "dB"), got, ref):
         assert rel(u, w) < tol, (name, rel(u, w))
+
+
+def _attn_keep_scale_host(seed: int, site: int, B: int, H: int, L: int, p: float) -> torch.Tensor:
+    """Host replica of attention.hip attn_keep_scale / attn_drop_key (SplitMix64 finaliser) -> [B, H, L, L] of {0, 1/(1-p)}."""
+    import numpy as np
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mix(z):
+        z = (z + np.uint64(0x9e3779b97f4a7c15)) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & M
+        return z ^ (z >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        key = mix(np.uint64(seed) ^ (np.uint64(site) << np.uint64(32)))
+        idx = np.arange(B * H * L * L, dtype=np.uint64)
+        u = (mix(key + idx) & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+    thr = min(4294967295.0, float(np.float32(p) * np.float32(4294967296.0)))
+    keep = u >= np.uint64(int(thr))
+    return torch.from_numpy(keep.reshape(B, H, L, L).astype(np.float64)) / (1.0 - float(np.float32(p)))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("causal", [False, True])
+def test_attn_relpos_probability_dropout(dtype, causal):
+    """attention.py:118 `self.dropout(attn)`: the fused kernels mask the PV operand (not the softmax denominator) with a
+    counter-based mask; forward and backward must agree with torch math that uses the SAME mask (replicated on the host)."""
+    from oracle import ref_math as R
+    HF = HFmod()
+    B, H, L, lens, pdrop = 2, 2, 70, [70, 41], 0.1
+    d = H * 64
+    qkv = q(rnd(B, L, 3 * d, seed=1), dtype)
+    p = q(rnd(2 * L - 1, d, seed=2), dtype)
+    bu, bv = 0.3 * rnd(H, 64, seed=3), 0.3 * rnd(H, 64, seed=4)
+    gy = q(rnd(B, L, d, seed=5), dtype)
+    qd = qkv.reshape(B * L, -1).to(DEV, dtype).requires_grad_(True)
+    HF.dropout_begin_step()
+    o = HF.attn_relpos(qd[:, :d], qd[:, d:2 * d], qd[:, 2 * d:], p.to(DEV, dtype), bu.to(DEV), bv.to(DEV), B, H, L,
+                       torch.tensor(lens, dtype=torch.int32, device=DEV), causal, 0.125, dropout_p=pdrop)
+    o.backward(gy.reshape(B * L, -1).to(DEV, dtype))
+    seed, site = int(HF._DROPOUT["seed"].item()), HF._DROPOUT["site"]
+    ks = _attn_keep_scale_host(seed, site, B, H, L, pdrop)
+    assert abs(float((ks > 0).double().mean()) - (1 - pdrop)) < 0.02
+    qr = qkv.double().requires_grad_(True)
+    qq, kk, vv = (t.reshape(B, L, H, 64) for t in qr.split(d, dim=-1))
+    pp = p.double().view(1, -1, H, 64).transpose(1, 2)
+    ac = (qq + bu.double()).transpose(1, 2) @ kk.transpose(1, 2).transpose(-1, -2)
+    bd = R.rel_shift((qq + bv.double()).transpose(1, 2) @ pp.transpose(-1, -2))
+    mask = _masks(lens, L).bool().unsqueeze(1)
+    if causal:
+        mask = mask & torch.tril(torch.ones(L, L, dtype=torch.bool)).unsqueeze(0)
+    mm = mask.unsqueeze(1).eq(0)
+    at = torch.softmax(((ac + bd) / 8.0).masked_fill(mm, -float("inf")), -1).masked_fill(mm, 0.0)
+    orf = ((at * ks) @ vv.transpose(1, 2)).transpose(1, 2).reshape(B, L, d)
+    orf.backward(gy.double())
+    assert rel(o.reshape(B, L, -1), orf) < TOL[dtype]
+    assert rel(qd.grad.reshape(B, L, -1), qr.grad) < TOL[dtype] * 3
