@@ -65,10 +65,10 @@ def build(workload, dtype, device, r, alpha, dropout=False):
         flow = build_flow_model(None, 'cpu', numerics=num)
         llm = build_llm_model(None, 'cpu', numerics=num) if workload != 'flow_only' else torch.nn.Identity()
         if workload in ('joint', 'flow_only'):
-            apply_lora_to_model(flow, r=r, lora_alpha=alpha, lora_dropout=JC['flow_lora']['lora_dropout'] if dropout else 0.0,
+            apply_lora_to_model(flow, r=r, lora_alpha=alpha, lora_dropout=JC['flow_lora']['lora_dropout'] if dropout in (1, 2) else 0.0,
                                 target_modules=JC['flow_lora']['target_modules'])
         if workload in ('joint', 'llm_only'):
-            apply_lora_to_model(llm, r=r, lora_alpha=alpha, lora_dropout=JC['llm_lora']['lora_dropout'] if dropout else 0.0,
+            apply_lora_to_model(llm, r=r, lora_alpha=alpha, lora_dropout=JC['llm_lora']['lora_dropout'] if dropout in (1, 2) else 0.0,
                                 target_modules=JC['llm_lora']['target_modules'])
         if workload == 'llm_only':
             flow.requires_grad_(False)
@@ -77,6 +77,12 @@ def build(workload, dtype, device, r, alpha, dropout=False):
     jm = jm.to(device)
     # default: eval(), dropout off, like the parity fixtures and the CPU baseline; --dropout 1 = the reference's training
     # regularisation (LoRA dropout 0.15 / 0.05, encoder dropouts 0.1) through the un-fused train-mode path
+    if dropout == 2:          # LoRA dropout only (diagnostic): encoder dropouts off
+        for m in jm.modules():
+            if hasattr(m, 'dropout_rate'):
+                m.dropout_rate = 0.0
+            if hasattr(m, 'embed') and hasattr(m.embed, 'out'):
+                m.embed.out[2].p = 0.0
     return jm.train() if dropout else jm.eval()
 
 
@@ -143,7 +149,7 @@ def main():
     ap.add_argument("--rank-lora", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", type=int, default=1, help="capture fwd+bwd in a hipGraph (0 = eager launches)")
-    ap.add_argument("--dropout", type=int, default=0, help="1 = train() mode with the reference's LoRA / encoder dropouts (slower, un-fused path)")
+    ap.add_argument("--dropout", type=int, default=0, help="1 = train() mode with the reference's LoRA / encoder dropouts (slower, un-fused path); 2 / 3 = LoRA / encoder dropouts only (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -159,7 +165,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    jm = build(a.workload, dtype, dev, a.rank_lora, 2 * a.rank_lora, bool(a.dropout))
+    jm = build(a.workload, dtype, dev, a.rank_lora, 2 * a.rank_lora, a.dropout)
     opt = FlatAdamW([p for p in jm.parameters() if p.requires_grad], lr=2e-4, weight_decay=0.01, max_grad_norm=1.0)
     B, T = a.batch, a.frames
     batch = jm.prepare_batch(synth_batch([T] * B, seed=1234 + rank), dev)

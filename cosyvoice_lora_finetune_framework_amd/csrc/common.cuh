@@ -159,6 +159,26 @@ template <int N> __device__ __forceinline__ void act_grad_mul_vec(int act, float
     }
 }
 
+// ---------------------------------------------------------------- counter-based dropout masks
+// keep(i) for element i of a tensor is a pure function of (*seed, site, i): SplitMix64 finaliser on a 64-bit counter,
+// 4 x 32 random bits per group of 4 consecutive elements.  Every kernel that needs the mask of a (seed, site) pair
+// (cvft_dropout_add, the dropout-skinny product, the LoRA side dgrad) calls these, so they all see the same mask.
+__device__ __forceinline__ unsigned long long cvft_mix64(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned long long cvft_drop_key(const long long* seed, unsigned site) {
+    return cvft_mix64((unsigned long long)seed[0] ^ ((unsigned long long)site << 32));
+}
+__device__ __forceinline__ unsigned cvft_drop_thr(float p) { return (unsigned)fminf(4294967295.f, p * 4294967296.f); }
+// keep flags of elements 4g .. 4g+3
+__device__ __forceinline__ void cvft_keep4(unsigned long long key, unsigned long long g, unsigned thr, bool (&k)[4]) {
+    const unsigned long long r0 = cvft_mix64(key + 2 * g), r1 = cvft_mix64(key + 2 * g + 1);
+    k[0] = (unsigned)r0 >= thr; k[1] = (unsigned)(r0 >> 32) >= thr; k[2] = (unsigned)r1 >= thr; k[3] = (unsigned)(r1 >> 32) >= thr;
+}
+
 // ---------------------------------------------------------------- reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -488,27 +488,21 @@ extern "C" int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, voi
 // storing a mask tensor, and a captured hipGraph gets fresh masks on every replay because *seed lives on the device.
 // Not torch's Philox stream: equality with the reference is statistical (keep rate, scale), as for any RNG change.
 // ------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long cvft_mix64(unsigned long long z) {
-    z += 0x9e3779b97f4a7c15ULL;
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-    return z ^ (z >> 31);
-}
 template <typename T>
 __global__ void dropout_add_kernel(size_t n, const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, float p,
                                    const long long* __restrict__ seed, unsigned site) {
-    const unsigned long long key = cvft_mix64((unsigned long long)seed[0] ^ ((unsigned long long)site << 32));
-    const unsigned thr = (unsigned)fminf(4294967295.f, p * 4294967296.f);     // keep when u32 >= thr
+    const unsigned long long key = cvft_drop_key(seed, site);
+    const unsigned thr = cvft_drop_thr(p);                                    // keep when u32 >= thr
     const float scale = 1.f / (1.f - p);
     const size_t n4 = (n + 3) / 4;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (size_t)gridDim.x * blockDim.x) {
-        const unsigned long long r0 = cvft_mix64(key + 2 * g), r1 = cvft_mix64(key + 2 * g + 1);
-        const unsigned u[4] = {(unsigned)r0, (unsigned)(r0 >> 32), (unsigned)r1, (unsigned)(r1 >> 32)};
+        bool kp[4];
+        cvft_keep4(key, g, thr, kp);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const size_t i = 4 * g + e;
             if (i >= n) break;
-            float v = u[e] >= thr ? to_f32(x[i]) * scale : 0.f;
+            float v = kp[e] ? to_f32(x[i]) * scale : 0.f;
             if (res) v += to_f32(res[i]);
             y[i] = from_f32<T>(v);
         }
@@ -527,5 +521,79 @@ extern "C" int cvft_dropout_add(int dtype, int64_t n, const void* x, const void*
         hipLaunchKernelGGL((dropout_add_kernel<bf16_t>), dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (size_t)n, (const bf16_t*)x,
                            (const bf16_t*)residual, (bf16_t*)y, p, (const long long*)seed, site);
     CVFT_LAUNCH_CHECK("cvft_dropout_add");
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------
+// LoRA side dgrad under lora_dropout (lora.py:70-73 backward):  the side path saw drop(x), so its input gradient is
+//   out[m,k] = dx[m,k] + sum_t keep_t(m*K + k)/(1-p) * sum_{j<16} V[m,16t+j] * A[16t+j][k]
+// (t = adapters stacked on this input: 1, or 3 for q|k|v, each with its own mask site).  Memory-bound: one pass over
+// [M,K]; A slice and V rows staged in LDS; masks from the shared counter-based generator.
+// ------------------------------------------------------------------------------
+template <int RT>
+__global__ void __launch_bounds__(256) lora_side_dgrad_kernel(int M, int K, const bf16_t* __restrict__ V, int ldv,
+                                                              const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ dx,
+                                                              int ldi, bf16_t* __restrict__ out, int ldo, float p,
+                                                              const long long* __restrict__ seed, uint4 sites) {
+    constexpr int R = 16 * RT;
+    __shared__ float As[R][64 + 1];
+    __shared__ float Vs[64][R + 1];
+    const int k0 = blockIdx.x * 64, m0 = blockIdx.y * 64, tid = threadIdx.x;
+    for (int e = tid; e < R * 64; e += 256) {
+        const int j = e / 64, c = e % 64;
+        As[j][c] = (k0 + c < K) ? to_f32(A[(size_t)j * lda + k0 + c]) : 0.f;
+    }
+    for (int e = tid; e < 64 * R; e += 256) {
+        const int r = e / R, j = e % R;
+        Vs[r][j] = (m0 + r < M) ? to_f32(V[(size_t)(m0 + r) * ldv + j]) : 0.f;
+    }
+    __syncthreads();
+    const unsigned thr = cvft_drop_thr(p);
+    const float scale = 1.f / (1.f - p);
+    const unsigned st[4] = {sites.x, sites.y, sites.z, sites.w};
+    unsigned long long keys[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) keys[t] = cvft_drop_key(seed, st[t]);
+    const int cg = tid & 15, rr = tid >> 4;                       // 16 column groups of 4 x 16 row slots
+    const int kk = k0 + cg * 4;
+    if (kk >= K) return;
+    for (int i = 0; i < 4; ++i) {
+        const int r = rr + 16 * i, m = m0 + r;
+        if (m >= M) break;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            bool kp[4];
+            cvft_keep4(keys[t], ((unsigned long long)m * K + kk) >> 2, thr, kp);
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = Vs[r][16 * t + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[e] += v * As[16 * t + j][cg * 4 + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += kp[e] ? part[e] * scale : 0.f;
+        }
+        const bf16x4 d = *reinterpret_cast<const bf16x4*>(dx + (size_t)m * ldi + kk);
+        bf16x4 o = {(bf16_t)((float)d[0] + acc[0]), (bf16_t)((float)d[1] + acc[1]), (bf16_t)((float)d[2] + acc[2]), (bf16_t)((float)d[3] + acc[3])};
+        *reinterpret_cast<bf16x4*>(out + (size_t)m * ldo + kk) = o;
+    }
+}
+extern "C" int cvft_lora_side_dgrad(int M, int K, int R, const void* V, int ldv, const void* A, int lda, const void* dx, int ldi,
+                                    void* out, int ldo, float p, const int64_t* seed, const unsigned* sites, void* stream) {
+    CVFT_CHECK_ARG(M > 0 && K > 0 && K % 4 == 0 && (R == 16 || R == 48) && V && A && dx && out && seed && sites && ldv >= R && lda >= K &&
+                   ldi >= K && ldo >= K && ldi % 4 == 0 && ldo % 4 == 0 && p > 0.f && p < 1.f &&
+                   (((uintptr_t)dx | (uintptr_t)out) & 7) == 0, "cvft_lora_side_dgrad: bad args (bf16, K %% 4 == 0, R in {16, 48})");
+    dim3 grid((K + 63) / 64, (M + 63) / 64);
+    uint4 st = make_uint4(sites[0], R > 16 ? sites[1] : 0u, R > 16 ? sites[2] : 0u, 0u);
+    if (R == 16)
+        hipLaunchKernelGGL((lora_side_dgrad_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, M, K, (const bf16_t*)V, ldv, (const bf16_t*)A, lda,
+                           (const bf16_t*)dx, ldi, (bf16_t*)out, ldo, p, (const long long*)seed, st);
+    else
+        hipLaunchKernelGGL((lora_side_dgrad_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, M, K, (const bf16_t*)V, ldv, (const bf16_t*)A, lda,
+                           (const bf16_t*)dx, ldi, (bf16_t*)out, ldo, p, (const long long*)seed, st);
+    CVFT_LAUNCH_CHECK("cvft_lora_side_dgrad");
     return 0;
 }

@@ -30,7 +30,7 @@ struct RankProb {             // one gradient product: slabs of  Rk^T Wd  ([r, C
     int Cn; const bf16_t* Wd; int ldw; const bf16_t* Rk; int ldr; float* out; int ldo; int transpose_out;
     size_t part_stride; int rows_per_block;
 };
-struct RankPair { RankProb p[2]; };
+struct RankPair { RankProb p[4]; };      // up to four problems per launch (blockIdx.z)
 
 // blockIdx.z selects the problem: a LoRA layer's dA and dB (same row count M, same rank) go out as ONE launch.
 template <int RB>
@@ -202,7 +202,7 @@ int lora_rank_mfma_launch(int M, int Cn, int r, const void* Wd, int ldw, const v
     if (!rank_ok(Cn, r, Wd, ldw, Rk, ldr, part, rows_per_block)) return 1;
     RankPair pp;
     pp.p[0] = make_prob(Cn, r, Wd, ldw, Rk, ldr, part, transpose_out, rows_per_block);
-    pp.p[1] = pp.p[0];
+    pp.p[1] = pp.p[2] = pp.p[3] = pp.p[0];
     rank_launch(M, r, pp, 1, st);
     return 0;
 }
@@ -218,7 +218,25 @@ extern "C" int cvft_lora_rank_partial_pair(int M, int r, int K, const void* X, i
     RankPair pp;
     pp.p[0] = make_prob(K, r, X, ldx, V, ldv, partA, 0, rpbA);
     pp.p[1] = make_prob(N, r, dY, ldy, U, ldu, partB, 1, rpbB);
+    pp.p[2] = pp.p[3] = pp.p[0];
     rank_launch(M, r, pp, 2, (hipStream_t)stream);
     CVFT_LAUNCH_CHECK("cvft_lora_rank_partial_pair");
+    return 0;
+}
+
+// Up to four slab products of the same row count M and rank r in one launch (the three dA of stacked q|k|v adapters
+// under lora_dropout have three different dropped inputs).
+extern "C" int cvft_lora_rank_partial_multi(int M, int r, int n, const cvft_rank_prob* probs, void* stream) {
+    CVFT_CHECK_ARG(M > 0 && n >= 1 && n <= 4 && probs, "cvft_lora_rank_partial_multi: 1 <= n <= 4");
+    RankPair pp;
+    for (int i = 0; i < n; ++i) {
+        const cvft_rank_prob& q = probs[i];
+        CVFT_CHECK_ARG(q.Wd && q.Rk && q.part && rank_ok(q.C, r, q.Wd, q.ldw, q.Rk, q.ldr, q.part, q.rows_per_block),
+                       "cvft_lora_rank_partial_multi: problem %d: bf16 operands 16-byte aligned, widths %% 8 == 0, r in {16,32,48,64}", i);
+        pp.p[i] = make_prob(q.C, r, q.Wd, q.ldw, q.Rk, q.ldr, q.part, q.transpose_out, q.rows_per_block);
+    }
+    for (int i = n; i < 4; ++i) pp.p[i] = pp.p[0];
+    rank_launch(M, r, pp, n, (hipStream_t)stream);
+    CVFT_LAUNCH_CHECK("cvft_lora_rank_partial_multi");
     return 0;
 }

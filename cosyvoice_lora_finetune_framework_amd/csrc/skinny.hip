@@ -104,3 +104,117 @@ int skinny_launch(const GP<bf16_t>& p, hipStream_t st) {
     CVFT_LAUNCH_CHECK("cvft_gemm");
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------
+// The same product on a DROPPED input (lora.py:70-73 in train mode):  C[:, 16t:16t+16] = alpha/(1-p) * drop_t(X) . A_t^T,
+// one mask site per rank tile t (the stacked q|k|v adapters each have their own nn.Dropout).  The mask is applied to
+// the X fragments in registers (bitwise AND; the 1/(1-p) scale rides in alpha), so drop(x) is never materialised.
+// ------------------------------------------------------------------------------
+template <int RB, int MT, int KS>
+__global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const bf16_t* __restrict__ X, int ldx,
+                                                             const bf16_t* __restrict__ A, int lda, float alpha,
+                                                             bf16_t* __restrict__ C, int ldc, float p,
+                                                             const long long* __restrict__ seed, uint4 sites) {
+    __shared__ __attribute__((aligned(16))) float red[4][MT][RB][16][17];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
+    const int m0 = blockIdx.x * 16 * MT;
+    const int kper = ((K / 32 + 7) / 8) * 32;
+    const int kb = w * kper, ke = min(K, kb + kper);
+    const unsigned thr = cvft_drop_thr(p);
+    const unsigned st[4] = {sites.x, sites.y, sites.z, sites.w};
+    unsigned long long keys[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) keys[j] = cvft_drop_key(seed, st[j]);
+    f32x4 acc[MT][RB];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int j = 0; j < RB; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int rows[MT];
+    const bf16_t* xp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        rows[t] = min(m0 + t * 16 + l15, M - 1);
+        xp[t] = X + (size_t)rows[t] * ldx + kg * 8;
+    }
+    const bf16_t* ap = A + (size_t)l15 * lda + kg * 8;
+    for (int k0 = kb; k0 < ke; k0 += 32 * KS) {
+        uint4 xv[KS][MT], av[KS][RB];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = min(k0 + 32 * s, K - 32);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) xv[s][t] = *reinterpret_cast<const uint4*>(xp[t] + k);
+#pragma unroll
+            for (int j = 0; j < RB; ++j) av[s][j] = *reinterpret_cast<const uint4*>(ap + (size_t)j * 16 * lda + k);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bool live = k0 + 32 * s < ke;
+            const int k = min(k0 + 32 * s, K - 32) + kg * 8;     // first of this lane's 8 consecutive k
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const bf16x8 b = *reinterpret_cast<bf16x8*>(&av[s][j]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const unsigned long long g = ((unsigned long long)rows[t] * K + k) >> 2;
+                    bool k0_[4], k1_[4];
+                    cvft_keep4(keys[j], g, thr, k0_);
+                    cvft_keep4(keys[j], g + 1, thr, k1_);
+                    uint4 v = xv[s][t];
+                    v.x &= (live && k0_[0] ? 0x0000ffffu : 0u) | (live && k0_[1] ? 0xffff0000u : 0u);
+                    v.y &= (live && k0_[2] ? 0x0000ffffu : 0u) | (live && k0_[3] ? 0xffff0000u : 0u);
+                    v.z &= (live && k1_[0] ? 0x0000ffffu : 0u) | (live && k1_[1] ? 0xffff0000u : 0u);
+                    v.w &= (live && k1_[2] ? 0x0000ffffu : 0u) | (live && k1_[3] ? 0xffff0000u : 0u);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&v), b, acc[t][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (w >= 4) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[w - 4][t][j][kg * 4 + r][l15] = acc[t][j][r];
+    }
+    __syncthreads();
+    if (w < 4) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[w][t][j][kg * 4 + r][l15] += acc[t][j][r];
+    }
+    __syncthreads();
+    const float sc = alpha / (1.f - p);
+    for (int e = threadIdx.x; e < 16 * MT * RB * 16; e += 512) {
+        const int r = e / (RB * 16), c = e % (RB * 16);
+        if (m0 + r >= M) continue;
+        const int t = r >> 4, rr = r & 15, j = c >> 4, cc = c & 15;
+        const float s = red[0][t][j][rr][cc] + red[1][t][j][rr][cc] + red[2][t][j][rr][cc] + red[3][t][j][rr][cc];
+        C[(size_t)(m0 + r) * ldc + c] = (bf16_t)(sc * s);
+    }
+}
+
+// U[M, R] = alpha * sum_k drop_t(X)[m,k] A[16t + j][k]   (X contiguous rows of K: the mask index is m*K + k)
+extern "C" int cvft_skinny_dropout(int M, int K, int R, const void* X, int ldx, const void* A, int lda, float alpha, void* C,
+                                   int ldc, float p, const int64_t* seed, const unsigned* sites, void* stream) {
+    CVFT_CHECK_ARG(M > 0 && K >= 32 && K % 32 == 0 && (R == 16 || R == 48) && X && A && C && seed && sites && ldx == K && lda >= K &&
+                   ldc >= R && p > 0.f && p < 1.f && (((uintptr_t)X | (uintptr_t)A) & 15) == 0 && lda % 8 == 0,
+                   "cvft_skinny_dropout: bad args (bf16, contiguous X rows, K %% 32 == 0, R in {16, 48})");
+    constexpr int MT = 2;
+    dim3 grid((M + 16 * MT - 1) / (16 * MT));
+    const int ksteps_per_wave = (K / 32 + 7) / 8;
+    uint4 st = make_uint4(sites[0], R > 16 ? sites[1] : 0u, R > 16 ? sites[2] : 0u, 0u);
+#define SKD_LAUNCH(RBv, KSv) hipLaunchKernelGGL((skinny_dropout_kernel<RBv, MT, KSv>), grid, dim3(512), 0, (hipStream_t)stream, M, K, \
+                                                (const bf16_t*)X, ldx, (const bf16_t*)A, lda, alpha, (bf16_t*)C, ldc, p, (const long long*)seed, st)
+    if (R == 16) { if (ksteps_per_wave >= 2) SKD_LAUNCH(1, 2); else SKD_LAUNCH(1, 1); }
+    else { if (ksteps_per_wave >= 2) SKD_LAUNCH(3, 2); else SKD_LAUNCH(3, 1); }
+#undef SKD_LAUNCH
+    CVFT_LAUNCH_CHECK("cvft_skinny_dropout");
+    return 0;
+}

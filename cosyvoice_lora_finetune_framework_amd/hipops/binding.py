@@ -20,6 +20,12 @@ F32, BF16 = 0, 1
 ACT = {None: 0, "none": 0, "relu": 1, "silu": 2, "swish": 2, "gelu": 3, "gelu_erf": 3, "gelu_tanh": 4, "mish": 5}
 
 
+class RankProb(C.Structure):
+    """mirror of cvft_rank_prob (include/cvft.h)"""
+    _fields_ = [("C", C.c_int), ("Wd", C.c_void_p), ("ldw", C.c_int), ("Rk", C.c_void_p), ("ldr", C.c_int),
+                ("part", C.c_void_p), ("transpose_out", C.c_int), ("rows_per_block", C.c_int)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
@@ -51,6 +57,7 @@ SIGNATURES = {
     "cvft_lora_rank_accum": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "cvft_lora_rank_partial": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "cvft_lora_rank_partial_pair": [_i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p],
+    "cvft_lora_rank_partial_multi": [_i, _i, _i, _p, _p],
     "cvft_lora_grad_reduce": [_i, _p, _i, _p],
     "cvft_lora_shadow": [_i, _p, _p, _p],
     "cvft_layernorm_fwd": [_i, _i, _i, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p],
@@ -70,6 +77,8 @@ SIGNATURES = {
     "cvft_act_fwd": [_i, _i64, _i, _p, _p, _p],
     "cvft_act_bwd": [_i, _i64, _i, _p, _p, _p, _p],
     "cvft_dropout_add": [_i, _i64, _p, _p, _p, _f, _p, C.c_uint, _p],
+    "cvft_skinny_dropout": [_i, _i, _i, _p, _i, _p, _i, _f, _p, _i, _f, _p, _p, _p],
+    "cvft_lora_side_dgrad": [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f, _p, _p, _p],
     "cvft_cfm_prepare": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p],
     "cvft_masked_mse_fwd": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "cvft_masked_mse_bwd": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p],

@@ -189,6 +189,49 @@ def dropout_add(x, p: float, residual=None):
     return DropoutAddFn.apply(x, residual, p, _DROPOUT["site"])
 
 
+def _next_drop_site() -> int:
+    if _DROPOUT["seed"] is None:
+        dropout_begin_step()
+    _DROPOUT["site"] += 1
+    return _DROPOUT["site"]
+
+
+def _sites_arr(sites):
+    return (C.c_uint * len(sites))(*sites)
+
+
+def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
+    """drop(x) for a given mask site (no autograd): re-materialises a forward mask in backward."""
+    x = _c(x)
+    y = torch.empty_like(x)
+    check(lib().cvft_dropout_add(dt(x), x.numel(), ptr(x), None, ptr(y), float(p), ptr(_DROPOUT["seed"]), site, stream()),
+          "cvft_dropout_add")
+    return y
+
+
+def skinny_dropout(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, sites) -> torch.Tensor:
+    """U[M, R] = alpha * drop_t(x) A_t^T per rank tile t (mask sites[t]); x bf16 contiguous [M, K], A [R, K]."""
+    U = torch.empty((x.shape[0], A.shape[0]), dtype=x.dtype, device=x.device)
+    check(lib().cvft_skinny_dropout(x.shape[0], x.shape[1], A.shape[0], ptr(x), x.stride(0), ptr(A), A.stride(0), float(alpha),
+                                    ptr(U), U.stride(0), float(p), ptr(_DROPOUT["seed"]), _sites_arr(sites), stream()),
+          "cvft_skinny_dropout")
+    return U
+
+
+def side_dgrad(V: torch.Tensor, A: torch.Tensor, dx: torch.Tensor, p: float, sites) -> torch.Tensor:
+    """dx += sum_t mask_t/(1-p) * (V_t A_t)   in place (dx [M, K] bf16 contiguous rows)."""
+    check(lib().cvft_lora_side_dgrad(dx.shape[0], dx.shape[1], A.shape[0], ptr(V), V.stride(0), ptr(A), A.stride(0), ptr(dx),
+                                     dx.stride(0), ptr(dx), dx.stride(0), float(p), ptr(_DROPOUT["seed"]), _sites_arr(sites), stream()),
+          "cvft_lora_side_dgrad")
+    return dx
+
+
+def _can_drop_fuse(x: torch.Tensor, r: int) -> bool:
+    """The fused lora_dropout path (mask inside the skinny / side-dgrad kernels): bf16, contiguous rows, K % 32 == 0."""
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and x.shape[1] % 32 == 0 and r in (16, 48)
+            and x.data_ptr() % 16 == 0)
+
+
 class ActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act: str):
@@ -393,7 +436,7 @@ def _widen_zero_padded(t: torch.Tensor, pitch: int) -> torch.Tensor:
     return w
 
 
-def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residual, keep_preact: bool):
+def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residual, keep_preact: bool, drop=None):
     """One LoRA linear forward: y = act(x W^T + b + scale * (x A^T) B^T) (+ residual).
     Returns (y, U, z, ops): U = scale * x A^T [M, r] (saved for dB), z = pre-activation (when kept), ops = the
     compute-dtype (A, A^T, B, B^T) operands."""
@@ -403,8 +446,10 @@ def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residu
         Ac, At = _lora_operands(A, x.dtype)
         Bc, Bt = _lora_operands(B, x.dtype)
         ops = (Ac, At, Bc, Bt)
-        fused = _can_fuse(x, Ac, Bc, pack.N, pack.K)
-        if fused:
+        fused = drop is None and _can_fuse(x, Ac, Bc, pack.N, pack.K)
+        if drop is not None:              # lora_dropout: the side path sees drop(x); mask applied inside the skinny kernel
+            U = skinny_dropout(x, Ac, scale, drop[0], [drop[1]])
+        elif fused:
             U = torch.empty((x.shape[0], Ac.shape[0]), dtype=x.dtype, device=x.device)
         else:
             U = gemm(x, Ac, alpha=scale)
@@ -469,13 +514,25 @@ def _lora_param_grads(x, U, V, dz, A_ref, B_ref, ops):
 
 
 def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_dx: bool, need_dAB: bool,
-             dx_residual=None, dact_src=None, dact: Optional[str] = None):
+             dx_residual=None, dact_src=None, dact: Optional[str] = None, drop=None):
     """Backward of one LoRA linear given dz = gradient at its pre-activation output.
     dx = (dz W + (scale * dz B) A) [* act'(dact_src)] [+ dx_residual]  -- the last two ride in the dgrad epilogue
     (fused producer-activation backward, fused gradient accumulation);  dA / dB go to the parameters' flat .grad
     buffers (through the active LoraGradSink when there is one) or are returned."""
     dx = dA = dB = V = None
     has_lora = ops is not None
+    if has_lora and drop is not None:
+        # lora_dropout: dx = dz W + mask/(1-p) * (V A); the masked term is added by the side-dgrad kernel, the adapter
+        # gradients see drop(x), re-materialised from the mask site
+        assert dact_src is None, "producer-activation fusion is not combined with lora_dropout"
+        Ac, At, Bc, Bt = ops
+        V = gemm(dz, Bt, alpha=scale)
+        if need_dx:
+            dx = gemm(dz, pack.Wb, residual=dx_residual)
+            dx = side_dgrad(V, Ac, dx, drop[0], [drop[1]])
+        if need_dAB:
+            dA, dB = _lora_param_grads(dropout_raw(x, drop[0], drop[1]), U, V, dz, A_ref, B_ref, ops)
+        return dx, dA, dB
     if has_lora:
         Ac, At, Bc, Bt = ops
         if need_dx and _can_fuse(dz, Bt, At, pack.K, pack.N):
@@ -497,10 +554,11 @@ class LinearFn(torch.autograd.Function):
     accumulated straight into the parameters' (flat) .grad buffers when those exist."""
 
     @staticmethod
-    def forward(ctx, x, A, B, residual, pack: LinearPack, scale: float, act: Optional[str]):
+    def forward(ctx, x, A, B, residual, pack: LinearPack, scale: float, act: Optional[str], drop_p: float = 0.0):
         x = _c(x)
         need_grad = any(ctx.needs_input_grad[:3])
         ctx.padded = False
+        ctx.drop = (float(drop_p), _next_drop_site()) if (drop_p > 0 and A is not None) else None
         if A is None and act is None and residual is None and pack.Npad != pack.N:
             Wf, bias, _ = pack.padded
             y = gemm(x, Wf, bias=bias)                                  # [M][Npad], pad columns exactly zero
@@ -508,7 +566,7 @@ class LinearFn(torch.autograd.Function):
             ctx.pack, ctx.padded = pack, True
             ctx.save_for_backward(x, None, None)
             return y[:, :pack.N]
-        y, U, z, ops = _lin_fwd(x, A, B, pack, scale, act, residual, need_grad)
+        y, U, z, ops = _lin_fwd(x, A, B, pack, scale, act, residual, need_grad, ctx.drop)
         ctx.pack, ctx.scale, ctx.act = pack, scale, act
         ctx.ops, ctx.A_ref, ctx.B_ref = ops, A, B
         ctx.save_for_backward(x, U, z)
@@ -519,13 +577,13 @@ class LinearFn(torch.autograd.Function):
         x, U, z = ctx.saved_tensors
         if ctx.padded:
             dx = gemm(_widen_zero_padded(dy, ctx.pack.Npad), ctx.pack.padded[2]) if ctx.needs_input_grad[0] else None
-            return dx, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None
         dy = _c(dy) if ctx.act else _rowc(dy)
         dz = act_bwd(z, dy, ctx.act) if ctx.act else dy
         dx, dA, dB = _lin_bwd(x, U, ctx.ops, ctx.A_ref, ctx.B_ref, ctx.pack, ctx.scale, dz, ctx.needs_input_grad[0],
-                              ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+                              ctx.needs_input_grad[1] or ctx.needs_input_grad[2], drop=ctx.drop)
         dres = dy if ctx.needs_input_grad[3] else None
-        return dx, dA, dB, dres, None, None, None
+        return dx, dA, dB, dres, None, None, None, None
 
 
 class LinearQKVFn(torch.autograd.Function):
@@ -584,10 +642,14 @@ class LinearQKVStackedFn(torch.autograd.Function):
     bf16 training path only (needs the optimiser-maintained stacked shadows); anything else uses LinearQKVFn."""
 
     @staticmethod
-    def forward(ctx, x, Aq, Bq, Ak, Bk, Av, Bv, wstack: QKVStack, ops, scale: float):
+    def forward(ctx, x, Aq, Bq, Ak, Bk, Av, Bv, wstack: QKVStack, ops, scale: float, drop_p: float = 0.0):
         x = _c(x)
         A, At, Bb, Bbt = ops
-        if QKV_FUSE_SIDE and x.shape[1] % 64 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
+        ctx.drop = (float(drop_p), [_next_drop_site() for _ in range(3)]) if drop_p > 0 else None
+        if ctx.drop is not None:          # lora_dropout: three mask sites (each LoRALinear owns its nn.Dropout)
+            U = skinny_dropout(x, A, scale, ctx.drop[0], ctx.drop[1])
+            Y = gemm(x, wstack.Wf, bias=wstack.bias, U=U, Bl=Bb)
+        elif QKV_FUSE_SIDE and x.shape[1] % 64 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
             U = torch.empty((x.shape[0], A.shape[0]), dtype=x.dtype, device=x.device)     # [M, 3r], written by the launch
             Y = gemm(x, wstack.Wf, bias=wstack.bias, La=A, lora_scale=scale, Uout=U, Bl=Bb)
         else:
@@ -609,6 +671,8 @@ class LinearQKVStackedFn(torch.autograd.Function):
             dY = torch.as_strided(dq, (M, 3 * N), (3 * N, 1), dq.storage_offset())     # the attention backward's fused buffer
         else:
             dY = torch.cat([dq, dk, dv], 1)
+        if ctx.drop is not None:
+            return LinearQKVStackedFn._backward_dropout(ctx, x, U, dY)
         if (QKV_FUSE_SIDE and ctx.needs_input_grad[0] and dY.shape[1] % 64 == 0 and dY.stride(0) % 8 == 0
                 and dY.data_ptr() % 16 == 0):
             V = torch.empty((M, Bbt.shape[0]), dtype=dY.dtype, device=dY.device)
@@ -643,7 +707,54 @@ class LinearQKVStackedFn(torch.autograd.Function):
                 rank_accum(x, V[:, i * r:(i + 1) * r], tA, False)
                 rank_accum(dY[:, i * N:(i + 1) * N], U[:, i * r:(i + 1) * r], tB, True)
                 out += [None, None] if direct else [tA, tB]
-        return (dx, *out, None, None, None)
+        return (dx, *out, None, None, None, None)
+
+    @staticmethod
+    def _backward_dropout(ctx, x, U, dY):
+        w, (A, At, Bb, Bbt), scale = ctx.w, ctx.ops, ctx.scale
+        p, sites = ctx.drop
+        N, M, K = w.N, x.shape[0], x.shape[1]
+        V = gemm(dY, Bbt, alpha=scale)                                  # [M, 3r]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = side_dgrad(V, A, gemm(dY, w.Wb), p, sites)             # + sum_t mask_t/(1-p) (V_t A_t)
+        r3 = V.shape[1]
+        r = r3 // 3
+        sink = LoraGradSink.active
+        grads = [(a.grad, b.grad) for a, b in ctx.refs]
+        direct = all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for pair in grads for g in pair)
+        xds = [dropout_raw(x, p, st) for st in sites]                   # the three dropped inputs, re-derived
+        if sink is not None and direct and sink.side is None:
+            rpa, nsa = LoraGradSink.plan(M, K)
+            probs = (cb.RankProb * 3)()
+            keep = []
+            for i, (gA, _) in enumerate(grads):
+                ws = LoraGradSink.workspace(ctx.refs[i][0], nsa)
+                Vi = V[:, i * r:(i + 1) * r]
+                probs[i].C, probs[i].Wd, probs[i].ldw = K, xds[i].data_ptr(), xds[i].stride(0)
+                probs[i].Rk, probs[i].ldr, probs[i].part = Vi.data_ptr(), V.stride(0), ws.data_ptr()
+                probs[i].transpose_out, probs[i].rows_per_block = 0, rpa
+                keep.append(ws)
+            check(lib().cvft_lora_rank_partial_multi(M, r, 3, probs, stream()), "cvft_lora_rank_partial_multi")
+            for i, (gA, _) in enumerate(grads):
+                sink.add(keep[i], gA, gA.numel(), nsa)
+            rpb_, nsb = LoraGradSink.plan(M, 3 * N)
+            wsB = LoraGradSink.workspace(ctx.refs[0][1], nsb * 9)
+            check(lib().cvft_lora_rank_partial(dt(dY), M, 3 * N, r3, ptr(dY), dY.stride(0), ptr(U), U.stride(0), ptr(wsB), 1, rpb_,
+                                               stream()), "cvft_lora_rank_partial")
+            for i, (_, gB) in enumerate(grads):
+                sink.add_block(wsB.data_ptr() + (i * N * r3 + i * r) * 4, gB, N, r, r3, 3 * N * r3, nsb)
+            sink.keep.append((xds, V, U, dY))
+            out = [None] * 6
+        else:
+            out = []
+            for i, (gA, gB) in enumerate(grads):
+                tA = gA if direct else torch.zeros((r, K), dtype=torch.float32, device=x.device)
+                tB = gB if direct else torch.zeros((N, r), dtype=torch.float32, device=x.device)
+                rank_accum(xds[i], V[:, i * r:(i + 1) * r], tA, False)
+                rank_accum(dY[:, i * N:(i + 1) * N], U[:, i * r:(i + 1) * r], tB, True)
+                out += [None, None] if direct else [tA, tB]
+        return (dx, *out, None, None, None, None)
 
 
 class FeedForwardFn(torch.autograd.Function):
@@ -651,13 +762,15 @@ class FeedForwardFn(torch.autograd.Function):
     epilogue of W2's dgrad launch (no separate activation-backward pass over the [M, hidden] tensor)."""
 
     @staticmethod
-    def forward(ctx, x, A1, B1, A2, B2, residual, pack1, pack2, s1: float, s2: float, act: str):
+    def forward(ctx, x, A1, B1, A2, B2, residual, pack1, pack2, s1: float, s2: float, act: str, p1: float = 0.0, p2: float = 0.0):
         x = _c(x)
         need_grad = any(ctx.needs_input_grad[:5])
-        h, U1, z, ops1 = _lin_fwd(x, A1, B1, pack1, s1, act, None, need_grad)
-        y, U2, _, ops2 = _lin_fwd(h, A2, B2, pack2, s2, None, residual, False)
+        ctx.drops = ((float(p1), _next_drop_site()) if (p1 > 0 and A1 is not None) else None,
+                     (float(p2), _next_drop_site()) if (p2 > 0 and A2 is not None) else None)
+        h, U1, z, ops1 = _lin_fwd(x, A1, B1, pack1, s1, act, None, need_grad, ctx.drops[0])
+        y, U2, _, ops2 = _lin_fwd(h, A2, B2, pack2, s2, None, residual, False, ctx.drops[1])
         ctx.cfg = (pack1, pack2, s1, s2, act, ops1, ops2, (A1, B1), (A2, B2))
-        ctx.save_for_backward(x, U1, z, h if A2 is not None else None, U2)
+        ctx.save_for_backward(x, U1, z, h if A2 is not None else None, U2)      # (h: dA2 = V2^T h, or drop(h) re-derived)
         return y
 
     @staticmethod
@@ -668,12 +781,17 @@ class FeedForwardFn(torch.autograd.Function):
         need1 = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         need2 = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         need_dx = ctx.needs_input_grad[0]
-        dz, dA2, dB2 = _lin_bwd(h, U2, ops2, A2, B2, pack2, s2, dy, need_dx or need1, need2, dact_src=z, dact=act)
+        d1, d2 = ctx.drops
+        if d2 is None:
+            dz, dA2, dB2 = _lin_bwd(h, U2, ops2, A2, B2, pack2, s2, dy, need_dx or need1, need2, dact_src=z, dact=act)
+        else:       # lora_dropout on W2: its masked side term must join before act'(z) multiplies -> separate activation backward
+            dh, dA2, dB2 = _lin_bwd(h, U2, ops2, A2, B2, pack2, s2, dy, need_dx or need1, need2, drop=d2)
+            dz = act_bwd(z, dh, act) if dh is not None else None
         dx = dA1 = dB1 = None
         if dz is not None:
-            dx, dA1, dB1 = _lin_bwd(x, U1, ops1, A1, B1, pack1, s1, dz, need_dx, need1)
+            dx, dA1, dB1 = _lin_bwd(x, U1, ops1, A1, B1, pack1, s1, dz, need_dx, need1, drop=d1)
         dres = dy if ctx.needs_input_grad[5] else None
-        return dx, dA1, dB1, dA2, dB2, dres, None, None, None, None, None
+        return dx, dA1, dB1, dA2, dB2, dres, None, None, None, None, None, None, None
 
 
 class LoraSideFn(torch.autograd.Function):
@@ -707,8 +825,10 @@ def lora_side(xd, A, B, base, scale: float):
     return LoraSideFn.apply(xd, A, B, base, scale)
 
 
-def lora_linear(x, pack: LinearPack, A=None, B=None, scale: float = 1.0, act: Optional[str] = None, residual=None):
-    return LinearFn.apply(x, A, B, residual, pack, scale, act)
+def lora_linear(x, pack: LinearPack, A=None, B=None, scale: float = 1.0, act: Optional[str] = None, residual=None,
+                drop_p: float = 0.0):
+    """drop_p > 0 (train mode, lora.py:70): the side path sees dropout(x); needs _can_drop_fuse(x, r)."""
+    return LinearFn.apply(x, A, B, residual, pack, scale, act, drop_p)
 
 
 _QKV_STACKS = {}
@@ -744,18 +864,24 @@ def _qkv_stacked_operands(x, packs, loras, scales):
     return ws, ops
 
 
-def lora_linear_qkv(x, packs, loras, scales):
-    """(q, k, v) = three LoRA linears of x; loras = ((Aq, Bq), (Ak, Bk), (Av, Bv)) with None entries for plain layers."""
+def lora_linear_qkv(x, packs, loras, scales, drop_p: float = 0.0):
+    """(q, k, v) = three LoRA linears of x; loras = ((Aq, Bq), (Ak, Bk), (Av, Bv)) with None entries for plain layers.
+    drop_p > 0: lora_dropout (train mode) -- only on the stacked bf16 path; returns None when that path does not apply
+    (the caller then falls back to three separate dropout-path linears)."""
     (Aq, Bq), (Ak, Bk), (Av, Bv) = loras
     st = _qkv_stacked_operands(x, packs, loras, scales)
+    if drop_p > 0:
+        if st is None or not _can_drop_fuse(x, 48):
+            return None
+        return LinearQKVStackedFn.apply(x, Aq, Bq, Ak, Bk, Av, Bv, st[0], st[1], scales[0], drop_p)
     if st is not None:
-        return LinearQKVStackedFn.apply(x, Aq, Bq, Ak, Bk, Av, Bv, st[0], st[1], scales[0])
+        return LinearQKVStackedFn.apply(x, Aq, Bq, Ak, Bk, Av, Bv, st[0], st[1], scales[0], 0.0)
     return LinearQKVFn.apply(x, Aq, Bq, Ak, Bk, Av, Bv, tuple(packs), tuple(scales))
 
 
 def lora_feed_forward(x, pack1, pack2, lora1=(None, None), lora2=(None, None), s1: float = 1.0, s2: float = 1.0,
-                      act: str = "relu", residual=None):
-    return FeedForwardFn.apply(x, lora1[0], lora1[1], lora2[0], lora2[1], residual, pack1, pack2, s1, s2, act)
+                      act: str = "relu", residual=None, p1: float = 0.0, p2: float = 0.0):
+    return FeedForwardFn.apply(x, lora1[0], lora1[1], lora2[0], lora2[1], residual, pack1, pack2, s1, s2, act, p1, p2)
 
 
 # ---------------------------------------------------------------------------------

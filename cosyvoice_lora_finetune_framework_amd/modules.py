@@ -78,8 +78,11 @@ def hip_linear(mod: nn.Module, x: torch.Tensor, dtype: Optional[torch.dtype] = N
     pack = _cached(base, "lin", base.weight, dtype, lambda: HF.LinearPack(w, b, dtype))
     if x.dtype != dtype:
         x = x.to(dtype)
-    if A is not None and mod.training and isinstance(drop, nn.Dropout) and drop.p > 0:
-        # reference lora.py:70: dropout on the side-path input only
+    if A is not None and _lora_dropout_on(mod, drop):
+        # reference lora.py:70: dropout on the side-path input only.  Fused form (mask inside the rank-side kernels,
+        # counter-based) when the shapes allow, else nn.Dropout + separate side-path launches
+        if type(drop) is nn.Dropout and HF._can_drop_fuse(x, A.shape[0]):
+            return HF.lora_linear(x, pack, A, Bm, scale, act, residual, drop_p=drop.p)
         return _lora_dropout_path(x, pack, A, Bm, scale, drop, act, residual)
     return HF.lora_linear(x, pack, A, Bm, scale, act, residual)
 
@@ -91,20 +94,30 @@ def _lora_dropout_on(mod: nn.Module, drop) -> bool:
 def hip_qkv(mq: nn.Module, mk: nn.Module, mv: nn.Module, x: torch.Tensor):
     """(q, k, v) projections of one input with the input-gradient accumulation fused (HF.LinearQKVFn)."""
     parts = [_lin_parts(m) for m in (mq, mk, mv)]
-    if any(p[3] is not None and _lora_dropout_on(m, p[6]) for m, p in zip((mq, mk, mv), parts)):
-        return hip_linear(mq, x), hip_linear(mk, x), hip_linear(mv, x)
+    drops = [p[6].p if (p[3] is not None and _lora_dropout_on(m, p[6])) else 0.0 for m, p in zip((mq, mk, mv), parts)]
     packs = [_cached(p[0], "lin", p[0].weight, x.dtype, lambda p=p: HF.LinearPack(p[1], p[2], x.dtype)) for p in parts]
+    if any(d > 0 for d in drops):
+        out = None
+        if drops[0] == drops[1] == drops[2] and all(type(p[6]) is nn.Dropout for p in parts):
+            out = HF.lora_linear_qkv(x, packs, [(p[3], p[4]) for p in parts], [p[5] for p in parts], drop_p=drops[0])
+        return out if out is not None else (hip_linear(mq, x), hip_linear(mk, x), hip_linear(mv, x))
     return HF.lora_linear_qkv(x, packs, [(p[3], p[4]) for p in parts], [p[5] for p in parts])
 
 
 def hip_ffn(m1: nn.Module, m2: nn.Module, x: torch.Tensor, act: str, residual: Optional[torch.Tensor] = None):
     """W2 act(W1 x) (+ residual) with the activation backward fused into W2's dgrad (HF.FeedForwardFn)."""
     p1, p2 = _lin_parts(m1), _lin_parts(m2)
-    if (p1[3] is not None and _lora_dropout_on(m1, p1[6])) or (p2[3] is not None and _lora_dropout_on(m2, p2[6])):
-        return hip_linear(m2, hip_linear(m1, x, act=act), residual=residual)
+    d1 = p1[6].p if (p1[3] is not None and _lora_dropout_on(m1, p1[6])) else 0.0
+    d2 = p2[6].p if (p2[3] is not None and _lora_dropout_on(m2, p2[6])) else 0.0
+    if d1 > 0 or d2 > 0:
+        ok = x.dtype == torch.bfloat16 and x.is_contiguous() and x.data_ptr() % 16 == 0 and \
+            (d1 == 0 or (type(p1[6]) is nn.Dropout and p1[3].shape[0] == 16 and p1[1].shape[1] % 32 == 0)) and \
+            (d2 == 0 or (type(p2[6]) is nn.Dropout and p2[3].shape[0] == 16 and p2[1].shape[1] % 32 == 0))
+        if not ok:
+            return hip_linear(m2, hip_linear(m1, x, act=act), residual=residual)
     k1 = _cached(p1[0], "lin", p1[0].weight, x.dtype, lambda: HF.LinearPack(p1[1], p1[2], x.dtype))
     k2 = _cached(p2[0], "lin", p2[0].weight, x.dtype, lambda: HF.LinearPack(p2[1], p2[2], x.dtype))
-    return HF.lora_feed_forward(x, k1, k2, (p1[3], p1[4]), (p2[3], p2[4]), p1[5], p2[5], act, residual)
+    return HF.lora_feed_forward(x, k1, k2, (p1[3], p1[4]), (p2[3], p2[4]), p1[5], p2[5], act, residual, p1=d1, p2=d2)
 
 
 def _lora_dropout_path(x, pack, A, Bm, scale, drop, act, residual):

@@ -111,6 +111,14 @@ int cvft_lora_rank_partial(int dtype, int M, int C, int r, const void* Wd, int l
  * (row blocks of rpbA / rpbB rows, multiples of 32; operands 16-byte aligned, K % 8 == N % 8 == 0, r in {16,32,48,64}). */
 int cvft_lora_rank_partial_pair(int M, int r, int K, const void* X, int ldx, const void* V, int ldv, float* partA, int rpbA,
                                 int N, const void* dY, int ldy, const void* U, int ldu, float* partB, int rpbB, void* stream);
+typedef struct {
+    int C; const void* Wd; int ldw;      /* wide operand [M][C] (x or dY) */
+    const void* Rk; int ldr;            /* rank operand [M][r] (V or U) */
+    float* part; int transpose_out;     /* slabs [s][r][C] (0) or [s][C][r] (1) */
+    int rows_per_block;                 /* multiple of 32 */
+} cvft_rank_prob;
+/* 1..4 such products (same M, same r) in one launch */
+int cvft_lora_rank_partial_multi(int M, int r, int n, const cvft_rank_prob* probs, void* stream);
 int cvft_lora_grad_reduce(int ntasks, const void* tasks, int max_blocks_x, void* stream);
 /* One launch per optimiser step: bf16 copy and transposed bf16 copy of every LoRA master in the flat fp32 buffer.
  * tiles: int64[ntiles][6] = {src offset (elements of flat_p), dst ptr, dst_t ptr, rows | cols << 32,
@@ -209,6 +217,13 @@ int cvft_act_bwd(int dtype, int64_t n, int act, const void* z, const void* dy, v
  * backward pass calls the same entry point on dy with the same (seed, site) instead of storing a mask. */
 int cvft_dropout_add(int dtype, int64_t n, const void* x, const void* residual, void* y, float p,
                      const int64_t* seed, unsigned site, void* stream);
+/* LoRA side path under lora_dropout (lora.py:70-73), bf16, masks shared with cvft_dropout_add (element index m*K + k):
+ *   cvft_skinny_dropout : U[M,R] = alpha/(1-p) * sum_k keep_t(m,k) X[m,k] A[16t+j][k]   (t = rank tile, sites[t]; R = 16 or 48)
+ *   cvft_lora_side_dgrad: out[m,k] = dx[m,k] + sum_t keep_t(m,k)/(1-p) * sum_j V[m,16t+j] A[16t+j][k] */
+int cvft_skinny_dropout(int M, int K, int R, const void* X, int ldx, const void* A, int lda, float alpha, void* C, int ldc,
+                        float p, const int64_t* seed, const unsigned* sites, void* stream);
+int cvft_lora_side_dgrad(int M, int K, int R, const void* V, int ldv, const void* A, int lda, const void* dx, int ldi,
+                         void* out, int ldo, float p, const int64_t* seed, const unsigned* sites, void* stream);
 /* CFM prepare (flow_matching.py:173-186 == flow_model.py:143-161), channel-last:
  *   feat raw log-mel [B][T][80] fp32, z [B][T][80] fp32, t_raw [B], cfg_keep [B] (0/1), mu [B][T][80],
  *   spk [B][80], cond (or NULL = zeros)  ->  xin [B][T][320] = [y | mu*keep | spk*keep | cond*keep],  u [B][T][80] (fp32), t [B]. */

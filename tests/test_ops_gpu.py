@@ -641,3 +641,98 @@ def test_attn_relpos_probability_dropout(dtype, causal):
     orf.backward(gy.double())
     assert rel(o.reshape(B, L, -1), orf) < TOL[dtype]
     assert rel(qd.grad.reshape(B, L, -1), qr.grad) < TOL[dtype] * 3
+
+
+def _keep_scale_host(seed: int, site: int, n: int, p: float) -> torch.Tensor:
+    """Host replica of common.cuh cvft_drop_key / cvft_keep4 (the mask of cvft_dropout_add, cvft_skinny_dropout and
+    cvft_lora_side_dgrad): flat [n] tensor of {0, 1/(1-p)}."""
+    import numpy as np
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mix(z):
+        z = (z + np.uint64(0x9e3779b97f4a7c15)) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & M
+        return z ^ (z >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        key = mix(np.uint64(seed) ^ (np.uint64(site) << np.uint64(32)))
+        g = np.arange((n + 3) // 4, dtype=np.uint64)
+        r0, r1 = mix(key + np.uint64(2) * g), mix(key + np.uint64(2) * g + np.uint64(1))
+    u = np.stack([r0 & np.uint64(0xFFFFFFFF), r0 >> np.uint64(32), r1 & np.uint64(0xFFFFFFFF), r1 >> np.uint64(32)], 1).reshape(-1)[:n]
+    thr = int(min(4294967295.0, float(np.float32(p) * np.float32(4294967296.0))))
+    return torch.from_numpy((u >= np.uint64(thr)).astype(np.float64)) / (1.0 - float(np.float32(p)))
+
+
+@pytest.mark.parametrize("act", [None, "silu"])
+def test_lora_dropout_fused_path_matches_torch(act):
+    """lora.py:64-76 in train mode on the fused bf16 path: the mask lives inside cvft_skinny_dropout (forward) and
+    cvft_lora_side_dgrad / cvft_dropout_add (backward); compared with torch math on the host-replicated mask."""
+    from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
+    from cosyvoice_lora_finetune_framework_amd.modules import hip_linear
+    HF = HFmod()
+    torch.manual_seed(5)
+    M, K, N, pdrop = 300, 128, 192, 0.15
+    mod = LoRALinear(torch.nn.Linear(K, N), r=16, lora_alpha=32, lora_dropout=pdrop).to(DEV)
+    torch.nn.init.normal_(mod.lora_B, std=0.1)
+    mod.train()
+    x = (torch.randn(M, K, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    res = torch.randn(M, N, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    gy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    HF.dropout_begin_step()
+    y = hip_linear(mod, x, act=act, residual=res)
+    assert "LinearFn" in type(y.grad_fn).__name__                       # the fused path, not LoraSideFn
+    y.backward(gy)
+    seed, site = int(HF._DROPOUT["seed"].item()), HF._DROPOUT["site"]
+    mask = _keep_scale_host(seed, site, M * K, pdrop).reshape(M, K).to(DEV).float()
+    assert abs(float((mask > 0).float().mean()) - (1 - pdrop)) < 0.02
+    got = [y.float(), x.grad.float(), res.grad.float(), mod.lora_A.grad.clone(), mod.lora_B.grad.clone()]
+    for t in (mod.lora_A, mod.lora_B):
+        t.grad = None
+    xf, rf = x.detach().float().requires_grad_(True), res.detach().float().requires_grad_(True)
+    W, b = mod.original_layer.weight.float(), mod.original_layer.bias.float()
+    z = xf @ W.t() + b + mod.scaling * ((xf * mask) @ mod.lora_A.t()) @ mod.lora_B.t()
+    yr = (torch.nn.functional.silu(z) if act else z) + rf
+    yr.backward(gy.float())
+    for name, u, w in zip(("y", "dx", "dres", "dA", "dB"), got, [yr, xf.grad, rf.grad, mod.lora_A.grad, mod.lora_B.grad]):
+        assert rel(u, w) < 3e-2, (name, rel(u, w))
+
+
+def test_qkv_stacked_lora_dropout_matches_torch():
+    """Stacked q|k|v under lora_dropout: three mask sites in one cvft_skinny_dropout launch, one side-dgrad launch,
+    dA of the three adapters from three re-derived dropped inputs in one multi-problem slab launch."""
+    from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
+    from cosyvoice_lora_finetune_framework_amd.modules import hip_qkv
+    from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
+    HF = HFmod()
+    torch.manual_seed(3)
+    K, N, M, pdrop = 256, 512, 1000, 0.05
+    mods = [LoRALinear(torch.nn.Linear(K, N), r=16, lora_alpha=32, lora_dropout=pdrop).to(DEV) for _ in range(3)]
+    for m in mods:
+        torch.nn.init.normal_(m.lora_B, std=0.05)
+        m.train()
+    params = [p for m in mods for p in (m.lora_A, m.lora_B)]
+    opt = FlatAdamW(params, lr=1e-3)
+    x = (torch.randn(M, K, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    g = [torch.randn(M, N, device=DEV).to(torch.bfloat16) for _ in range(3)]
+    opt.zero_grad()
+    HF.dropout_begin_step()
+    with HF.LoraGradSink():
+        q_, k_, v_ = hip_qkv(mods[0], mods[1], mods[2], x)
+        assert "Stacked" in type(q_.grad_fn).__name__
+        fused = torch.cat(g, 1)
+        torch.autograd.backward([q_, k_, v_], [fused[:, :N], fused[:, N:2 * N], fused[:, 2 * N:]])
+    seed, last = int(HF._DROPOUT["seed"].item()), HF._DROPOUT["site"]
+    xf = x.detach().float().requires_grad_(True)
+    outs = []
+    for i, m in enumerate(mods):
+        mask = _keep_scale_host(seed, last - 2 + i, M * K, pdrop).reshape(M, K).to(DEV).float()
+        W, b = m.original_layer.weight.float(), m.original_layer.bias.float()
+        A, Bm = m.lora_A.detach().clone().requires_grad_(True), m.lora_B.detach().clone().requires_grad_(True)
+        y = xf @ W.t() + b + m.scaling * ((xf * mask) @ A.t()) @ Bm.t()
+        outs.append((y, A, Bm))
+    torch.autograd.backward([o[0] for o in outs], [t.float() for t in g])
+    for i, (y, A, Bm) in enumerate(outs):
+        assert rel((q_, k_, v_)[i].float(), y) < 2e-2
+        assert rel(mods[i].lora_A.grad, A.grad) < 3e-2, ("dA", i, rel(mods[i].lora_A.grad, A.grad))
+        assert rel(mods[i].lora_B.grad, Bm.grad) < 3e-2, ("dB", i)
+    assert rel(x.grad.float(), xf.grad) < 3e-2
