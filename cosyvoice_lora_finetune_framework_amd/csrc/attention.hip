@@ -23,6 +23,7 @@ struct AP {
     T *dq, *dk, *dv; int ldg;
     // attention-probability dropout (attention.py:118 `self.dropout(attn)`; DROP instantiations only)
     float drop_p; const long long* seed; unsigned site;
+    int iso;      // REL = false: prompt-isolation split (modules.py:844-879); 0 = off
 };
 
 // keep-scale of score (b, h, i, j): 1/(1-p) or 0.  Counter-based (SplitMix64 finaliser, same as cvft_dropout_add), so
@@ -166,6 +167,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
                     x = valid ? x : NEG_INF;
                 } else {
                     x = (j < L) ? x + (j < lb ? 0.f : -1.0e10f) : NEG_INF;
+                    if (p.iso > 0 && ((i < p.iso) != (j < p.iso))) x = NEG_INF;      // prompt / target segments do not mix
                 }
                 s[nt][r] = x;
                 tm = fmaxf(tm, x);
@@ -357,7 +359,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
                 if (REL) {
                     valid = (j < lb) && (j < L) && (!p.causal || j <= i);
                 } else {
-                    valid = (j < L);
+                    valid = (j < L) && !(p.iso > 0 && ((i < p.iso) != (j < p.iso)));
                     x += (j < lb ? 0.f : -1.0e10f);
                 }
                 const float pv = valid ? __expf(x - lse_r[r]) : 0.f;
@@ -544,7 +546,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AP<T>& p, const int bx) 
                     if (REL) {
                         valid = (j < lb) && (j < L) && (i < L) && (!p.causal || j <= i);
                     } else {
-                        valid = (j < L) && (i < L);
+                        valid = (j < L) && (i < L) && !(p.iso > 0 && ((i < p.iso) != (j < p.iso)));
                         x += (j < lb ? 0.f : -1.0e10f);
                     }
                     const float pv = valid ? __expf(x - lse_s[il]) : 0.f;
@@ -697,27 +699,27 @@ static AP<T> make_ap(int B, int H, int L, const void* q, const void* k, const vo
     a.B = B; a.H = H; a.L = L; a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.ld = ld;
     a.p = (const T*)pp; a.ldp = ldp; a.bu = bu; a.bv = bv; a.len = len; a.causal = causal; a.scale = scale;
     a.o = nullptr; a.ldo = 0; a.lse = nullptr; a.d_o = nullptr; a.delta = nullptr; a.dq = a.dk = a.dv = nullptr; a.ldg = 0;
-    a.drop_p = 0.f; a.seed = nullptr; a.site = 0;
+    a.drop_p = 0.f; a.seed = nullptr; a.site = 0; a.iso = 0;
     return a;
 }
 
 extern "C" int cvft_attn_bias_fwd(int dtype, int B, int H, int T_, const void* q, const void* k, const void* v, int ld,
-                                  const int32_t* klen, float scale, void* o, int ldo, float* lse, void* stream) {
+                                  const int32_t* klen, float scale, int iso_len, void* o, int ldo, float* lse, void* stream) {
     if (check_common("cvft_attn_bias_fwd", dtype, B, H, T_, ld, ldo, q, k, v)) return -1;
     CVFT_CHECK_ARG(o && lse, "cvft_attn_bias_fwd: null output");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CVFT_F32) {
         AP<float> a = make_ap<float>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
-        a.o = (float*)o; a.ldo = ldo; a.lse = lse;
+        a.o = (float*)o; a.ldo = ldo; a.lse = lse; a.iso = (iso_len > 0 && iso_len < T_) ? iso_len : 0;
         return launch_fwd<float, false>(a, st);
     }
     AP<bf16_t> a = make_ap<bf16_t>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
-    a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse;
+    a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse; a.iso = (iso_len > 0 && iso_len < T_) ? iso_len : 0;
     return launch_fwd<bf16_t, false>(a, st);
 }
 
 extern "C" int cvft_attn_bias_bwd(int dtype, int B, int H, int T_, const void* q, const void* k, const void* v, int ld,
-                                  const int32_t* klen, float scale, const void* o, const void* d_o, int ldo,
+                                  const int32_t* klen, float scale, int iso_len, const void* o, const void* d_o, int ldo,
                                   const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg, void* stream) {
     if (check_common("cvft_attn_bias_bwd", dtype, B, H, T_, ld, ldo, q, k, v)) return -1;
     CVFT_CHECK_ARG(o && d_o && lse && delta && dq && dk && dv && ldg >= H * 64, "cvft_attn_bias_bwd: bad args");
@@ -726,12 +728,12 @@ extern "C" int cvft_attn_bias_bwd(int dtype, int B, int H, int T_, const void* q
     if (dtype == CVFT_F32) {
         AP<float> a = make_ap<float>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
         a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const float*)d_o; a.delta = delta;
-        a.dq = (float*)dq; a.dk = (float*)dk; a.dv = (float*)dv; a.ldg = ldg;
+        a.dq = (float*)dq; a.dk = (float*)dk; a.dv = (float*)dv; a.ldg = ldg; a.iso = (iso_len > 0 && iso_len < T_) ? iso_len : 0;
         return launch_bwd<float, false>(a, delta, (const float*)o, st);
     }
     AP<bf16_t> a = make_ap<bf16_t>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
     a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const bf16_t*)d_o; a.delta = delta;
-    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg;
+    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.iso = (iso_len > 0 && iso_len < T_) ? iso_len : 0;
     return launch_bwd<bf16_t, false>(a, delta, (const bf16_t*)o, st);
 }
 

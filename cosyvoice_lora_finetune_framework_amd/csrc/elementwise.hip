@@ -221,7 +221,7 @@ extern "C" int cvft_cfm_prepare(int dtype, int B, int T, const float* feat, cons
 template <typename T>
 __global__ void __launch_bounds__(256) masked_mse_fwd_kernel(int B, int T_, int C, const T* __restrict__ pred,
                                                               const float* __restrict__ u, const int* __restrict__ len,
-                                                              float* __restrict__ loss_sum) {
+                                                              const float* __restrict__ w, float* __restrict__ loss_sum) {
     __shared__ float sm[16];
     const size_t total = (size_t)B * T_ * C;
     float s = 0.f;
@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(256) masked_mse_fwd_kernel(int B, int T_, int 
         int t = (int)(bt % T_), b = (int)(bt / T_);
         if (!len || t < len[b]) {
             float d = to_f32(pred[i]) - u[i];
+            if (w) d *= w[bt];              // per-frame loss weight (prompt region 0, boundary frames > 1; flow_model.py:179-202)
             s += d * d;
         }
     }
@@ -238,40 +239,41 @@ __global__ void __launch_bounds__(256) masked_mse_fwd_kernel(int B, int T_, int 
 }
 template <typename T>
 __global__ void masked_mse_bwd_kernel(int B, int T_, int C, const T* __restrict__ pred, const float* __restrict__ u,
-                                      const int* __restrict__ len, const float* __restrict__ gscale, T* __restrict__ dpred) {
+                                      const int* __restrict__ len, const float* __restrict__ w, const float* __restrict__ gscale,
+                                      T* __restrict__ dpred) {
     const size_t total = (size_t)B * T_ * C;
     const float g = 2.f * gscale[0];
     EW_LOOP(i, total) {
         size_t bt = i / C;
         int t = (int)(bt % T_), b = (int)(bt / T_);
         float d = 0.f;
-        if (!len || t < len[b]) d = g * (to_f32(pred[i]) - u[i]);
+        if (!len || t < len[b]) d = g * (to_f32(pred[i]) - u[i]) * (w ? w[bt] * w[bt] : 1.f);
         dpred[i] = from_f32<T>(d);
     }
 }
 extern "C" int cvft_masked_mse_fwd(int dtype, int B, int T, int C, const void* pred, const float* u, const int32_t* len,
-                                   float* loss_sum, void* stream) {
+                                   const float* w, float* loss_sum, void* stream) {
     CHECK_DTYPE("cvft_masked_mse_fwd", dtype);
     CVFT_CHECK_ARG(B > 0 && T > 0 && C > 0 && pred && u && loss_sum, "cvft_masked_mse_fwd: bad args");
     size_t total = (size_t)B * T * C;
     unsigned g = ew_grid(total);
     if (g > 1024) g = 1024;
     if (dtype == CVFT_F32)
-        hipLaunchKernelGGL((masked_mse_fwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, B, T, C, (const float*)pred, u, len, loss_sum);
+        hipLaunchKernelGGL((masked_mse_fwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, B, T, C, (const float*)pred, u, len, w, loss_sum);
     else
-        hipLaunchKernelGGL((masked_mse_fwd_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, B, T, C, (const bf16_t*)pred, u, len, loss_sum);
+        hipLaunchKernelGGL((masked_mse_fwd_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, B, T, C, (const bf16_t*)pred, u, len, w, loss_sum);
     CVFT_LAUNCH_CHECK("cvft_masked_mse_fwd");
     return 0;
 }
 extern "C" int cvft_masked_mse_bwd(int dtype, int B, int T, int C, const void* pred, const float* u, const int32_t* len,
-                                   const float* gscale, void* dpred, void* stream) {
+                                   const float* w, const float* gscale, void* dpred, void* stream) {
     CHECK_DTYPE("cvft_masked_mse_bwd", dtype);
     CVFT_CHECK_ARG(B > 0 && T > 0 && C > 0 && pred && u && gscale && dpred, "cvft_masked_mse_bwd: bad args");
     size_t total = (size_t)B * T * C;
     if (dtype == CVFT_F32)
-        hipLaunchKernelGGL((masked_mse_bwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, C, (const float*)pred, u, len, gscale, (float*)dpred);
+        hipLaunchKernelGGL((masked_mse_bwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, C, (const float*)pred, u, len, w, gscale, (float*)dpred);
     else
-        hipLaunchKernelGGL((masked_mse_bwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, C, (const bf16_t*)pred, u, len, gscale, (bf16_t*)dpred);
+        hipLaunchKernelGGL((masked_mse_bwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, C, (const bf16_t*)pred, u, len, w, gscale, (bf16_t*)dpred);
     CVFT_LAUNCH_CHECK("cvft_masked_mse_bwd");
     return 0;
 }

@@ -3,19 +3,20 @@
 Same classes / constructor arguments / state-dict keys as the reference's flow_model.py
 (``ConditionalCFM`` flow_model.py:50-204, ``MaskedDiffWithXvec`` 207-246,
 ``build_flow_model`` 641-767) == vendored cosyvoice/flow/{flow,flow_matching}.py; only the
-training hot path is built here (``compute_loss`` and the no-prompt forward that
-llm_flow_model.py:181-229 drives); the Euler sampler / anti-leakage strategies are
-SURVEY.md section 8(f) "next" items.
+training hot path (``compute_loss`` and the no-prompt forward that llm_flow_model.py:181-229
+drives) plus the SURVEY.md section 8(f) items: the Euler sampler (rank 3) and the flow-only
+anti-leakage training path (rank 4).
 """
 from __future__ import annotations
 
 import os
+import random
 from typing import Any, Dict, Optional
 
 import torch
 import torch.nn as nn
 
-from .config import MEL_MEAN, MEL_STD
+from .config import ANTI_LEAKAGE_CONFIG, MEL_MEAN, MEL_STD, NO_PROMPT_TRAINING_CONFIG
 from .hipops import functional as HF
 from .modules import (ConditionalDecoder, InterpolateRegulator, Numerics, RelPosEncoder, hip_linear, to_len)
 
@@ -39,9 +40,12 @@ class ConditionalCFM(nn.Module):
                 "cfg_rand": torch.rand(B, device=device)}
 
     def compute_loss_cl(self, feat, mu, spk, length, B: int, T: int, num: Numerics, draws=None,
-                        mel_mean: float = 0.0, mel_std: float = 1.0, cond=None):
+                        mel_mean: float = 0.0, mel_std: float = 1.0, cond=None, prompt_lens=None):
         """Channel-last hot path.  feat [B,T,80] fp32 (raw log-mel if mel_mean/std given), mu [B*T,80],
-        spk [B,80], length int32 [B] -> scalar loss (flow_matching.py:154-193)."""
+        spk [B,80], length int32 [B] -> scalar loss (flow_matching.py:154-193).
+        prompt_lens (list of B ints, flow_model.py:164-202): prompt-isolation attention in the estimator (split at the
+        batch's longest prompt), loss weight 0 on each sample's prompt frames and `boundary_loss_weight` on the
+        `boundary_frames` after them."""
         dev = mu.device
         if draws is None:
             draws = self.make_draws(B, T, dev)
@@ -51,9 +55,32 @@ class ConditionalCFM(nn.Module):
             else torch.ones(B, device=dev)
         xin, u, t = HF.cfm_prepare(mu, spk, feat.to(dev, torch.float32).contiguous(), z.contiguous(), t_raw, keep, B, T,
                                    mel_mean, mel_std, self.sigma_min, cond)
-        pred = self.estimator.forward_cl(xin, t, B, T, length, num.gelu)
-        denom = (length.sum() * pred.shape[1]).to(torch.float32)
-        return HF.masked_mse(pred, u, length, denom, B, T), xin
+        if prompt_lens is not None and len(prompt_lens) > 0:
+            self.estimator.prompt_isolation_len = int(max(prompt_lens))
+            self.estimator.prompt_isolation_enabled = True
+        else:
+            self.estimator.prompt_isolation_len = 0
+        try:
+            pred = self.estimator.forward_cl(xin, t, B, T, length, num.gelu)
+        finally:
+            self.estimator.prompt_isolation_len = 0
+        if prompt_lens is None:
+            denom = (length.sum() * pred.shape[1]).to(torch.float32)
+            return HF.masked_mse(pred, u, length, denom, B, T), xin
+        # loss_mask of flow_model.py:179-196, built on the host from lengths: padding mask, prompt frames 0, then the
+        # boundary window overwritten with its weight (as the reference does, also where it reaches past the length)
+        lens = length.detach().cpu().tolist()
+        w = torch.zeros(B, T, dtype=torch.float32)
+        bf, bw = ANTI_LEAKAGE_CONFIG.get('boundary_frames', 15), ANTI_LEAKAGE_CONFIG.get('boundary_loss_weight', 3.0)
+        for i, pl in enumerate(prompt_lens):
+            w[i, :lens[i]] = 1.0
+            if pl > 0:
+                w[i, :pl] = 0.0
+                if ANTI_LEAKAGE_CONFIG.get('boundary_loss_enabled', True):
+                    w[i, pl:min(pl + bf, T)] = bw
+        w = w.reshape(-1).to(dev)
+        denom = (w.sum() * pred.shape[1]).clamp_min(1e-20)
+        return HF.masked_mse(pred, u, None, denom, B, T, weight=w), xin
 
     @torch.no_grad()
     def forward(self, mu, mask, n_timesteps, temperature=1.0, spks=None, cond=None, prompt_len=0, cache=None,
@@ -103,14 +130,13 @@ class ConditionalCFM(nn.Module):
 
     def compute_loss(self, x1, mask, mu, spks=None, cond=None, prompt_lens=None, draws=None, num: Optional[Numerics] = None):
         """Reference signature: x1,mu,cond (B,80,T) normalised mel; mask (B,1,T); spks (B,80)."""
-        if prompt_lens:
-            raise NotImplementedError("prompt-region loss masking (SURVEY 8f rank 4) is not built yet")
         num = num or Numerics(dtype=mu.dtype)
         B, _, T = mu.shape
         length = mask.reshape(B, T).sum(dim=1).to(torch.int32)
         mu_cl = mu.transpose(1, 2).reshape(B * T, -1).to(num.dtype)
         cond_cl = None if cond is None else cond.transpose(1, 2).reshape(B * T, -1).to(num.dtype).contiguous()
-        loss, xin = self.compute_loss_cl(x1.transpose(1, 2), mu_cl, spks.to(num.dtype), length, B, T, num, draws, cond=cond_cl)
+        loss, xin = self.compute_loss_cl(x1.transpose(1, 2), mu_cl, spks.to(num.dtype), length, B, T, num, draws, cond=cond_cl,
+                                         prompt_lens=prompt_lens)
         y = xin[:, :x1.shape[1]].reshape(B, T, -1).transpose(1, 2)
         return loss, y
 
@@ -164,8 +190,82 @@ class MaskedDiffWithXvec(nn.Module):
         loss, _ = self.decoder.compute_loss_cl(feat, mu, spk, feat_len, B, T, num, draws, self.mel_mean, self.mel_std)
         return {'loss': loss}
 
+    def prompt_plan(self, feat_len, cross_len=None):
+        """Host side of the anti-leakage strategies (flow_model.py:320-386), drawing from `random` in the reference's
+        order: per utterance prompt dropout -> dynamic prompt length -> [cross-sample clamp] -> [silence band] -> text
+        blinding.  Returns per-utterance dicts {total, copy, cross, silence, blind}."""
+        C = ANTI_LEAKAGE_CONFIG
+        plan = []
+        for i, j in enumerate(feat_len):
+            j = int(j)
+            if C.get('prompt_dropout_enabled', True) and random.random() < C.get('prompt_dropout_prob', 0.10):
+                plan.append(dict(total=0, copy=0, cross=False, silence=0, blind=False))
+                continue
+            if C.get('dynamic_prompt_enabled', True):
+                lo = max(1, int(C.get('prompt_min_ratio', 0.10) * j))
+                hi = max(lo + 1, int(C.get('prompt_max_ratio', 0.30) * j))
+                pl = random.randint(lo, hi)
+            else:
+                pl = max(1, int(0.3 * j))
+            cross = bool(C.get('cross_sample_enabled', True) and cross_len is not None and int(cross_len[i]) > 0)
+            if cross:
+                pl = min(pl, int(cross_len[i]))
+            sil = 0
+            if C.get('silence_padding_enabled', False):
+                st = random.randint(C.get('silence_min_tokens', 5), C.get('silence_max_tokens', 10))
+                frames = max(3, min(int(st * 22050 / 256 / self.input_frame_rate), 20))
+                if pl + frames < j:
+                    sil = frames
+            blind = bool(C.get('text_blinding_enabled', True) and random.random() < C.get('text_blinding_prob', 0.7))
+            plan.append(dict(total=pl + sil, copy=pl, cross=cross, silence=sil, blind=blind))
+        return plan
+
+    def forward_with_prompt(self, batch: dict, device, draws=None, plan=None) -> Dict[str, Any]:
+        """flow_model.py:248-400: flow-only training with a mel prompt as conditioning and the
+        anti-leakage strategies -- dynamic prompt length, prompt dropout, cross-sample prompts, optional silence band,
+        text blinding of the encoder output, prompt-region loss mask + boundary weight, prompt-isolation attention."""
+        num = self.numerics
+        dt = num.dtype
+        token = batch['speech_token'].to(device)
+        B, Lt = token.shape
+        feat = batch['speech_feat'].to(device).float()
+        T = feat.shape[1]
+        tok_len = to_len(batch['speech_token_len'], device)
+        feat_len = to_len(batch['speech_feat_len'], device)
+        with torch.no_grad():
+            spk = hip_linear(self.spk_embed_affine_layer, HF.l2norm_rows(batch['embedding'].to(device), dt))
+            tok = HF.embed_gather(token, self._embedding_table(dt), tok_len)
+        h = self.encoder.forward_cl(tok, B, Lt, tok_len, num, causal=False)
+        h = hip_linear(self.encoder_proj, h)
+        mu = self.length_regulator.forward_cl(h, B, Lt, T, feat_len)
+        cross = batch.get('cross_sample_mel')
+        cross_len = batch.get('cross_sample_mel_len') if cross is not None else None
+        if plan is None:
+            plan = self.prompt_plan(batch['speech_feat_len'].tolist(), None if cross_len is None else cross_len.tolist())
+        featn = self.normalize_mel(feat)
+        crossn = None if cross is None else self.normalize_mel(cross.to(device).float())
+        sil_val = (ANTI_LEAKAGE_CONFIG.get('silence_mel_value', -11.5) - self.mel_mean) / self.mel_std
+        conds = torch.zeros_like(featn)
+        keep_rows = torch.ones(B, T, device=device, dtype=dt)
+        for i, pl in enumerate(plan):
+            c = pl['copy']
+            if c > 0:
+                conds[i, :c] = crossn[i, :c] if pl['cross'] else featn[i, :c]
+                if pl['silence'] > 0:
+                    conds[i, c:c + pl['silence']] = sil_val
+                if pl['blind']:
+                    keep_rows[i, :c] = 0.0            # text blinding: the encoder output under the prompt is zeroed
+        mu = mu * keep_rows.reshape(B * T, 1)
+        loss, _ = self.decoder.compute_loss_cl(feat, mu, spk, feat_len, B, T, num, draws, self.mel_mean, self.mel_std,
+                                               cond=conds.reshape(B * T, -1).to(dt).contiguous(),
+                                               prompt_lens=[pl['total'] for pl in plan])
+        return {'loss': loss}
+
     def forward(self, batch: dict, device) -> Dict[str, Any]:
-        return self.forward_no_prompt(batch, device)
+        """flow_model.py:248-318: the no-prompt mode when NO_PROMPT_TRAINING_CONFIG['enabled'], else the with-prompt path."""
+        if NO_PROMPT_TRAINING_CONFIG.get('enabled', False):
+            return self.forward_no_prompt(batch, device)
+        return self.forward_with_prompt(batch, device)
 
 
 def build_flow_model(pretrained_path: Optional[str] = None, device: str = 'cuda', input_size: int = 512,

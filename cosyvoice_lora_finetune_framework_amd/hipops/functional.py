@@ -1080,33 +1080,34 @@ def groupnorm_mish(x, gamma, beta, B: int, T: int, G: int, eps: float = 1e-5, le
 # ---------------------------------------------------------------------------------
 class AttnBiasFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, B: int, H: int, T: int, klen, scale: float):
+    def forward(ctx, q, k, v, B: int, H: int, T: int, klen, scale: float, iso_len: int = 0):
         assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
         assert q.stride(0) == k.stride(0) == v.stride(0)
         o = torch.empty((B * T, H * 64), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
-        check(lib().cvft_attn_bias_fwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, ptr(o),
+        check(lib().cvft_attn_bias_fwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, int(iso_len), ptr(o),
                                        o.stride(0), ptr(lse), stream()), "cvft_attn_bias_fwd")
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.args = (B, H, T, klen, scale)
+        ctx.args = (B, H, T, klen, scale, int(iso_len))
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        B, H, T, klen, scale = ctx.args
+        B, H, T, klen, scale, iso_len = ctx.args
         do = _c(do)
         dqkv = torch.empty((B * T, 3 * H * 64), dtype=q.dtype, device=q.device)
         dq, dk, dv = dqkv[:, :H * 64], dqkv[:, H * 64:2 * H * 64], dqkv[:, 2 * H * 64:]
         delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
-        check(lib().cvft_attn_bias_bwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, ptr(o),
+        check(lib().cvft_attn_bias_bwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, iso_len, ptr(o),
                                        ptr(do), o.stride(0), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                        dqkv.stride(0), stream()), "cvft_attn_bias_bwd")
-        return dq, dk, dv, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None
 
 
-def attn_bias(q, k, v, B: int, H: int, T: int, klen, scale: float):
-    return AttnBiasFn.apply(q, k, v, B, H, T, klen, scale)
+def attn_bias(q, k, v, B: int, H: int, T: int, klen, scale: float, iso_len: int = 0):
+    """iso_len > 0: prompt-isolation mask -- frames [0, iso_len) and [iso_len, T) attend only within their segment."""
+    return AttnBiasFn.apply(q, k, v, B, H, T, klen, scale, iso_len)
 
 
 class AttnRelPosFn(torch.autograd.Function):
@@ -1271,11 +1272,12 @@ class MaskedMseFn(torch.autograd.Function):
     """sum(((pred-u)*mask)^2) / denom   (reference flow_matching.py:192), denom a device scalar."""
 
     @staticmethod
-    def forward(ctx, pred, u, length, denom, B: int, T: int):
+    def forward(ctx, pred, u, length, denom, B: int, T: int, weight=None):
         pred = _c(pred)
         Cn = pred.shape[1]
         s = torch.zeros(1, dtype=torch.float32, device=pred.device)
-        check(lib().cvft_masked_mse_fwd(dt(pred), B, T, Cn, ptr(pred), ptr(u), ptr(length), ptr(s), stream()),
+        ctx.weight = None if weight is None else _c(weight.float())
+        check(lib().cvft_masked_mse_fwd(dt(pred), B, T, Cn, ptr(pred), ptr(u), ptr(length), ptr(ctx.weight), ptr(s), stream()),
               "cvft_masked_mse_fwd")
         ctx.save_for_backward(pred, u, length, denom)
         ctx.dims = (B, T, Cn)
@@ -1287,13 +1289,14 @@ class MaskedMseFn(torch.autograd.Function):
         B, T, Cn = ctx.dims
         gs = (g.float() / denom).reshape(1).contiguous()
         dpred = torch.empty_like(pred)
-        check(lib().cvft_masked_mse_bwd(dt(pred), B, T, Cn, ptr(pred), ptr(u), ptr(length), ptr(gs), ptr(dpred), stream()),
-              "cvft_masked_mse_bwd")
-        return dpred, None, None, None, None, None
+        check(lib().cvft_masked_mse_bwd(dt(pred), B, T, Cn, ptr(pred), ptr(u), ptr(length), ptr(ctx.weight), ptr(gs), ptr(dpred),
+                                        stream()), "cvft_masked_mse_bwd")
+        return dpred, None, None, None, None, None, None
 
 
-def masked_mse(pred, u, length, denom, B: int, T: int):
-    return MaskedMseFn.apply(pred, u, length, denom, B, T)
+def masked_mse(pred, u, length, denom, B: int, T: int, weight=None):
+    """weight [B*T] fp32 (optional): per-frame loss weights, entering squared like the reference's (pred-u)*loss_mask."""
+    return MaskedMseFn.apply(pred, u, length, denom, B, T, weight)
 
 
 class CrossEntropyFn(torch.autograd.Function):

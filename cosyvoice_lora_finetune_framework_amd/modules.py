@@ -279,11 +279,11 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
 
-    def forward(self, x, B, T, length, gelu: str):
+    def forward(self, x, B, T, length, gelu: str, iso_len: int = 0):
         a = self.attn1
         x, y = hip_layernorm_fork(self.norm1, x)
         q, k, v = hip_qkv(a.to_q, a.to_k, a.to_v, y)
-        o = HF.attn_bias(q, k, v, B, a.heads, T, length, a.scale)
+        o = HF.attn_bias(q, k, v, B, a.heads, T, length, a.scale, iso_len)
         x = hip_linear(a.to_out[0], o, residual=x)
         x, y = hip_layernorm_fork(self.norm3, x)
         act = "gelu_tanh" if self.ff.net[0].approximate == "tanh" else gelu
@@ -341,9 +341,15 @@ class ConditionalDecoder(nn.Module):
     def forward_cl(self, xin, t, B: int, T: int, length, gelu: str = "gelu_erf"):
         """xin [B*T, in_channels] (already [y|mu|spk|cond] packed), t [B] fp32, length int32 [B]
         -> [B*T, out_channels] (masked)."""
-        if self.prompt_isolation_len:
-            raise NotImplementedError("prompt-isolation attention mask (SURVEY 8f rank 4) is not built yet")
         dtype = xin.dtype
+        plen = self.prompt_isolation_len if self.prompt_isolation_enabled else 0
+
+        def iso(Tl: int) -> int:
+            """modules.py:1033-1042: the prompt / target split rescaled to this U-Net level (block-diagonal attention)."""
+            if plen <= 0:
+                return 0
+            sp = max(1, int(plen * (Tl / T)))
+            return sp if sp < Tl else 0
         with torch.no_grad():
             temb = self.time_mlp(self.time_embeddings(t, dtype=dtype))
             temb_mish = HF.act_fwd(temb, "mish")
@@ -353,7 +359,7 @@ class ConditionalDecoder(nn.Module):
         for resnet, tblocks, down in self.down_blocks:
             x = resnet(x, B, Tc, lc, temb_mish)
             for tb in tblocks:
-                x = tb(x, B, Tc, lc, gelu)
+                x = tb(x, B, Tc, lc, gelu, iso(Tc))
             hiddens.append((x, Tc, lc))
             if isinstance(down, Downsample1D):
                 pk = conv_pack(down.conv, dtype)
@@ -366,14 +372,14 @@ class ConditionalDecoder(nn.Module):
         for resnet, tblocks in self.mid_blocks:
             x = resnet(x, B, Tc, lc, temb_mish)
             for tb in tblocks:
-                x = tb(x, B, Tc, lc, gelu)
+                x = tb(x, B, Tc, lc, gelu, iso(Tc))
         for resnet, tblocks, up in self.up_blocks:
             skip, Ts, ls = hiddens.pop()
             assert Ts == Tc, (Ts, Tc)
             x = torch.cat([x, skip], dim=1)
             x = resnet(x, B, Ts, ls, temb_mish)
             for tb in tblocks:
-                x = tb(x, B, Ts, ls, gelu)
+                x = tb(x, B, Ts, ls, gelu, iso(Ts))
             if isinstance(up, Upsample1D):
                 Tn = hiddens[-1][1]                 # cropped to the next skip's length
                 x = HF.conv1d(x, conv_pack(up.conv, dtype), B, Ts, Tn, in_len=ls)

@@ -163,9 +163,11 @@ int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, const void* x
  * (B,T,T) mask_to_bias tensor (decoder.py:238-240, utils.py:103-109).
  * ------------------------------------------------------------------------------- */
 int cvft_attn_bias_fwd(int dtype, int B, int H, int T, const void* q, const void* k, const void* v, int ld,
-                       const int32_t* klen, float scale, void* o, int ldo, float* lse, void* stream);
+                       const int32_t* klen, float scale, int iso_len, void* o, int ldo, float* lse, void* stream);
+/* iso_len > 0: prompt-isolation mask (modules.py:844-879): frames [0, iso_len) and [iso_len, T) attend only within
+ * their own segment (block-diagonal -inf bias on top of the key-padding bias). */
 int cvft_attn_bias_bwd(int dtype, int B, int H, int T, const void* q, const void* k, const void* v, int ld,
-                       const int32_t* klen, float scale, const void* o, const void* d_o, int ldo,
+                       const int32_t* klen, float scale, int iso_len, const void* o, const void* d_o, int ldo,
                        const float* lse, float* delta /*[B][H][T] ws*/, void* dq, void* dk, void* dv, int ldg,
                        void* stream);
 
@@ -232,10 +234,12 @@ int cvft_cfm_prepare(int dtype, int B, int T, const float* feat, const float* z,
                      float mel_mean, float mel_std, float sigma_min, void* xin, float* u, float* t, void* stream);
 /* masked MSE (flow_matching.py:192): loss_sum[0] += sum(((pred-u)*m)^2) (caller divides by sum(mask)*80);
  * backward: dpred = gscale[0] * 2 * (pred-u) * m  with gscale a DEVICE scalar (= upstream grad / denominator). */
+/* w (or NULL): per-frame loss weights [B*T] fp32 -- loss_sum += sum(((pred-u) * w)^2) over frames t < len[b]
+ * (prompt region 0, boundary frames > 1: flow_model.py:179-202; note the weight enters squared, as in the reference) */
 int cvft_masked_mse_fwd(int dtype, int B, int T, int C, const void* pred, const float* u, const int32_t* len,
-                        float* loss_sum, void* stream);
+                        const float* w, float* loss_sum, void* stream);
 int cvft_masked_mse_bwd(int dtype, int B, int T, int C, const void* pred, const float* u, const int32_t* len,
-                        const float* gscale, void* dpred, void* stream);
+                        const float* w, const float* gscale, void* dpred, void* stream);
 /* linear interpolation along time (F.interpolate mode='linear', align_corners=False), channel-last.
  * x [B][Lin][C] -> y [B][Lout][C]   (length_regulator.py:47) */
 int cvft_interp_linear_fwd(int dtype, int B, int Lin, int Lout, int C, const void* x, void* y, void* stream);

@@ -241,9 +241,11 @@ def basic_transformer_block(sd, p: str, x, bias, cfg: OracleConfig):
     return x + lora_linear(sd, f"{p}.ff.net.2", y, s)
 
 
-def estimator(sd, p: str, x, mask, mu, t, spks, cond, cfg: OracleConfig):
-    """cosyvoice/flow/decoder.py:210-291 == modules.py:998-1106 (prompt isolation off).
-    x,mu,cond (B,80,T); mask (B,1,T); t (B,); spks (B,80)."""
+def estimator(sd, p: str, x, mask, mu, t, spks, cond, cfg: OracleConfig, prompt_len: int = 0):
+    """cosyvoice/flow/decoder.py:210-291 == modules.py:998-1106.  x,mu,cond (B,80,T); mask (B,1,T); t (B,); spks (B,80).
+    prompt_len > 0: the twin's prompt-isolation bias (modules.py:844-879, 1033-1042) -- block-diagonal -inf at the
+    split rescaled to each U-Net level."""
+    T_full = x.shape[-1]
     g = cfg.est_groups
     in_ch = sd[f"{p}.time_mlp.linear_1.weight"].shape[1]
     temb = sinusoidal_pos_emb(t, in_ch).to(t.dtype)
@@ -254,6 +256,14 @@ def estimator(sd, p: str, x, mask, mu, t, spks, cond, cfg: OracleConfig):
     def tblocks(x, m, bp):
         xt = x.transpose(1, 2).contiguous()
         bias = mask_to_bias(m.bool().expand(-1, xt.size(1), -1), xt.dtype)
+        if prompt_len > 0:
+            n = xt.size(1)
+            sp = max(1, int(prompt_len * (n / T_full)))
+            if sp < n:
+                iso = torch.zeros(1, n, n, dtype=xt.dtype)
+                iso[:, sp:, :sp] = float("-inf")
+                iso[:, :sp, sp:] = float("-inf")
+                bias = bias + iso
         for j in range(_count(sd, bp)):
             xt = basic_transformer_block(sd, f"{bp}.{j}", xt, bias, cfg)
         return xt.transpose(1, 2).contiguous()
@@ -362,6 +372,53 @@ def flow_forward(sd, batch, draws, cfg: OracleConfig, return_all: bool = False):
     if return_all:
         return dict(loss=loss, h_enc=h_enc, mu=mu, y=y, u=u, pred=pred, t=t.view(-1))
     return loss
+
+
+def flow_forward_prompt(sd, batch, draws, cfg: OracleConfig, plan, boundary_frames: int, boundary_weight: float,
+                        silence_value: float = -11.5, return_all: bool = False):
+    """flow_model.py:248-400 + 137-204 (flow-only training with a mel prompt and the anti-leakage strategies), given the
+    per-utterance decisions `plan` = [{total, copy, cross, silence, blind}] the reference draws from `random`."""
+    s = cfg.flow_lora_scale
+    token, token_len = batch["speech_token"], batch["speech_token_len"]
+    feat = (batch["speech_feat"].float() - cfg.mel_mean) / cfg.mel_std
+    feat_len = batch["speech_feat_len"]
+    emb = F.normalize(batch["embedding"].float(), dim=1)
+    emb = lora_linear(sd, "spk_embed_affine_layer", emb, s)
+    tmask = (~make_pad_mask(token_len)).float().unsqueeze(-1)
+    tok = F.embedding(torch.clamp(token, min=0), sd["input_embedding.weight"]) * tmask
+    h_enc, _ = encoder(sd, "encoder", tok, token_len, kind="conformer", causal=False,
+                       ln_eps=cfg.flow_enc_ln_eps, xscale=cfg.flow_xscale, scale=s)
+    h = lora_linear(sd, "encoder_proj", h_enc, s)
+    mu = length_regulator(sd, "length_regulator", h, feat_len)                 # (B,T,80)
+    conds = torch.zeros_like(feat)
+    keep = torch.ones_like(mu[:, :, :1])
+    cross = None
+    if "cross_sample_mel" in batch:
+        cross = (batch["cross_sample_mel"].float() - cfg.mel_mean) / cfg.mel_std
+    for i, pl in enumerate(plan):
+        c = pl["copy"]
+        if c > 0:
+            conds[i, :c] = cross[i, :c] if pl["cross"] else feat[i, :c]
+            if pl["silence"] > 0:
+                conds[i, c:c + pl["silence"]] = (silence_value - cfg.mel_mean) / cfg.mel_std
+            if pl["blind"]:
+                keep[i, :c] = 0.0
+    mu = mu * keep
+    x1 = feat.transpose(1, 2).contiguous()
+    mask = (~make_pad_mask(feat_len)).to(mu).unsqueeze(1)
+    t, y, u = cfm_prepare(x1, draws["t_raw"], draws["z"], cfg.sigma_min)
+    cm = (draws["cfg_rand"] > cfg.training_cfg_rate).to(x1.dtype)
+    prompt_lens = [pl["total"] for pl in plan]
+    pred = estimator(sd, "decoder.estimator", y, mask, mu.transpose(1, 2) * cm.view(-1, 1, 1), t.view(-1),
+                     emb * cm.view(-1, 1), conds.transpose(1, 2) * cm.view(-1, 1, 1), cfg, prompt_len=max(prompt_lens))
+    loss_mask = mask.clone()
+    for i, pl in enumerate(prompt_lens):
+        if pl > 0:
+            loss_mask[i, :, :pl] = 0
+            loss_mask[i, :, pl:min(pl + boundary_frames, loss_mask.shape[2])] = boundary_weight
+    diff = (pred - u) * loss_mask
+    loss = (diff ** 2).sum() / (torch.sum(loss_mask) * u.shape[1])
+    return dict(loss=loss, cond=conds.transpose(1, 2), mu=mu.transpose(1, 2)) if return_all else loss
 
 
 # ---------------------------------------------------------------------------------

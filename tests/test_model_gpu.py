@@ -279,3 +279,41 @@ def test_sub_batch_chains_reproduce_global_batch_means(tiny_meta):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (outs[0][0], outs[1][0])
     assert set(outs[0][1]) == set(outs[1][1])
     assert max(rel(outs[1][1][k], outs[0][1][k]) for k in outs[0][1]) < 1e-4
+
+
+def test_flow_prompt_path_loss_and_grads(tiny_meta):
+    """MaskedDiffWithXvec.forward with prompts and the anti-leakage strategies (flow_model.py:248-400,
+    137-204) -- the product's forward() under the reference's `random` seed reproduces the reference's per-utterance
+    decisions (dropout / dynamic length / cross-sample / silence band / text blinding), loss and LoRA gradients."""
+    import random
+    from cosyvoice_lora_finetune_framework_amd import flow_model as FM
+    g, meta = load_npz("flow_prompt_tiny.npz"), load_json("flow_prompt_meta.json")
+    m = build_flow_product(tiny_meta["flow"], DEV, _numerics("vendored"))
+    draws = dict(t_raw=g["draw_t_raw"], z=g["draw_z"], cfg_rand=g["draw_cfg_rand"])
+    old = (FM.ANTI_LEAKAGE_CONFIG, FM.NO_PROMPT_TRAINING_CONFIG)
+    FM.ANTI_LEAKAGE_CONFIG, FM.NO_PROMPT_TRAINING_CONFIG = meta["anti_leakage"], {"enabled": False}
+    seen = {}
+    orig = m.decoder.compute_loss_cl
+
+    def spy(*a, **kw):
+        seen.update(prompt_lens=list(kw["prompt_lens"]), cond=kw["cond"].detach().clone(), mu=a[1].detach().clone())
+        return orig(*a, **kw)
+    m.decoder.compute_loss_cl = spy
+    try:
+        random.seed(meta["random_seed"])
+        out = m.forward_with_prompt(_batch(g), DEV, draws)
+    finally:
+        FM.ANTI_LEAKAGE_CONFIG, FM.NO_PROMPT_TRAINING_CONFIG = old
+    B, _, T = g["cond"].shape
+    assert seen["prompt_lens"] == g["prompt_lens"].tolist()
+    assert rel(seen["cond"].reshape(B, T, 80).transpose(1, 2), g["cond"]) < 1e-6
+    assert rel(seen["mu"].reshape(B, T, 80).transpose(1, 2), g["mu"]) < 1e-4
+    ref = float(g["loss"])
+    assert abs(float(out["loss"]) - ref) / ref < LOSS_TOL, (float(out["loss"]), ref)
+    out["loss"].backward()
+    grads = lora_grads(m)
+    refg = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith("grad/")}
+    assert set(grads) == set(refg)
+    worst = max(rel(grads[k], refg[k]) for k in refg)
+    assert worst < GRAD_TOL, worst
+    assert m.decoder.estimator.prompt_isolation_len == 0          # reset after the step (flow_model.py:176-177)

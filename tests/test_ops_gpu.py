@@ -191,6 +191,63 @@ def test_attn_bias(dtype, T, lens):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,lens,iso", [(50, [50, 33], 7), (131, [131, 64], 64), (131, [131, 40], 65), (64, [64, 1], 1),
+                                        (200, [200, 150], 199), (96, [96, 96], 96)])
+def test_attn_bias_prompt_isolation(dtype, T, lens, iso):
+    """The twin's prompt-isolation bias (modules.py:844-879, 1033-1042): -inf between [0, iso) and [iso, T), added to the
+    -1e10 key-padding bias; covers a split inside/at a key tile edge, an utterance that ends before the split, and
+    iso >= T (no-op).  Compared on the valid query rows: a padded query row whose visible keys are all padding (utterance
+    shorter than the split) is a uniform mean of V in the reference and 0 here -- the estimator multiplies padded frames
+    by the mask before anything reads them (decoder.py:240-281) and they receive no gradient, so dO is 0 there."""
+    HF = HFmod()
+    B, H = 2, 2
+    qkv = q(rnd(B, T, 3 * H * 64, seed=1), dtype)
+    valid = _masks(lens, T).unsqueeze(-1)
+    gy = q(rnd(B, T, H * 64, seed=2), dtype) * valid
+    qr = qkv.double().requires_grad_(True)
+    qq, kk, vv = (t.reshape(B, T, H, 64).transpose(1, 2) for t in qr.split(H * 64, dim=-1))
+    bias = ((1.0 - _masks(lens, T)).double() * -1.0e10).view(B, 1, 1, T).expand(B, 1, T, T).clone()
+    if iso < T:
+        bias[:, :, iso:, :iso] = float("-inf")
+        bias[:, :, :iso, iso:] = float("-inf")
+    sim = qq @ kk.transpose(-1, -2) * 0.125 + bias
+    orf = (sim.softmax(-1) @ vv).transpose(1, 2).reshape(B, T, H * 64)
+    orf.backward(gy.double())
+    qd = qkv.reshape(B * T, -1).to(DEV, dtype).requires_grad_(True)
+    o = HF.attn_bias(qd[:, :H * 64], qd[:, H * 64:2 * H * 64], qd[:, 2 * H * 64:], B, H, T,
+                     torch.tensor(lens, dtype=torch.int32, device=DEV), 0.125, iso if iso < T else 0)
+    o.backward(gy.reshape(B * T, -1).to(DEV, dtype))
+    assert torch.isfinite(o).all() and torch.isfinite(qd.grad).all()
+    assert rel(o.reshape(B, T, -1).cpu() * valid, orf * valid) < TOL[dtype]
+    assert rel(qd.grad.reshape(B, T, -1), qr.grad) < TOL[dtype] * 3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_masked_mse_frame_weights(dtype):
+    """flow_model.py:183-202: loss_mask with the prompt zeroed and a boundary weight; the weight multiplies the residual
+    (so it enters squared) and the denominator is sum(loss_mask) * 80.  The boundary band is written past an utterance's
+    end too (the reference does not re-mask it)."""
+    HF = HFmod()
+    B, T, lens, plens, bf, bw = 3, 37, [37, 20, 9], [5, 0, 7], 6, 3.0
+    pred = q(rnd(B, T, 80, seed=1), dtype)
+    u = rnd(B, T, 80, seed=2)
+    w = _masks(lens, T).clone()
+    for i, pl in enumerate(plens):
+        if pl > 0:
+            w[i, :pl] = 0
+            w[i, pl:min(pl + bf, T)] = bw
+    pr = pred.double().requires_grad_(True)
+    lr = (((pr - u.double()) * w.unsqueeze(-1).double()) ** 2).sum() / (w.sum().double() * 80)
+    lr.backward()
+    pd = pred.reshape(B * T, 80).to(DEV, dtype).requires_grad_(True)
+    den = (w.sum() * 80).float().to(DEV)
+    loss = HF.masked_mse(pd, u.reshape(B * T, 80).to(DEV), None, den, B, T, weight=w.reshape(-1).float().to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(lr)) / float(lr) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert rel(pd.grad.reshape(B, T, 80), pr.grad) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("L,lens", [(45, [45, 30]), (130, [130, 77]), (64, [64, 64])])
 def test_attn_relpos(dtype, causal, L, lens):

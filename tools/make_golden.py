@@ -280,6 +280,53 @@ def gen_data():
     npz_save(os.path.join(GOLD, "data_path.npz"), **arr)
 
 
+def gen_prompt():
+    """Anti-leakage flow-only training path: the reference's MaskedDiffWithXvec.forward with prompts
+    on the tiny LoRA-wrapped flow model, under random.seed / torch.manual_seed; the per-utterance decisions it drew are
+    recovered from the compute_loss call and stored with the loss and the LoRA gradients."""
+    import random
+    import flow_model as ref_fm
+    cfg_al = {'silence_padding_enabled': True, 'silence_min_tokens': 5, 'silence_max_tokens': 10, 'silence_mel_value': -11.5,
+              'dynamic_prompt_enabled': True, 'prompt_min_ratio': 0.10, 'prompt_max_ratio': 0.30,
+              'prompt_dropout_enabled': True, 'prompt_dropout_prob': 0.25, 'boundary_loss_enabled': True, 'boundary_frames': 25,
+              'boundary_loss_weight': 3.0, 'cross_sample_enabled': True, 'cross_sample_prob': 0.5,
+              'text_blinding_enabled': True, 'text_blinding_prob': 0.7}
+    old = (ref_fm.ANTI_LEAKAGE_CONFIG, ref_fm.NO_PROMPT_TRAINING_CONFIG)
+    ref_fm.ANTI_LEAKAGE_CONFIG, ref_fm.NO_PROMPT_TRAINING_CONFIG = cfg_al, {'enabled': False}
+    try:
+        batch = synth_batch([44, 37, 29, 40], text_lens=[7, 5, 6, 4], token_lens=[24, 20, 15, 21], seed=21, text_vocab=100, speech_vocab=50)
+        g = torch.Generator().manual_seed(8)
+        batch['cross_sample_mel'] = torch.randn(4, 9, 80, generator=g) * 2 - 6
+        batch['cross_sample_mel_len'] = torch.tensor([9, 0, 6, 9])
+        torch.manual_seed(0)
+        m = build_ref_flow('vendored', **TINY_FLOW)
+        spec, _ = wrap_and_fill(m, r=4, alpha=8, targets=FLOW_TARGETS, seed=3)
+        m.eval()
+        cap = {}
+        orig = m.decoder.compute_loss
+
+        def spy(x1, mask, mu, spks=None, cond=None, prompt_lens=None):
+            cap.update(mu=mu.detach().clone(), cond=cond.detach().clone(), prompt_lens=list(prompt_lens))
+            return orig(x1, mask, mu, spks, cond=cond, prompt_lens=prompt_lens)
+        m.decoder.compute_loss = spy
+        random.seed(123)
+        torch.manual_seed(77)
+        out = m(batch, torch.device('cpu'))
+        out['loss'].backward()
+        grads = lora_grads(m)
+        draws = cfm_draws(4, 44, seed=77)
+    finally:
+        ref_fm.ANTI_LEAKAGE_CONFIG, ref_fm.NO_PROMPT_TRAINING_CONFIG = old
+    print(f"prompt path: loss={out['loss'].item():.8f} prompt_lens={cap['prompt_lens']}")
+    arr = dict(loss=out['loss'].detach(), cond=cap['cond'], mu=cap['mu'], prompt_lens=torch.tensor(cap['prompt_lens']),
+               draw_t_raw=draws['t_raw'], draw_z=draws['z'], draw_cfg_rand=draws['cfg_rand'], **{f"in_{k}": v for k, v in batch.items()})
+    for k, gr in grads.items():
+        arr[f"grad/{k}"] = gr
+    npz_save(os.path.join(GOLD, "flow_prompt_tiny.npz"), **arr)
+    with open(os.path.join(GOLD, "flow_prompt_meta.json"), "w") as f:
+        json.dump(dict(anti_leakage=cfg_al, random_seed=123, draw_seed=77), f, indent=1)
+
+
 def run_flow_nograd(model, batch, seed):
     jm = ref_joint.JointLLMFlowModel(nn.Identity(), model, 'flow_only')
     torch.manual_seed(seed)
@@ -463,6 +510,8 @@ if __name__ == "__main__":
         gen_sampler()
     if a.only in ("all", "data"):
         gen_data()
+    if a.only in ("all", "prompt"):
+        gen_prompt()
     if a.only in ("all", "train"):
         gen_train()
     if a.only in ("all", "full"):
