@@ -262,10 +262,75 @@ class MaskedDiffWithXvec(nn.Module):
         return {'loss': loss}
 
     def forward(self, batch: dict, device) -> Dict[str, Any]:
-        """flow_model.py:248-318: the no-prompt mode when NO_PROMPT_TRAINING_CONFIG['enabled'], else the with-prompt path."""
+        """flow_model.py:248-318: the no-prompt mode when NO_PROMPT_TRAINING_CONFIG['enabled'] ('full': conditioning all
+        zero; 'mixed' :437-455: per utterance, with probability 1 - no_prompt_ratio, a short own-mel prompt with its loss
+        mask / isolation and none of the anti-leakage strategies), else the with-prompt path."""
         if NO_PROMPT_TRAINING_CONFIG.get('enabled', False):
-            return self.forward_no_prompt(batch, device)
+            if NO_PROMPT_TRAINING_CONFIG.get('mode', 'full') == 'full':
+                return self.forward_no_prompt(batch, device)
+            ratio = NO_PROMPT_TRAINING_CONFIG.get('no_prompt_ratio', 0.8)
+            plan = []
+            for j in batch['speech_feat_len'].tolist():
+                pl = 0 if random.random() < ratio else random.randint(1, max(2, int(0.1 * int(j))))
+                plan.append(dict(total=pl, copy=pl, cross=False, silence=0, blind=False))
+            return self.forward_with_prompt(batch, device, plan=plan)
         return self.forward_with_prompt(batch, device)
+
+    @staticmethod
+    def ode_steps_for(n_frames: int) -> int:
+        """flow_model.py:525-536: Euler steps by sequence length."""
+        return 20 if n_frames > 500 else 15 if n_frames > 300 else 10
+
+    def _encode_one(self, token, embedding, device):
+        """spk projection + token embedding + encoder + encoder_proj for one utterance: ([L, 80], [1, 80])."""
+        num, dt = self.numerics, self.numerics.dtype
+        L = token.shape[1]
+        ln = torch.tensor([L], dtype=torch.int32, device=device)
+        spk = hip_linear(self.spk_embed_affine_layer, HF.l2norm_rows(embedding.to(device), dt))
+        tok = HF.embed_gather(token.to(device), self._embedding_table(dt), ln)
+        h = self.encoder.forward_cl(tok, 1, L, ln, num, causal=False)
+        return hip_linear(self.encoder_proj, h), spk
+
+    @torch.no_grad()
+    def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding,
+                  flow_cache=None, noise: Optional[torch.Tensor] = None):
+        """flow_model.py:474-551 (batch 1): prompt + target tokens through the encoder, head/mid/tail length regulation,
+        the prompt mel as conditioning, Euler steps by length (HIP estimator); returns (target mel (1,80,mel_len2) fp32,
+        new cache).  Like the reference it does not normalise the mel.  `noise` pins the sampler's initial z."""
+        assert token.shape[0] == 1
+        device = self.input_embedding.weight.device
+        n1, n2 = prompt_token.shape[1], token.shape[1]
+        h, spk = self._encode_one(torch.cat([prompt_token, token], dim=1), embedding, device)
+        mel1, mel2 = prompt_feat.shape[1], int(n2 / self.input_frame_rate * 22050 / 256)
+        mu = self.length_regulator.inference_cl(h[:n1], h[n1:], mel1, mel2, self.input_frame_rate)
+        T = mel1 + mel2
+        cond = torch.zeros(1, T, self.output_size, device=device, dtype=torch.float32)
+        cond[:, :mel1] = prompt_feat.to(device)
+        feat, cache = self.decoder(mu=mu.float().t().unsqueeze(0).contiguous(), mask=torch.ones(1, 1, T, device=device),
+                                   n_timesteps=self.ode_steps_for(T), spks=spk.float(), cond=cond.transpose(1, 2).contiguous(),
+                                   prompt_len=mel1, cache=flow_cache, noise=noise, num=self.numerics)
+        return feat[:, :, mel1:].float(), cache
+
+    @torch.no_grad()
+    def inference_like_training(self, token, token_len, feat_len, embedding, prompt_feat=None, prompt_len=0, n_timesteps=10,
+                                noise: Optional[torch.Tensor] = None):
+        """flow_model.py:553-638 (batch 1): the whole token sequence regulated to feat_len frames as in training, optional
+        prompt conditioning of prompt_len frames -> full mel (1,80,feat_len) fp32."""
+        assert token.shape[0] == 1
+        device = self.input_embedding.weight.device
+        T = int(feat_len.item()) if torch.is_tensor(feat_len) else int(feat_len)
+        h, spk = self._encode_one(token, embedding, device)
+        mu = self.length_regulator.forward_cl(h, 1, token.shape[1], T, torch.tensor([T], dtype=torch.int32, device=device))
+        cond = torch.zeros(1, T, self.output_size, device=device, dtype=torch.float32)
+        if prompt_feat is not None and prompt_len > 0:
+            n = min(prompt_len, prompt_feat.shape[1], T)
+            cond[:, :n] = prompt_feat[:, :n].to(device)
+        if n_timesteps is None or n_timesteps == 10:
+            n_timesteps = self.ode_steps_for(T)
+        feat, _ = self.decoder(mu=mu.float().t().unsqueeze(0).contiguous(), mask=torch.ones(1, 1, T, device=device),
+                               n_timesteps=n_timesteps, spks=spk.float(), cond=cond.transpose(1, 2).contiguous(),
+                               prompt_len=prompt_len if prompt_feat is not None else 0, cache=None, noise=noise, num=self.numerics)
+        return feat.float()
 
 
 def build_flow_model(pretrained_path: Optional[str] = None, device: str = 'cuda', input_size: int = 512,

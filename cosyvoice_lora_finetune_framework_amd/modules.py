@@ -588,9 +588,28 @@ class InterpolateRegulator(nn.Module):
         model.append(nn.Conv1d(channels, out_channels, 1, 1))
         self.model = nn.Sequential(*model)
 
+    def inference_cl(self, x1, x2, mel_len1: int, mel_len2: int, input_frame_rate: int = 50):
+        """length_regulator.py:52-70 == modules.py:823-838 (batch 1): x1 [L1, C] prompt part, x2 [L2, C] target part ->
+        [mel_len1 + mel_len2, C].  The parts are interpolated separately, the target's first / last 20 tokens at the
+        nominal rate and its middle taking up the slack, so the prompt/target seam falls on an exact frame."""
+        up = lambda t, n: HF.interp_linear(t.contiguous(), 1, t.shape[0], n)
+        if x2.shape[0] > 40:
+            e = int(20 / input_frame_rate * 22050 / 256)
+            x2 = torch.cat([up(x2[:20], e), up(x2[20:-20], mel_len2 - 2 * e), up(x2[-20:], e)], dim=0)
+        else:
+            x2 = up(x2, mel_len2)
+        x = torch.cat([up(x1, mel_len1), x2], dim=0) if x1.shape[0] != 0 else x2
+        return self._stack_cl(x.contiguous(), 1, mel_len1 + mel_len2, None)
+
+    def inference(self, x1, x2, mel_len1, mel_len2, input_frame_rate=50):
+        out = self.inference_cl(x1[0], x2[0], int(mel_len1), int(mel_len2), input_frame_rate)
+        return out.unsqueeze(0), mel_len1 + mel_len2
+
     def forward_cl(self, x, B: int, Lin: int, T: int, ylen):
         """x [B*Lin, C] -> [B*T, C] masked by ylen (int32 [B])."""
-        x = HF.interp_linear(x, B, Lin, T)
+        return self._stack_cl(HF.interp_linear(x, B, Lin, T), B, T, ylen)
+
+    def _stack_cl(self, x, B: int, T: int, ylen):
         mods = list(self.model)
         i = 0
         while i + 2 < len(mods):

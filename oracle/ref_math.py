@@ -301,18 +301,40 @@ def estimator(sd, p: str, x, mask, mu, t, spks, cond, cfg: OracleConfig, prompt_
     return _conv(sd, f"{p}.final_proj", x * m) * mask
 
 
-def length_regulator(sd, p: str, x: torch.Tensor, ylens: torch.Tensor):
-    """cosyvoice/flow/length_regulator.py:44-50 == modules.py:817-821."""
-    mask = (~make_pad_mask(ylens)).to(x).unsqueeze(-1)
-    x = F.interpolate(x.transpose(1, 2).contiguous(), size=int(ylens.max()), mode="linear")
+def _regulator_stack(sd, p: str, x: torch.Tensor):
+    """The conv stack of InterpolateRegulator (length_regulator.py:29-42): [Conv1d k3, GroupNorm(1), Mish] x n, Conv1d k1."""
     n = 0
     while f"{p}.model.{n + 1}.weight" in sd and sd[f"{p}.model.{n}.weight"].dim() == 3 and sd[f"{p}.model.{n + 1}.weight"].dim() == 1:
         x = _conv(sd, f"{p}.model.{n}", x, padding=1)
         x = F.group_norm(x, 1, sd[f"{p}.model.{n + 1}.weight"], sd[f"{p}.model.{n + 1}.bias"], 1e-5)
         x = F.mish(x)
         n += 3
-    x = _conv(sd, f"{p}.model.{n}", x)
-    return x.transpose(1, 2).contiguous() * mask
+    return _conv(sd, f"{p}.model.{n}", x)
+
+
+def length_regulator(sd, p: str, x: torch.Tensor, ylens: torch.Tensor):
+    """cosyvoice/flow/length_regulator.py:44-50 == modules.py:817-821."""
+    mask = (~make_pad_mask(ylens)).to(x).unsqueeze(-1)
+    x = F.interpolate(x.transpose(1, 2).contiguous(), size=int(ylens.max()), mode="linear")
+    return _regulator_stack(sd, p, x).transpose(1, 2).contiguous() * mask
+
+
+def length_regulator_inference(sd, p: str, x1, x2, mel_len1: int, mel_len2: int, input_frame_rate: int = 50):
+    """length_regulator.py:52-70 == modules.py:823-838: prompt part and target part interpolated separately, the target's
+    first / last 20 tokens at the nominal rate and the middle taking up the slack, so the prompt/target seam is exact."""
+    up = lambda t, n: F.interpolate(t.transpose(1, 2).contiguous(), size=n, mode="linear")
+    if x2.shape[1] > 40:
+        e = int(20 / input_frame_rate * 22050 / 256)
+        x2 = torch.cat([up(x2[:, :20], e), up(x2[:, 20:-20], mel_len2 - 2 * e), up(x2[:, -20:], e)], dim=2)
+    else:
+        x2 = up(x2, mel_len2)
+    x = torch.cat([up(x1, mel_len1), x2], dim=2) if x1.shape[1] != 0 else x2
+    return _regulator_stack(sd, p, x).transpose(1, 2).contiguous()
+
+
+def ode_steps_for(n_frames: int) -> int:
+    """flow_model.py:525-536: Euler steps by sequence length."""
+    return 20 if n_frames > 500 else 15 if n_frames > 300 else 10
 
 
 def cfm_prepare(x1, t_raw, z, sigma_min: float):
@@ -342,6 +364,45 @@ def cfm_sample(sd, p: str, z, mu, mask, spks, cond, n_timesteps: int, cfg: Oracl
         if step < len(t_span) - 1:
             dt = t_span[step + 1] - t
     return x.float()
+
+
+def _flow_encode(sd, token, token_len, embedding, cfg: OracleConfig):
+    emb = lora_linear(sd, "spk_embed_affine_layer", F.normalize(embedding.float(), dim=1), cfg.flow_lora_scale)
+    tmask = (~make_pad_mask(token_len)).float().unsqueeze(-1)
+    tok = F.embedding(torch.clamp(token, min=0), sd["input_embedding.weight"]) * tmask
+    h, _ = encoder(sd, "encoder", tok, token_len, kind="conformer", causal=False, ln_eps=cfg.flow_enc_ln_eps,
+                   xscale=cfg.flow_xscale, scale=cfg.flow_lora_scale)
+    return lora_linear(sd, "encoder_proj", h, cfg.flow_lora_scale), emb
+
+
+def flow_inference(sd, token, prompt_token, prompt_feat, embedding, z, cfg: OracleConfig, input_frame_rate: int = 50):
+    """flow_model.py:474-551 (MaskedDiffWithXvec.inference, batch 1, no flow cache): prompt + target tokens through the
+    encoder, head/mid/tail length regulation, prompt mel as conditioning, Euler steps by length; returns the target part
+    (1,80,mel_len2) and the cache (1,80,prompt+34,2) of flow_model.py:84-93.  z (1,80,T): the sampler's initial noise."""
+    n1, n2 = prompt_token.shape[1], token.shape[1]
+    tok = torch.cat([prompt_token, token], dim=1)
+    h, emb = _flow_encode(sd, tok, torch.tensor([n1 + n2]), embedding, cfg)
+    mel1, mel2 = prompt_feat.shape[1], int(n2 / input_frame_rate * 22050 / 256)
+    mu = length_regulator_inference(sd, "length_regulator", h[:, :n1], h[:, n1:], mel1, mel2, input_frame_rate).transpose(1, 2)
+    cond = torch.zeros(1, 80, mel1 + mel2)
+    cond[:, :, :mel1] = prompt_feat.transpose(1, 2)
+    cache = torch.stack([torch.cat([z[:, :, :mel1], z[:, :, -34:]], dim=2), torch.cat([mu[:, :, :mel1], mu[:, :, -34:]], dim=2)], dim=-1)
+    out = cfm_sample(sd, "decoder.estimator", z, mu, torch.ones(1, 1, mel1 + mel2), emb, cond, ode_steps_for(mel1 + mel2), cfg)
+    return out[:, :, mel1:], cache
+
+
+def flow_inference_like_training(sd, token, feat_len: int, embedding, z, cfg: OracleConfig, prompt_feat=None,
+                                 prompt_len: int = 0, n_timesteps: int = 10):
+    """flow_model.py:553-638: whole token sequence, plain length regulation to feat_len, optional prompt conditioning."""
+    h, emb = _flow_encode(sd, token, torch.tensor([token.shape[1]]), embedding, cfg)
+    mu = length_regulator(sd, "length_regulator", h, torch.tensor([feat_len])).transpose(1, 2)
+    cond = torch.zeros(1, 80, feat_len)
+    if prompt_feat is not None and prompt_len > 0:
+        n = min(prompt_len, prompt_feat.shape[1], feat_len)
+        cond[:, :, :n] = prompt_feat[:, :n].transpose(1, 2)
+    if n_timesteps is None or n_timesteps == 10:
+        n_timesteps = ode_steps_for(feat_len)
+    return cfm_sample(sd, "decoder.estimator", z, mu, torch.ones(1, 1, feat_len), emb, cond, n_timesteps, cfg)
 
 
 def flow_forward(sd, batch, draws, cfg: OracleConfig, return_all: bool = False):

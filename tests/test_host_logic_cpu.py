@@ -225,3 +225,43 @@ def test_shard_sampler_partitions_whole_global_batches():
     s = ShardSampler(23, 2, 0, 4, seed=5)
     s.set_epoch(1)
     assert list(s) != parts[0]
+
+
+def test_merge_joint_weights_from_trainer_checkpoint(tiny_meta, tmp_path):
+    """merge_joint_weights.py:65-273: a trainer checkpoint (`model.llm.` / `model.flow.` prefixes, one foreign key, one
+    shape-mismatched key) -> per-branch files in the ORIGINAL key names that load strictly into the un-wrapped models and
+    hold W + (alpha/r) B A; the flow half equals the reference's own merged export (tests/golden/flow_tiny_merged.npz)."""
+    import time
+    from conftest import load_npz
+    from helpers import build_flow_product, build_llm_product
+    from cosyvoice_lora_finetune_framework_amd import merge_joint_weights as MJ
+    from cosyvoice_lora_finetune_framework_amd.llm_flow_model import JointLLMFlowModel
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    num = Numerics(dtype=torch.float32)
+    trained = JointLLMFlowModel(build_llm_product(tiny_meta["llm"], "cpu", num), build_flow_product(tiny_meta["flow"], "cpu", num))
+    sd = {f"model.{k}": v.clone() for k, v in trained.state_dict().items()}
+    sd["model.flow.not_a_key"] = torch.zeros(3)
+    sd["model.llm.llm_decoder.bias"] = torch.zeros(7)                           # wrong shape: skipped, base value kept
+    ck = tmp_path / "joint_joint_epoch=1.ckpt"
+    torch.save({"state_dict": sd, "epoch": 1}, ck)
+    time.sleep(0.01)
+    torch.save({"state_dict": {}}, tmp_path / "joint_flow_only_epoch=9.ckpt")
+    assert MJ.find_latest_joint_checkpoint(str(tmp_path)) == str(ck)                  # prefers joint_joint over newer files
+    assert MJ.find_latest_joint_checkpoint(str(tmp_path), "flow_only").endswith("joint_flow_only_epoch=9.ckpt")
+    assert MJ.find_latest_joint_checkpoint(str(tmp_path), "llm_only") is None
+    # a fresh model with different adapter values: everything must come from the checkpoint
+    fresh = JointLLMFlowModel(build_llm_product(tiny_meta["llm"], "cpu", num), build_flow_product(tiny_meta["flow"], "cpu", num, seed=99))
+    lo, fo = str(tmp_path / "llm.pt"), str(tmp_path / "flow.pt")
+    MJ.merge_both_from_checkpoint(str(ck), lo, fo, model=fresh)
+    flow_m, llm_m = torch.load(fo), torch.load(lo)
+    assert not any("lora_" in k or "original_layer" in k for k in list(flow_m) + list(llm_m))
+    gm = load_npz("flow_tiny_merged.npz")
+    for k, v in gm.items():                                                          # the reference's merged tensors
+        assert torch.allclose(flow_m[k], v, rtol=1e-6, atol=1e-7), k
+    build_flow_product(tiny_meta["flow"], "cpu", num, lora=False).load_state_dict(flow_m, strict=True)
+    build_llm_product(tiny_meta["llm"], "cpu", num, lora=False).load_state_dict(llm_m, strict=True)
+    L = tiny_meta["llm"]["lora"]
+    name = "llm.encoders.0.self_attn.linear_q"
+    want = sd[f"model.llm.{name}.original_layer.weight"] + (L["alpha"] / L["r"]) * sd[f"model.llm.{name}.lora_B"] @ sd[f"model.llm.{name}.lora_A"]
+    assert torch.allclose(llm_m[f"{name}.weight"], want, rtol=1e-6, atol=1e-7)
+    assert not torch.equal(llm_m["llm_decoder.bias"], torch.zeros_like(llm_m["llm_decoder.bias"]))

@@ -317,3 +317,51 @@ def test_flow_prompt_path_loss_and_grads(tiny_meta):
     worst = max(rel(grads[k], refg[k]) for k in refg)
     assert worst < GRAD_TOL, worst
     assert m.decoder.estimator.prompt_isolation_len == 0          # reset after the step (flow_model.py:176-177)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 6e-2)])
+def test_flow_inference_entries_match_reference(tiny_meta, dtype, tol):
+    """MaskedDiffWithXvec.inference (flow_model.py:474-551) and inference_like_training (553-638) on the
+    HIP path against the reference's outputs (initial noise pinned)."""
+    g = load_npz("flow_inference_tiny.npz")
+    m = build_flow_product(tiny_meta["flow"], DEV, _numerics("vendored", dtype))
+    one = lambda n: torch.tensor([n])
+    mel, cache = m.inference(g["token"], one(46), g["prompt_token"], one(12), g["prompt_feat"], one(20), g["embedding"], noise=g["z"])
+    assert mel.dtype == torch.float32 and tuple(mel.shape) == tuple(g["inf_mel"].shape)
+    assert rel(mel, g["inf_mel"]) < tol, rel(mel, g["inf_mel"])
+    assert rel(cache, g["inf_cache"]) < (1e-5 if dtype == torch.float32 else 2e-2)
+    a = m.inference_like_training(g["token"], one(46), 52, g["embedding"], prompt_feat=g["prompt_feat"], prompt_len=9, noise=g["z2"])
+    b = m.inference_like_training(g["token"], one(46), one(52), g["embedding"], n_timesteps=4, noise=g["z2"])
+    assert rel(a, g["ilt_mel"]) < tol and rel(b, g["ilt_mel_noprompt"]) < tol, (rel(a, g["ilt_mel"]), rel(b, g["ilt_mel_noprompt"]))
+
+
+def test_flow_no_prompt_mixed_mode(tiny_meta):
+    """flow_model.py:437-455: NO_PROMPT 'mixed' mode = per-utterance short own-mel prompts drawn from `random`, routed through
+    the prompt path's loss mask; checked against the oracle on the plan re-drawn under the same seed."""
+    import random
+    from oracle import ref_math as R
+    from oracle.detweights import det_state_dict
+    from cosyvoice_lora_finetune_framework_amd import flow_model as FM
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    fm = tiny_meta["flow"]
+    m = build_flow_product(fm, DEV, _numerics("vendored"))
+    batch = synth_batch([40, 33, 28], text_lens=[7, 5, 6], token_lens=[22, 18, 15], seed=4, text_vocab=100, speech_vocab=50)
+    draws = cfm_draws(3, 40, seed=9)
+    old = FM.NO_PROMPT_TRAINING_CONFIG
+    FM.NO_PROMPT_TRAINING_CONFIG = {"enabled": True, "mode": "mixed", "no_prompt_ratio": 0.4}
+    seen = {}
+    orig_fw, orig_draws = m.forward_with_prompt, m.decoder.make_draws
+    m.forward_with_prompt = lambda b, d, dr=None, plan=None: (seen.update(plan=plan), orig_fw(b, d, draws, plan))[1]
+    try:
+        random.seed(11)
+        out = m(batch, DEV)
+    finally:
+        FM.NO_PROMPT_TRAINING_CONFIG = old
+    random.seed(11)
+    want = [0 if random.random() < 0.4 else random.randint(1, max(2, int(0.1 * j))) for j in [40, 33, 28]]
+    assert [p["total"] for p in seen["plan"]] == want and any(want) and not all(want)
+    sd = det_state_dict([(k, tuple(s)) for k, s in fm["spec"]], fm["weight_seed"])
+    cfg = R.OracleConfig(flow_lora_scale=fm["lora"]["alpha"] / fm["lora"]["r"])
+    ref = R.flow_forward_prompt(sd, batch, draws, cfg, seen["plan"], FM.ANTI_LEAKAGE_CONFIG["boundary_frames"],
+                                FM.ANTI_LEAKAGE_CONFIG["boundary_loss_weight"])
+    assert abs(float(out["loss"]) - float(ref)) / float(ref) < LOSS_TOL, (float(out["loss"]), float(ref))

@@ -233,6 +233,38 @@ def gen_sampler():
     npz_save(os.path.join(GOLD, "sampler_tiny.npz"), mu=mu, spks=spks, cond=cond, mask=mask, z=z, out=out, cache=cache)
 
 
+def gen_inference():
+    """Flow inference entries (second half): MaskedDiffWithXvec.inference (prompt + target tokens, the
+    head/mid/tail length regulator, length-dependent step count) and inference_like_training on the tiny flow model,
+    initial noise pinned."""
+    torch.manual_seed(0)
+    m = build_ref_flow('vendored', **TINY_FLOW)
+    wrap_and_fill(m, r=4, alpha=8, targets=FLOW_TARGETS, seed=3)
+    m.eval()
+    g = torch.Generator().manual_seed(58)
+    token = torch.randint(0, 64, (1, 46), generator=g)
+    ptoken = torch.randint(0, 64, (1, 12), generator=g)
+    pfeat = torch.randn(1, 20, 80, generator=g)
+    emb = torch.randn(1, 192, generator=g)
+    mel2 = int(46 / 50 * 22050 / 256)
+    z = torch.randn(1, 80, 20 + mel2, generator=g)
+    z2 = torch.randn(1, 80, 52, generator=g)
+    orig = torch.randn_like
+    out = {}
+    try:
+        torch.randn_like = lambda t, *a, **k: z.clone().to(t.dtype)
+        mel, cache = m.inference(token, torch.tensor([46]), ptoken, torch.tensor([12]), pfeat, torch.tensor([20]), emb)
+        out.update(inf_mel=mel, inf_cache=cache)
+        torch.randn_like = lambda t, *a, **k: z2.clone().to(t.dtype)
+        out['ilt_mel'] = m.inference_like_training(token, torch.tensor([46]), 52, emb, prompt_feat=pfeat, prompt_len=9, n_timesteps=10)
+        out['ilt_mel_noprompt'] = m.inference_like_training(token, torch.tensor([46]), torch.tensor([52]), emb, n_timesteps=4)
+    finally:
+        torch.randn_like = orig
+    print("inference:", {k: tuple(v.shape) for k, v in out.items()})
+    npz_save(os.path.join(GOLD, "flow_inference_tiny.npz"), token=token, prompt_token=ptoken, prompt_feat=pfeat, embedding=emb,
+             z=z, z2=z2, **out)
+
+
 def gen_data():
     """On-disk data path fixture: a small shard in the schema prepare_joint_data.py writes
     (275-284, 365-372) + what the reference's dataset.py makes of it under fixed seeds."""
@@ -512,6 +544,8 @@ if __name__ == "__main__":
         gen_data()
     if a.only in ("all", "prompt"):
         gen_prompt()
+    if a.only in ("all", "inference"):
+        gen_inference()
     if a.only in ("all", "train"):
         gen_train()
     if a.only in ("all", "full"):
