@@ -371,6 +371,10 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     p.direct_epi = direct_mode == 2 || (direct_mode == 1 && simple);
     const bool ident = p.ntaps == 1 && p.tap_off[0] == 0 && p.in_stride == 1 && p.Tin == p.Tm && !p.in_len;
     if (!ident || p.K % 64 != 0 || !p.vecA || !p.vecW || p.N <= 32) return 1;
+    if (!p.fuse && p.Tm == p.M && glds_direct_epilogue(p)) {
+        const int rb = gemm_big_launch(p, st);
+        if (rb != 1) return rb;
+    }
     const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     // Stage count: a deep DMA pipeline only pays while the CU still holds every block that wants to run there
     // (16 / 24 KB per stage), measured on cold operands (tools/bench_cold.py): <= 2 blocks per CU and >= 4 k-tiles ->

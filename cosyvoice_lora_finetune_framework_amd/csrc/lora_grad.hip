@@ -32,10 +32,8 @@ struct RankProb {             // one gradient product: slabs of  Rk^T Wd  ([r, C
 };
 struct RankPair { RankProb p[4]; };      // up to four problems per launch (blockIdx.z)
 
-// blockIdx.z selects the problem: a LoRA layer's dA and dB (same row count M, same rank) go out as ONE launch.
 template <int RB>
-__global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, RankPair prob_pair) {
-    const RankProb& pr = prob_pair.p[blockIdx.z];
+__device__ __forceinline__ void lora_rank_body(int M, const RankProb& pr) {
     const int Cn = pr.Cn, ldw = pr.ldw, ldr = pr.ldr, ldo = pr.ldo, transpose_out = pr.transpose_out;
     const int rows_per_block = pr.rows_per_block;
     const bf16_t* __restrict__ Wd = pr.Wd;
@@ -162,6 +160,30 @@ __global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, RankPair pro
         }
 }
 
+// blockIdx.z selects the problem: a LoRA layer's dA and dB (same row count M, same rank) go out as ONE launch.
+template <int RB>
+__global__ void __launch_bounds__(256) lora_rank_mfma_kernel(int M, RankPair prob_pair) {
+    lora_rank_body<RB>(M, prob_pair.p[blockIdx.z]);
+}
+
+// Batch form: the problems of MANY layers (each with its own row count), one per blockIdx.z, passed by value in the
+// kernel arguments (no device-side table: nothing to upload, so the launch is hipGraph-capturable as is).
+// A backward pass defers the small adapter-gradient products to its end (nothing downstream reads them) and issues
+// them here as a few chip-filling launches instead of one latency-bound launch per layer on the dgrad chain.
+struct RankProbM { const bf16_t* Wd; const bf16_t* Rk; float* out; int M, Cn, ldw, ldr, rows_per_block, transpose_out; };
+#define CVFT_RANK_BATCH 64
+struct RankBatch { RankProbM p[CVFT_RANK_BATCH]; };          // 64 x 48 B = 3 KB of the 4 KB kernel-argument segment
+template <int RB>
+__global__ void __launch_bounds__(256) lora_rank_mfma_batch_kernel(RankBatch batch) {
+    const RankProbM& e = batch.p[blockIdx.z];
+    RankProb pr;
+    pr.Cn = e.Cn; pr.Wd = e.Wd; pr.ldw = e.ldw; pr.Rk = e.Rk; pr.ldr = e.ldr; pr.out = e.out;
+    pr.transpose_out = e.transpose_out; pr.rows_per_block = e.rows_per_block;
+    pr.ldo = pr.transpose_out ? RB * 16 : pr.Cn;
+    pr.part_stride = (size_t)(RB * 16) * pr.Cn;
+    lora_rank_body<RB>(e.M, pr);
+}
+
 static bool rank_ok(int Cn, int r, const void* Wd, int ldw, const void* Rk, int ldr, const float* part, int rows_per_block) {
     return (r == 16 || r == 32 || r == 48 || r == 64) && Cn % 8 == 0 && ldw % 8 == 0 && ldr % 8 == 0 &&
            (reinterpret_cast<uintptr_t>(Wd) & 15) == 0 && (reinterpret_cast<uintptr_t>(Rk) & 15) == 0 &&
@@ -238,5 +260,48 @@ extern "C" int cvft_lora_rank_partial_multi(int M, int r, int n, const cvft_rank
     for (int i = n; i < 4; ++i) pp.p[i] = pp.p[0];
     rank_launch(M, r, pp, n, (hipStream_t)stream);
     CVFT_LAUNCH_CHECK("cvft_lora_rank_partial_multi");
+    return 0;
+}
+
+// n slab products of rank r, each with its own row count (host array of descriptors), in ceil(n / 64) launches.
+extern "C" int cvft_lora_rank_partial_batch(int r, int n, const cvft_rank_prob_m* probs, void* stream) {
+    CVFT_CHECK_ARG((r == 16 || r == 32 || r == 48 || r == 64) && n >= 1 && probs, "cvft_lora_rank_partial_batch: r in {16,32,48,64}, n >= 1");
+    for (int i = 0; i < n; ++i) {
+        const cvft_rank_prob_m& q = probs[i];
+        CVFT_CHECK_ARG(q.M > 0 && q.Wd && q.Rk && q.part && rank_ok(q.C, r, q.Wd, q.ldw, q.Rk, q.ldr, q.part, q.rows_per_block),
+                       "cvft_lora_rank_partial_batch: problem %d: bf16 operands 16-byte aligned, widths %% 8 == 0, rows_per_block %% 32 == 0", i);
+    }
+    const size_t sm = (size_t)4 * 2 * (32 * 128 + 32 * r * 2);
+    hipStream_t st = (hipStream_t)stream;
+    for (int i0 = 0; i0 < n; i0 += CVFT_RANK_BATCH) {
+        const int nb = min(CVFT_RANK_BATCH, n - i0);
+        RankBatch bt;
+        int gx = 1, gy = 1;
+        for (int i = 0; i < CVFT_RANK_BATCH; ++i) {
+            const cvft_rank_prob_m& q = probs[i0 + (i < nb ? i : 0)];
+            RankProbM& e = bt.p[i];
+            e.Wd = (const bf16_t*)q.Wd; e.Rk = (const bf16_t*)q.Rk; e.out = q.part; e.M = q.M; e.Cn = q.C; e.ldw = q.ldw; e.ldr = q.ldr;
+            e.rows_per_block = q.rows_per_block; e.transpose_out = q.transpose_out;
+            if (i < nb) {
+                gx = max(gx, (q.C + 255) / 256);
+                gy = max(gy, (q.M + q.rows_per_block - 1) / q.rows_per_block);
+            }
+        }
+        CVFT_CHECK_ARG(gy <= 65535, "cvft_lora_rank_partial_batch: too many row blocks");
+        dim3 grid(gx, gy, nb);
+#define RMB_LAUNCH(RBv)                                                                                                  \
+    do {                                                                                                                 \
+        auto kern = lora_rank_mfma_batch_kernel<RBv>;                                                                    \
+        static bool attr_set = false;                                                                                    \
+        if (sm > 48 * 1024 && !attr_set) {                                                                               \
+            attr_set = true;                                                                                             \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        }                                                                                                                \
+        hipLaunchKernelGGL(kern, grid, dim3(256), sm, st, bt);                                                           \
+    } while (0)
+        if (r == 16) RMB_LAUNCH(1); else if (r == 32) RMB_LAUNCH(2); else if (r == 48) RMB_LAUNCH(3); else RMB_LAUNCH(4);
+#undef RMB_LAUNCH
+    }
+    CVFT_LAUNCH_CHECK("cvft_lora_rank_partial_batch");
     return 0;
 }

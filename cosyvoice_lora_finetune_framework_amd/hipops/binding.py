@@ -26,6 +26,12 @@ class RankProb(C.Structure):
                 ("part", C.c_void_p), ("transpose_out", C.c_int), ("rows_per_block", C.c_int)]
 
 
+class RankProbM(C.Structure):
+    """mirror of cvft_rank_prob_m (include/cvft.h)"""
+    _fields_ = [("M", C.c_int), ("C", C.c_int), ("Wd", C.c_void_p), ("ldw", C.c_int), ("Rk", C.c_void_p), ("ldr", C.c_int),
+                ("part", C.c_void_p), ("transpose_out", C.c_int), ("rows_per_block", C.c_int)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
@@ -58,6 +64,7 @@ SIGNATURES = {
     "cvft_lora_rank_partial": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "cvft_lora_rank_partial_pair": [_i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "cvft_lora_rank_partial_multi": [_i, _i, _i, _p, _p],
+    "cvft_lora_rank_partial_batch": [_i, _i, _p, _p],
     "cvft_lora_grad_reduce": [_i, _p, _i, _p],
     "cvft_lora_shadow": [_i, _p, _p, _p],
     "cvft_layernorm_fwd": [_i, _i, _i, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p],

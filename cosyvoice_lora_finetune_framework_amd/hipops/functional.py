@@ -314,7 +314,8 @@ class LoraGradSink:
             side_stream = _os.environ.get('CVFT_SINK_SIDE', '0') != '0'
         self.tasks = []
         self.streams = {}                 # streams that received slab launches (the LLM / Flow branches may run on two)
-        self.keep = []                    # operands of side-stream launches stay alive until the join
+        self.keep = []                    # operands of side-stream / deferred launches stay alive until the join
+        self.deferred = {}                # rank -> table rows of slab products postponed to flush()
         self.side = None
         if side_stream:
             if LoraGradSink._side is None:
@@ -342,6 +343,41 @@ class LoraGradSink:
             if colblocks * (-(-M // cand)) >= 512:
                 rpb = cand
         return rpb, -(-M // rpb)
+
+    def will_defer(self, x: torch.Tensor, dY: torch.Tensor) -> bool:
+        """Small adapter-gradient products are postponed to flush() and issued there as a few chip-filling batch launches
+        (cvft_lora_rank_partial_batch): nothing downstream in backward reads them, and one at a time they are
+        launch-latency bound (~8 us each, ~250 per step on the flow branch's dgrad chain).  Large ones (the LLM's) stay
+        in line: their operands are still in L2 / MALL there, and their branch is not the critical path."""
+        return SINK_DEFER and self.side is None and x.dtype == torch.bfloat16 and x.numel() + dY.numel() <= SINK_DEFER_MAX
+
+    @staticmethod
+    def plan_deferred(M: int):
+        """Batched launches fill the chip by their problem count: long row blocks (fewer, smaller slabs to write and reduce)."""
+        return SINK_DEFER_RPB, -(-M // SINK_DEFER_RPB)
+
+    def rank_pair(self, defer: bool, M: int, r: int, K: int, x, V, wsA, rpa: int, N: int, dY, U, wsB, rpb: int):
+        """slabs of dA = V^T x ([r, K] per row block of rpa rows) and dB = dY^T U ([N, r] per row block of rpb rows): now, or
+        at flush() when `defer`."""
+        if not defer:
+            check(lib().cvft_lora_rank_partial_pair(M, r, K, ptr(x), x.stride(0), ptr(V), V.stride(0), ptr(wsA), rpa,
+                                                    N, ptr(dY), dY.stride(0), ptr(U), U.stride(0), ptr(wsB), rpb, stream()),
+                  "cvft_lora_rank_partial_pair")
+            return
+        for C, Wd, Rk, ws, tr, rp in ((K, x, V, wsA, 0, rpa), (N, dY, U, wsB, 1, rpb)):
+            assert (C % 8 == 0 and Wd.stride(0) % 8 == 0 and Rk.stride(0) % 8 == 0 and Wd.data_ptr() % 16 == 0 and Rk.data_ptr() % 16 == 0
+                    and ws.data_ptr() % 16 == 0 and rp % 32 == 0 and Wd.dtype == Rk.dtype == torch.bfloat16 and Rk.shape[1] == r)
+            self.deferred.setdefault(r, []).append((M, C, Wd.data_ptr(), Wd.stride(0), Rk.data_ptr(), Rk.stride(0), ws.data_ptr(), tr, rp, 0))
+        self.keep.append((x, V, dY, U))
+        self._note_stream()
+
+    def _launch_deferred(self):
+        for r, rows in self.deferred.items():
+            arr = (cb.RankProbM * len(rows))()
+            for e, (M, Cn, Wd, ldw, Rk, ldr, ws, tr, rp, _) in zip(arr, rows):
+                e.M, e.C, e.Wd, e.ldw, e.Rk, e.ldr, e.part, e.transpose_out, e.rows_per_block = M, Cn, Wd, ldw, Rk, ldr, ws, tr, rp
+            check(lib().cvft_lora_rank_partial_batch(r, len(rows), arr, stream()), "cvft_lora_rank_partial_batch")
+        self.deferred = {}
 
     @staticmethod
     def workspace(P: torch.Tensor, nsplit: int) -> torch.Tensor:
@@ -376,6 +412,7 @@ class LoraGradSink:
             if h != cur.cuda_stream:
                 cur.wait_stream(st)
         self.streams = {}
+        self._launch_deferred()
         self.keep = []
         key = tuple(self.tasks)
         ent = LoraGradSink._cache.get(key)
@@ -391,6 +428,9 @@ class LoraGradSink:
 
 
 import os as _os
+SINK_DEFER = _os.environ.get('CVFT_SINK_DEFER', '1') != '0'
+SINK_DEFER_MAX = int(_os.environ.get('CVFT_SINK_DEFER_MAX', 12_000_000))      # x.numel() + dY.numel(): the flow branch's layers
+SINK_DEFER_RPB = int(_os.environ.get('CVFT_SINK_DEFER_RPB', 256))
 FUSE_MAX_MN = int(_os.environ.get('CVFT_FUSE_MAX_MN', 3_000_000))   # measured (tools/bench_fused.py): the in-launch side path wins for the small estimator GEMMs only
 
 
@@ -489,13 +529,12 @@ def _lora_param_grads(x, U, V, dz, A_ref, B_ref, ops):
             sink.keep.append((x, V, dz, U))
         with ctxm:
             if x.dtype == torch.bfloat16 and r in (16, 32, 48, 64):
-                # dA and dB in one launch (matrix-core slab kernel)
-                rpa, nsa = LoraGradSink.plan(M, x.shape[1])
-                rpb_, nsb = LoraGradSink.plan(M, dz.shape[1])
+                # dA and dB in one launch (matrix-core slab kernel), or postponed to the sink's batch launch
+                defer = sink.will_defer(x, dz)
+                rpa, nsa = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, x.shape[1])
+                rpb_, nsb = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, dz.shape[1])
                 wsA, wsB = LoraGradSink.workspace(A, nsa), LoraGradSink.workspace(B, nsb)
-                check(lib().cvft_lora_rank_partial_pair(M, r, x.shape[1], ptr(x), x.stride(0), ptr(V), V.stride(0), ptr(wsA), rpa,
-                                                        dz.shape[1], ptr(dz), dz.stride(0), ptr(U), U.stride(0), ptr(wsB), rpb_,
-                                                        stream()), "cvft_lora_rank_partial_pair")
+                sink.rank_pair(defer, M, r, x.shape[1], x, V, wsA, rpa, dz.shape[1], dz, U, wsB, rpb_)
                 sink.add(wsA, gA, A.numel(), nsa)
                 sink.add(wsB, gB, B.numel(), nsb)
             else:
@@ -687,13 +726,12 @@ class LinearQKVStackedFn(torch.autograd.Function):
         direct = all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for pair in grads for g in pair)
         if sink is not None and direct and sink.side is None:
             K = x.shape[1]
-            rpa, nsa = LoraGradSink.plan(M, K)
-            rpb_, nsb = LoraGradSink.plan(M, 3 * N)
+            defer = r3 in (16, 32, 48, 64) and sink.will_defer(x, dY)
+            rpa, nsa = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, K)
+            rpb_, nsb = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, 3 * N)
             wsA = LoraGradSink.workspace(ctx.refs[0][0], nsa * 3)       # slab [3r, K] per row block
             wsB = LoraGradSink.workspace(ctx.refs[0][1], nsb * 9)       # slab [3N, 3r] per row block
-            check(lib().cvft_lora_rank_partial_pair(M, r3, K, ptr(x), x.stride(0), ptr(V), V.stride(0), ptr(wsA), rpa,
-                                                    3 * N, ptr(dY), dY.stride(0), ptr(U), U.stride(0), ptr(wsB), rpb_, stream()),
-                  "cvft_lora_rank_partial_pair")
+            sink.rank_pair(defer, M, r3, K, x, V, wsA, rpa, 3 * N, dY, U, wsB, rpb_)
             for i, (gA, _) in enumerate(grads):
                 sink.add_block(wsA.data_ptr() + i * r * K * 4, gA, r, K, K, r3 * K, nsa)
             for i, (_, gB) in enumerate(grads):

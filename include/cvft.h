@@ -119,6 +119,16 @@ typedef struct {
 } cvft_rank_prob;
 /* 1..4 such products (same M, same r) in one launch */
 int cvft_lora_rank_partial_multi(int M, int r, int n, const cvft_rank_prob* probs, void* stream);
+typedef struct {
+    int M; int C; const void* Wd; int ldw;   /* wide operand [M][C] (x or dY) */
+    const void* Rk; int ldr;                 /* rank operand [M][r] (V or U) */
+    float* part; int transpose_out;          /* slabs [s][r][C] (0) or [s][C][r] (1) */
+    int rows_per_block;                      /* multiple of 32 */
+} cvft_rank_prob_m;
+/* n such products of rank r, each with its OWN row count (host array; one problem per blockIdx.z, 64 per launch, passed
+ * in the kernel arguments so the launches are hipGraph-capturable).  Used by a backward pass that defers the small
+ * per-layer adapter-gradient products (autograd of lora.py:71-76) to its end. */
+int cvft_lora_rank_partial_batch(int r, int n, const cvft_rank_prob_m* probs, void* stream);
 int cvft_lora_grad_reduce(int ntasks, const void* tasks, int max_blocks_x, void* stream);
 /* One launch per optimiser step: bf16 copy and transposed bf16 copy of every LoRA master in the flat fp32 buffer.
  * tiles: int64[ntiles][6] = {src offset (elements of flat_p), dst ptr, dst_t ptr, rows | cols << 32,
