@@ -26,12 +26,20 @@
 //
 // STATUS (round 1): correct (same results as gemm_glds.hip on every shape tried), NOT yet faster, therefore opt-in
 // (CVFT_GEMM_BIG=1 / 2).  Measured on MI355X at 5328 x 3072 x 1024, hot operands: 86 us (gemm_glds: 59 us, hipBLASLt
-// 33 us).  By ablation: launch + prologue 13.5 us; k-loop 44 us = 2.8 us per k-tile, of which barriers + fragment reads
-// alone 1.0, MFMAs +1.1, DMA issue +1.1 (they add up: the two rows' L and M phases are not overlapping as designed --
-// open question; with K = 4096 the marginal k-tile costs 1.0 us = 2 PFLOP/s, so the steady state is there once the
-// ramp is paid); register epilogue 27 us (32 MB of 8-byte stores with nothing left to overlap them).  Next: find what
-// serialises L against the partner's M (in-kernel s_memtime stamps), 16-byte epilogue stores through LDS, persistent
-// blocks so that one tile's epilogue overlaps the next tile's prologue.
+// 33 us).  By ablation: launch + prologue 13.5 us; k-loop 44 us; register epilogue 27 us (32 MB of 8-byte stores with
+// nothing left to overlap them).  In-kernel cycle stamps (CVFT_BIG_STAMP=1, tools/big_stamps.py; one wave per row,
+// k-tiles 8..11) show where the k-loop's ~3800 cycles per k-tile go -- ideal is 2048 (2 waves x 64 MFMAs x 16):
+//   * an M phase (32 MFMAs) issues in ~600 cycles beside the partner's L phase;
+//   * an L phase is 12 ds_read_b128 = ~280 cycles PLUS ~60 cycles per LDS-DMA issue: 530-620 with 4-6 pieces, so the
+//     phases are balanced only while a wave issues <= 4 pieces per L phase (row 0 issues 6 + 6, row 1 0 + 4);
+//   * vmcnt(0) at the end of M(kt,1) waits 340-480 cycles: pieces issued one slot earlier need ~1100 cycles to land --
+//     the refills should target tile kt+2 in the stage just consumed (W quarter wc by wave (1,wc) right after its own
+//     last read, A halves by row 0), 4 pieces per L phase and counted vmcnt(4), which gives every piece >= 2 slots;
+//   * each s_barrier costs ~80 cycles (4 per k-tile).
+// With those fixes the loop should reach ~2700 cycles per k-tile (31 us); the fixed 40 us (prologue + epilogue at one
+// block per CU, nothing to overlap them with) then dominate at K = 1024: the epilogue needs 16-byte stores through the
+// (by then idle) LDS, and the tile loop needs to be persistent so that one tile's epilogue overlaps the next tile's
+// prologue.  With K = 4096 the marginal k-tile already costs 1.0 us (2 PFLOP/s).
 //
 // The rank-R LoRA extension is applied after the main loop from fragment-shaped direct loads; the epilogue is the
 // register epilogue of gemm_common.cuh (swapped MFMA operands: a lane owns 4 consecutive output columns).
@@ -46,6 +54,9 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 #define BIG_STAGE 65536
 #define BIG_W_OFF 32768
 
+__device__ unsigned long long cvft_big_stamps[2 * 16 * 8];
+
+template <bool STAMP>
 __global__ void __launch_bounds__(512) gemm_big_kernel(GP<bf16_t> p) {
     typedef bf16_t T;
     constexpr int BM = 256, BN = 256, BK = 64, MI = 8, NI = 4;
@@ -144,6 +155,9 @@ __global__ void __launch_bounds__(512) gemm_big_kernel(GP<bf16_t> p) {
         const unsigned char* Ws = smem + st * BIG_STAGE + w_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            const bool rec = STAMP && blockIdx.x == 8 && wc == 0 && lane == 0 && kt >= 8 && kt < 12;
+            unsigned long long* sb = cvft_big_stamps + wr * 128 + ((kt - 8) * 2 + ks) * 8;
+            if (rec) sb[0] = __builtin_readcyclecounter();
             // ---------------- L(kt, ks): this wave's 8 A and 4 W fragments of k-step ks (+ its DMA issues)
             const int rd = ks ? rd1 : rd0;
             bf16x8 a[MI], b[NI];
@@ -166,10 +180,13 @@ __global__ void __launch_bounds__(512) gemm_big_kernel(GP<bf16_t> p) {
                     }
                 }
             }
+            if (rec) sb[1] = __builtin_readcyclecounter();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // fragments are in registers
             __builtin_amdgcn_sched_barrier(0);
+            if (rec) sb[2] = __builtin_readcyclecounter();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            if (rec) sb[3] = __builtin_readcyclecounter();
             // ---------------- M(kt, ks)
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -179,10 +196,14 @@ __global__ void __launch_bounds__(512) gemm_big_kernel(GP<bf16_t> p) {
                     Mma<T>::mma(acc[i][j], b[j], a[i]);           // swapped: lane owns 4 consecutive n
                 }
             __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rec) sb[4] = __builtin_readcyclecounter();
             if (ks == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's refills have landed ...
             __builtin_amdgcn_sched_barrier(0);
+            if (rec) sb[5] = __builtin_readcyclecounter();
             __builtin_amdgcn_s_barrier();                         // ... and are ordered for every reader from the next slot on
             __builtin_amdgcn_sched_barrier(0);
+            if (rec) sb[6] = __builtin_readcyclecounter();
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                    // row 0 makes up for the stagger barrier
@@ -264,14 +285,21 @@ int gemm_big_launch(const GP<bf16_t>& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         attr_set = true;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) {
             cvft_set_error("cvft_gemm: hipFuncSetAttribute(%zu) failed: %s", sm, hipGetErrorString(e));
             return -2;
         }
     }
-    hipLaunchKernelGGL(gemm_big_kernel, dim3((unsigned)tiles), dim3(512), sm, st, q);
+    static const int stamp = getenv("CVFT_BIG_STAMP") ? atoi(getenv("CVFT_BIG_STAMP")) : 0;
+    if (stamp) hipLaunchKernelGGL(gemm_big_kernel<true>, dim3((unsigned)tiles), dim3(512), sm, st, q);
+    else hipLaunchKernelGGL(gemm_big_kernel<false>, dim3((unsigned)tiles), dim3(512), sm, st, q);
     cvft_set_kernel_label("gemm_big_kernel<bf16,256,256,2x4,stagger>");
     CVFT_LAUNCH_CHECK("cvft_gemm");
     return 0;
+}
+
+extern "C" int cvft_debug_big_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cvft_big_stamps), sizeof(unsigned long long) * 2 * 16 * 8);
 }
