@@ -413,21 +413,31 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     if (p.R > 0 && (p.R % 8 != 0 || p.R > 64 || !p.vecU || !p.vecB)) return 1;
     // measured on MI355X (tools/sweep_gemm.py): 128x64 x 8 waves once there are >= 4 64x64 tiles per CU, else 64x64
     static const int big_env = getenv("CVFT_GLDS_BIG") ? atoi(getenv("CVFT_GLDS_BIG")) : 0;     // experiment hook
-    if (big && big_env && nk >= 8 && t64 >= 2048) {
+    if (big && big_env && nk >= 8 && t64 >= 1024) {
         switch (big_env) {
             case 1: return glds_launch_cfg<128, 128, 2, 2, 0, 3>(p, st);
-            case 2: return glds_launch_cfg<128, 128, 2, 2, 0, 4>(p, st);
             case 3: return glds_launch_cfg<128, 128, 2, 4, 0, 3>(p, st);
             case 4: return glds_launch_cfg<256, 128, 4, 2, 0, 2>(p, st);
-            case 5: return glds_launch_cfg<256, 128, 4, 2, 0, 3>(p, st);
             case 6: return glds_launch_cfg<128, 128, 2, 2, 0, 2>(p, st);
+            case 8: return glds_launch_cfg<128, 128, 2, 4, 0, 2>(p, st);
+            case 11: if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, 0, 3>(p, st);
+                     return glds_launch_cfg<128, 64, 4, 2, 0, 2>(p, st);
             default: break;
         }
     }
+    // LLM-sized launches with a deep k-loop: 128x128 tile, 8 waves as 4x2 (32x64 wave tiles), 2 stages = 64 KB, two
+    // blocks per CU.  Per k-tile a wave issues 12 fragment reads + 4 DMA pieces for 16 MFMAs instead of 8 + 3 for 8
+    // (in-kernel stamps, gemm_big.hip: ~23 cycles per ds_read_b128 and ~60 per DMA piece against 16 per MFMA -- the
+    // 32x32 wave tile is issue-bound), and a byte from L2 feeds 64 FLOP instead of 43.  Measured cold (tools/bench_cfg.py):
+    // 5328x4096x1024 541 -> 616 TFLOP/s, 5328x3072x1024 514 -> 613, 5328x1024x4096 581 -> 604, 5328x1024x1024 equal;
+    // 4 waves (64x64 wave tiles) or 192-row / 192-column tiles at one block per CU are slower.
+    if (big && (nk >= 8 || big_env == 12) && t64 >= 1000) return glds_launch_cfg<128, 128, 4, 2, 0, 2>(p, st);
     if (big) {
         if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, 0, 3>(p, st);
         return glds_launch_cfg<128, 64, 4, 2, 0, 2>(p, st);
     }
+    // 64x64 x 4 waves stays the best small tile: 128x64 / 64x128 with 4 waves (64x32 wave tiles) measured 10-40 % slower on
+    // the estimator / encoder shapes (M = 4000..4640, N = 256..1536), where block count matters more than issue efficiency
     if (ns >= 4) return glds_launch_cfg<64, 64, 2, 2, 0, 4>(p, st);
     if (ns == 3) return glds_launch_cfg<64, 64, 2, 2, 0, 3>(p, st);
     return glds_launch_cfg<64, 64, 2, 2, 0, 2>(p, st);
