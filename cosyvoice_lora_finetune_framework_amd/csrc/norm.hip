@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(512) gn_stats_kernel(int T_, int C, int G, con
     }
 }
 
-template <typename T>
+template <typename T, bool VECP>
 __global__ void __launch_bounds__(256) gn_apply_fwd_kernel(int B, int T_, int C, int G, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -262,24 +262,46 @@ __global__ void __launch_bounds__(256) gn_apply_fwd_kernel(int B, int T_, int C,
                                                             const float* __restrict__ rstd, const int* __restrict__ len,
                                                             const T* __restrict__ add, int apply_mish,
                                                             T* __restrict__ y) {
-    const size_t total = (size_t)B * T_ * C;
-    const int Cg = C / G;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        int c = (int)(i % C);
-        size_t bt = i / C;
-        int t = (int)(bt % T_), b = (int)(bt / T_);
-        int sg = b * G + c / Cg;
-        float z = (to_f32(x[i]) - mean[sg]) * rstd[sg] * gamma[c] + beta[c];
-        float o = apply_mish ? act_apply(CVFT_ACT_MISH, z) : z;
-        if (len && t >= len[b]) o = 0.f;
-        if (add) o += to_f32(add[(size_t)b * C + c]);
-        y[i] = from_f32<T>(o);
+    // one 16-byte chunk (VEC channels of one frame, all in one group since Cg % VEC == 0) per thread and step
+    constexpr int VEC = VECP ? 16 / sizeof(T) : 1;
+    const size_t total = (size_t)B * T_ * C / VEC;
+    const int Cg = C / G, CV = C / VEC;
+    for (size_t ch = (size_t)blockIdx.x * 256 + threadIdx.x; ch < total; ch += (size_t)gridDim.x * 256) {
+        const int c0 = (int)(ch % CV) * VEC;
+        const size_t bt = ch / CV;
+        const int t = (int)(bt % T_), b = (int)(bt / T_);
+        const int sg = b * G + c0 / Cg;
+        const float mu = mean[sg], rs = rstd[sg];
+        const bool dead = len && t >= len[b];
+        const size_t i = ch * VEC;
+        T xv[VEC], av[VEC], ov[VEC];
+        if (VECP) {
+            *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + i);
+            if (add) *reinterpret_cast<uint4*>(av) = *reinterpret_cast<const uint4*>(add + (size_t)b * C + c0);
+        } else {
+            xv[0] = x[i];
+            if (add) av[0] = add[(size_t)b * C + c0];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = c0 + k;
+            const float z = (to_f32(xv[k]) - mu) * rs * gamma[c] + beta[c];
+            float o = apply_mish ? act_apply(CVFT_ACT_MISH, z) : z;
+            if (dead) o = 0.f;
+            if (add) o += to_f32(av[k]);
+            ov[k] = from_f32<T>(o);
+        }
+        if (VECP) *reinterpret_cast<uint4*>(y + i) = *reinterpret_cast<const uint4*>(ov);
+        else y[i] = ov[0];
     }
 }
 
-// backward stats: s1 = sum(gamma*dz), s2 = sum(gamma*dz*xhat) over the group (same chunked walk)
+// backward stats: s1 = sum(gamma*dz), s2 = sum(gamma*dz*xhat) over the group.  One block per (b, g) left half the chip idle
+// and walked T * Cg elements through the Mish derivative serially (24 us per launch at [16, 500, 256]): the frames are
+// split into CVFT_GN_SPLIT chunks, block (b*G + g, s) writes its partial pair to ws[(sg * SPLIT + s) * 2], and the apply
+// kernel adds the SPLIT partials in a fixed order (deterministic, no atomics).
 template <typename T, bool VECP>
-__global__ void __launch_bounds__(512) gn_bwd_stats_kernel(int T_, int C, int G, const T* __restrict__ x,
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(int T_, int C, int G, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
                                                             const float* __restrict__ mean,
@@ -288,16 +310,18 @@ __global__ void __launch_bounds__(512) gn_bwd_stats_kernel(int T_, int C, int G,
                                                             float* __restrict__ ws) {
     constexpr int VEC = VECP ? 16 / sizeof(T) : 1;
     __shared__ float sm[16];
-    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int sg = blockIdx.x, b = sg / G, g = sg % G, sp = blockIdx.y;
     const int Cg = C / G, CgV = Cg / VEC;
     const size_t off = (size_t)b * T_ * C + g * Cg;
     const float n = (float)T_ * (float)Cg;
-    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
-    const int lb = len ? min(len[b], T_) : T_;
-    const int nch = lb * CgV;                   // frames t >= len contribute nothing
+    const float mu = mean[sg], rs = rstd[sg];
+    const int lb = len ? min(len[b], T_) : T_;                     // frames t >= len contribute nothing
+    const int tc = (T_ + CVFT_GN_SPLIT - 1) / CVFT_GN_SPLIT;
+    const int t0 = sp * tc, t1 = min(lb, t0 + tc);
+    const int nch = t1 > t0 ? (t1 - t0) * CgV : 0;
     float s1 = 0.f, s2 = 0.f;
-    for (int e = threadIdx.x; e < nch; e += 512) {
-        const int t = e / CgV, cc = (e % CgV) * VEC;
+    for (int e = threadIdx.x; e < nch; e += 256) {
+        const int t = t0 + e / CgV, cc = (e % CgV) * VEC;
         const size_t i = off + (size_t)t * C + cc;
         T xv[VEC], dv[VEC];
         if (VECP) {
@@ -321,12 +345,12 @@ __global__ void __launch_bounds__(512) gn_bwd_stats_kernel(int T_, int C, int G,
     s1 = block_sum(s1, sm);
     s2 = block_sum(s2, sm);
     if (threadIdx.x == 0) {
-        ws[blockIdx.x * 2 + 0] = s1 / n;
-        ws[blockIdx.x * 2 + 1] = s2 / n;
+        ws[((size_t)sg * CVFT_GN_SPLIT + sp) * 2 + 0] = s1 / n;
+        ws[((size_t)sg * CVFT_GN_SPLIT + sp) * 2 + 1] = s2 / n;
     }
 }
 
-template <typename T>
+template <typename T, bool VECP>
 __global__ void __launch_bounds__(256) gn_apply_bwd_kernel(int B, int T_, int C, int G, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -334,22 +358,46 @@ __global__ void __launch_bounds__(256) gn_apply_bwd_kernel(int B, int T_, int C,
                                                             const float* __restrict__ rstd, const int* __restrict__ len,
                                                             int apply_mish, const T* __restrict__ dy,
                                                             const float* __restrict__ ws, T* __restrict__ dx) {
-    const size_t total = (size_t)B * T_ * C;
-    const int Cg = C / G;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        int c = (int)(i % C);
-        size_t bt = i / C;
-        int t = (int)(bt % T_), b = (int)(bt / T_);
-        int sg = b * G + c / Cg;
-        float rs = rstd[sg];
-        float xh = (to_f32(x[i]) - mean[sg]) * rs;
-        float dz = 0.f;
-        if (!len || t < len[b]) {
-            dz = to_f32(dy[i]);
-            if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c] + beta[c]);
-            dz *= gamma[c];
+    constexpr int VEC = VECP ? 16 / sizeof(T) : 1;
+    const size_t total = (size_t)B * T_ * C / VEC;
+    const int Cg = C / G, CV = C / VEC;
+    for (size_t ch = (size_t)blockIdx.x * 256 + threadIdx.x; ch < total; ch += (size_t)gridDim.x * 256) {
+        const int c0 = (int)(ch % CV) * VEC;
+        const size_t bt = ch / CV;
+        const int t = (int)(bt % T_), b = (int)(bt / T_);
+        const int sg = b * G + c0 / Cg;
+        const float mu = mean[sg], rs = rstd[sg];
+        float w1 = 0.f, w2 = 0.f;
+#pragma unroll
+        for (int sp = 0; sp < CVFT_GN_SPLIT; ++sp) {
+            const float2 pr = *reinterpret_cast<const float2*>(ws + ((size_t)sg * CVFT_GN_SPLIT + sp) * 2);
+            w1 += pr.x;
+            w2 += pr.y;
         }
-        dx[i] = from_f32<T>(rs * (dz - ws[sg * 2] - xh * ws[sg * 2 + 1]));
+        const bool live = !len || t < len[b];
+        const size_t i = ch * VEC;
+        T xv[VEC], dv[VEC], ov[VEC];
+        if (VECP) {
+            *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + i);
+            *reinterpret_cast<uint4*>(dv) = *reinterpret_cast<const uint4*>(dy + i);
+        } else {
+            xv[0] = x[i];
+            dv[0] = dy[i];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = c0 + k;
+            const float xh = (to_f32(xv[k]) - mu) * rs;
+            float dz = 0.f;
+            if (live) {
+                dz = to_f32(dv[k]);
+                if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c] + beta[c]);
+                dz *= gamma[c];
+            }
+            ov[k] = from_f32<T>(rs * (dz - w1 - xh * w2));
+        }
+        if (VECP) *reinterpret_cast<uint4*>(dx + i) = *reinterpret_cast<const uint4*>(ov);
+        else dx[i] = ov[0];
     }
 }
 
@@ -368,16 +416,21 @@ extern "C" int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, co
     size_t total = (size_t)B * T * C;
     const int vec = dtype == CVFT_F32 ? 4 : 8;
     const bool vp = ((C / G) % vec == 0) && (C % vec == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const bool vpa = vp && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (!add || ((reinterpret_cast<uintptr_t>(add) & 15) == 0));
     if (dtype == CVFT_F32) {
         if (vp) hipLaunchKernelGGL((gn_stats_kernel<float, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, eps, mean, rstd);
         else hipLaunchKernelGGL((gn_stats_kernel<float, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, eps, mean, rstd);
-        hipLaunchKernelGGL((gn_apply_fwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
-                           (const float*)x, gamma, beta, mean, rstd, len, (const float*)add, apply_mish, (float*)y);
+        if (vpa) hipLaunchKernelGGL((gn_apply_fwd_kernel<float, true>), dim3(ew_grid(total / vec)), dim3(256), 0, st, B, T, C, G,
+                                    (const float*)x, gamma, beta, mean, rstd, len, (const float*)add, apply_mish, (float*)y);
+        else hipLaunchKernelGGL((gn_apply_fwd_kernel<float, false>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
+                                (const float*)x, gamma, beta, mean, rstd, len, (const float*)add, apply_mish, (float*)y);
     } else {
         if (vp) hipLaunchKernelGGL((gn_stats_kernel<bf16_t, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, eps, mean, rstd);
         else hipLaunchKernelGGL((gn_stats_kernel<bf16_t, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, eps, mean, rstd);
-        hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
-                           (const bf16_t*)x, gamma, beta, mean, rstd, len, (const bf16_t*)add, apply_mish, (bf16_t*)y);
+        if (vpa) hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16_t, true>), dim3(ew_grid(total / vec)), dim3(256), 0, st, B, T, C, G,
+                                    (const bf16_t*)x, gamma, beta, mean, rstd, len, (const bf16_t*)add, apply_mish, (bf16_t*)y);
+        else hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16_t, false>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
+                                (const bf16_t*)x, gamma, beta, mean, rstd, len, (const bf16_t*)add, apply_mish, (bf16_t*)y);
     }
     CVFT_LAUNCH_CHECK("cvft_groupnorm_mish_fwd");
     return 0;
@@ -392,22 +445,19 @@ extern "C" int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, co
     hipStream_t st = (hipStream_t)stream;
     size_t total = (size_t)B * T * C;
     const int vec = dtype == CVFT_F32 ? 4 : 8;
-    const bool vp = ((C / G) % vec == 0) && (C % vec == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0);
-    if (dtype == CVFT_F32) {
-        if (vp) hipLaunchKernelGGL((gn_bwd_stats_kernel<float, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, gamma,
-                                   beta, mean, rstd, len, apply_mish, (const float*)dy, ws);
-        else hipLaunchKernelGGL((gn_bwd_stats_kernel<float, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, gamma,
-                           beta, mean, rstd, len, apply_mish, (const float*)dy, ws);
-        hipLaunchKernelGGL((gn_apply_bwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
-                           (const float*)x, gamma, beta, mean, rstd, len, apply_mish, (const float*)dy, ws, (float*)dx);
-    } else {
-        if (vp) hipLaunchKernelGGL((gn_bwd_stats_kernel<bf16_t, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, gamma,
-                                   beta, mean, rstd, len, apply_mish, (const bf16_t*)dy, ws);
-        else hipLaunchKernelGGL((gn_bwd_stats_kernel<bf16_t, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, gamma,
-                           beta, mean, rstd, len, apply_mish, (const bf16_t*)dy, ws);
-        hipLaunchKernelGGL((gn_apply_bwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
-                           (const bf16_t*)x, gamma, beta, mean, rstd, len, apply_mish, (const bf16_t*)dy, ws, (bf16_t*)dx);
-    }
+    const bool vp = ((C / G) % vec == 0) && (C % vec == 0) &&
+                    (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+    const dim3 sgrid(B * G, CVFT_GN_SPLIT);
+#define GN_BWD(TT, VP)                                                                                                         \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL((gn_bwd_stats_kernel<TT, VP>), sgrid, dim3(256), 0, st, T, C, G, (const TT*)x, gamma, beta, mean, rstd, len, \
+                           apply_mish, (const TT*)dy, ws);                                                                     \
+        hipLaunchKernelGGL((gn_apply_bwd_kernel<TT, VP>), dim3(ew_grid(total / (VP ? vec : 1))), dim3(256), 0, st, B, T, C, G,  \
+                           (const TT*)x, gamma, beta, mean, rstd, len, apply_mish, (const TT*)dy, ws, (TT*)dx);                \
+    } while (0)
+    if (dtype == CVFT_F32) { if (vp) GN_BWD(float, true); else GN_BWD(float, false); }
+    else { if (vp) GN_BWD(bf16_t, true); else GN_BWD(bf16_t, false); }
+#undef GN_BWD
     CVFT_LAUNCH_CHECK("cvft_groupnorm_mish_bwd");
     return 0;
 }

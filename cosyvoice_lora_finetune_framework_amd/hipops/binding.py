@@ -20,6 +20,9 @@ F32, BF16 = 0, 1
 ACT = {None: 0, "none": 0, "relu": 1, "silu": 2, "swish": 2, "gelu": 3, "gelu_erf": 3, "gelu_tanh": 4, "mish": 5}
 
 
+GN_SPLIT = 8          # CVFT_GN_SPLIT (include/cvft.h)
+
+
 class RankProb(C.Structure):
     """mirror of cvft_rank_prob (include/cvft.h)"""
     _fields_ = [("C", C.c_int), ("Wd", C.c_void_p), ("ldw", C.c_int), ("Rk", C.c_void_p), ("ldr", C.c_int),

@@ -1101,7 +1101,7 @@ class GroupNormMishFn(torch.autograd.Function):
         B, T, Cn, G = ctx.dims
         dy = _c(dy)
         dx = torch.empty_like(x)
-        ws = torch.empty(B * G * 2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(B * G * 2 * cb.GN_SPLIT, dtype=torch.float32, device=x.device)
         check(lib().cvft_groupnorm_mish_bwd(dt(x), B, T, Cn, G, ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                             ptr(ctx.length), int(ctx.mish), ptr(dy), ptr(dx), ptr(ws), stream()),
               "cvft_groupnorm_mish_bwd")

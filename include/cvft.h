@@ -158,12 +158,13 @@ int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, const float* g
  * time-embedding add (modules.py:91) and InterpolateRegulator's Conv+GroupNorm(1)+Mish
  * stack (length_regulator.py:34-41).  apply_mish=0 gives plain GroupNorm.
  * ------------------------------------------------------------------------------- */
+#define CVFT_GN_SPLIT 8   /* frame chunks of the backward statistics pass (partials in ws, summed in fixed order) */
 int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, const void* x, const float* gamma,
                             const float* beta, float eps, const int32_t* len, const void* add /*[B][C] dtype or NULL*/,
                             int apply_mish, void* y, float* mean /*[B*G]*/, float* rstd /*[B*G]*/, void* stream);
 int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, const void* x, const float* gamma,
                             const float* beta, const float* mean, const float* rstd, const int32_t* len,
-                            int apply_mish, const void* dy, void* dx, float* ws /*[B*G*2]*/, void* stream);
+                            int apply_mish, const void* dy, void* dx, float* ws /*[B*G*CVFT_GN_SPLIT*2] scratch*/, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Fused attention, head_dim 64, additive key-padding bias -1e10 (NOT -inf):

@@ -149,7 +149,7 @@ def test_layernorm(dtype, relu, post):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("G,Cn", [(8, 64), (1, 80)])
+@pytest.mark.parametrize("G,Cn", [(8, 64), (1, 80), (8, 32)])      # (8, 32): Cg = 4 -> the scalar (non-vector) kernels in bf16
 def test_groupnorm_mish(dtype, G, Cn):
     HF = HFmod()
     B, T = 3, 29
