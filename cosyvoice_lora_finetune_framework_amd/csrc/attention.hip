@@ -294,12 +294,36 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
             qf[ks] = frag_add_bias(qf[ks], p.bu + h * 64, ks * MM::K, lane);
         }
     }
+    // delta[i] = sum_d dO[i][d] * O[i][d], computed here (it used to be a launch of its own, 90 per step): lane l of wave w
+    // sums 16 columns of row 16w + l/4 (dO from the staged tile, O from global), 4-lane reduce; the rows a lane needs
+    // come by shuffle, and the values are published for the dK/dV kernel, which runs after this one on the stream.
+    float dsum = 0.f;
+    {
+        const int row = 16 * w + (lane >> 2), c0 = (lane & 3) * 16, i = q0 + row;
+        if (i < L) {
+            const T* orow = p.o + (rowbase + i) * p.ldo + h * 64 + c0;
+            const T* drow = Vs + row * LDK + c0;
+            constexpr int NV = 16 / A::VEC;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const uint4 ov = *reinterpret_cast<const uint4*>(orow + v * A::VEC);
+                const uint4 dv = *reinterpret_cast<const uint4*>(drow + v * A::VEC);
+                const T* oe = reinterpret_cast<const T*>(&ov);
+                const T* de = reinterpret_cast<const T*>(&dv);
+#pragma unroll
+                for (int e = 0; e < A::VEC; ++e) dsum += to_f32(oe[e]) * to_f32(de[e]);
+            }
+        }
+        dsum += __shfl_xor(dsum, 1);
+        dsum += __shfl_xor(dsum, 2);
+        if ((lane & 3) == 0 && i < L) const_cast<float*>(p.delta)[((size_t)b * p.H + h) * L + i] = dsum;
+    }
     float lse_r[4], del_r[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = q0 + 16 * w + (lane >> 4) * 4 + r;
         lse_r[r] = (i < L) ? p.lse[((size_t)b * p.H + h) * L + i] : __builtin_inff();
-        del_r[r] = (i < L) ? p.delta[((size_t)b * p.H + h) * L + i] : 0.f;
+        del_r[r] = __shfl(dsum, 4 * ((lane >> 4) * 4 + r));
     }
     __syncthreads();
 
@@ -653,11 +677,10 @@ static int launch_fwd(const AP<T>& p, hipStream_t st) {
     return 0;
 }
 template <typename T, bool REL>
-static int launch_bwd(const AP<T>& p, float* delta, const T* o, hipStream_t st) {
-    size_t total = (size_t)p.B * p.L * p.H;
-    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.B, p.H, p.L, o,
-                       p.d_o, p.ldo, delta);
-    CVFT_LAUNCH_CHECK("attn_delta");
+static int launch_bwd(const AP<T>& p_in, float* delta, const T* o, hipStream_t st) {
+    AP<T> p = p_in;
+    p.o = const_cast<T*>(o);              // read-only here: the dQ kernel forms delta = rowsum(dO * O) itself
+    (void)delta;
     size_t s1 = smem_dq<T>(REL), s2 = smem_dkv<T>(REL);
     // (one merged launch for both roles was measured slower than two launches: 36.8 vs 36.5 ms/step)
     dim3 grid((p.L + 63) / 64, p.H, p.B);

@@ -153,20 +153,4 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// delta[b,h,i] = sum_d dO[i,d] * O[i,d]
-template <typename T>
-__global__ void __launch_bounds__(256) attn_delta_kernel(int B, int H, int L, const T* __restrict__ o,
-                                                          const T* __restrict__ d_o, int ldo, float* __restrict__ delta) {
-    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // one thread per (b, i, h)
-    size_t total = (size_t)B * L * H;
-    if (idx >= total) return;
-    int h = (int)(idx % H);
-    size_t bi = idx / H;
-    int i = (int)(bi % L), b = (int)(bi / L);
-    const T* po = o + bi * ldo + h * 64;
-    const T* pd = d_o + bi * ldo + h * 64;
-    float s = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < 64; ++d) s += to_f32(po[d]) * to_f32(pd[d]);
-    delta[((size_t)b * H + h) * L + i] = s;
-}
+// (delta[b,h,i] = sum_d dO[i,d] * O[i,d] is formed inside the dQ kernel: attention.hip, attn_bwd_dq_body)
