@@ -281,6 +281,10 @@ int cvft_adamw_flat(int64_t n, float* p, const float* g, float* m, float* v, con
 /* fp32 -> bf16 cast of a flat buffer */
 int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream);
 
+/* Diagnostics (development only): cycle stamps recorded by the opt-in 256x256 GEMM when CVFT_BIG_STAMP=1
+ * (csrc/gemm_big.hip, tools/big_stamps.py); host_out receives 256 uint64. */
+int cvft_debug_big_stamps(unsigned long long* host_out);
+
 #ifdef __cplusplus
 }
 #endif
