@@ -35,7 +35,9 @@ __host__ __device__ inline bool glds_direct_epilogue(const GP<bf16_t>& p) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int RT, int NS, bool DE>
+__device__ unsigned long long cvft_glds_stamps[2 * 16 * 8];      // diagnostics (CVFT_GLDS_STAMP=1, tools/glds_stamps.py)
+
+template <int BM, int BN, int WM, int WN, int RT, int NS, bool DE, bool STAMP = false>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     typedef bf16_t T;
     constexpr int NW = WM * WN, NT = NW * 64, BK = 64;
@@ -225,6 +227,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         if (t < nk) issue(t);
     int cb = 0, ib = NS - 1;                                    // buffer of tile kt / of tile kt + NS - 1
     for (int kt = 0; kt < nk; ++kt) {
+        const bool rec = STAMP && blockIdx.x == 100 && (wid == 0 || wid == NW - 1) && lane == 0 && kt >= 4 && kt < 12;
+        unsigned long long* sb = cvft_glds_stamps + (wid == 0 ? 0 : 128) + (kt - 4) * 8;
+        if (rec) sb[0] = __builtin_readcyclecounter();
         // this wave's pieces of tile kt have landed once at most the NS-2 younger tiles are still outstanding
         // (loads retire in order; the LoRA fragment loads are older than every tile)
         if (kt + NS - 2 < nk) {
@@ -234,10 +239,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         } else {
             wait_vmcnt<0>();                                    // pipeline tail
         }
+        if (rec) sb[1] = __builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();                           // everyone's pieces; and buffer ib (tile kt-1) is free
         asm volatile("" ::: "memory");
+        if (rec) sb[2] = __builtin_readcyclecounter();
         if (kt + NS - 1 < nk) issue(ib);
+        if (rec) sb[3] = __builtin_readcyclecounter();
         compute(cb);
+        if (rec) { asm volatile("s_nop 0" ::: "memory"); sb[4] = __builtin_readcyclecounter(); }
         cb = (cb + 1 == NS) ? 0 : cb + 1;
         ib = (ib + 1 == NS) ? 0 : ib + 1;
     }
@@ -420,6 +429,17 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
             case 4: return glds_launch_cfg<256, 128, 4, 2, 0, 2>(p, st);
             case 6: return glds_launch_cfg<128, 128, 2, 2, 0, 2>(p, st);
             case 8: return glds_launch_cfg<128, 128, 2, 4, 0, 2>(p, st);
+            case 13: return glds_launch_cfg<128, 128, 4, 2, 0, 3>(p, st);
+            case 14: return glds_launch_cfg<128, 128, 4, 2, 0, 4>(p, st);
+            case 15: {          // stamped build of the default 128x128 kernel (register epilogue)
+                auto kern = gemm_glds_kernel<128, 128, 4, 2, 0, 2, true, true>;
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+                GP<bf16_t> q = p;
+                q.xcd_nsplit = 1;
+                hipLaunchKernelGGL(kern, dim3((unsigned)(((p.M + 127) / 128) * ((p.N + 127) / 128))), dim3(512), 65536, st, q);
+                cvft_set_kernel_label("gemm_glds_kernel<bf16,128,128,4,2,ns2,regepi,stamped>");
+                return 0;
+            }
             case 11: if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, 0, 3>(p, st);
                      return glds_launch_cfg<128, 64, 4, 2, 0, 2>(p, st);
             default: break;
@@ -431,6 +451,11 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     // 32x32 wave tile is issue-bound), and a byte from L2 feeds 64 FLOP instead of 43.  Measured cold (tools/bench_cfg.py):
     // 5328x4096x1024 541 -> 616 TFLOP/s, 5328x3072x1024 514 -> 613, 5328x1024x4096 581 -> 604, 5328x1024x1024 equal;
     // 4 waves (64x64 wave tiles) or 192-row / 192-column tiles at one block per CU are slower.
+    // In-kernel stamps of this configuration (CVFT_GLDS_BIG=15, tools/glds_stamps.py; 5328x4096x1024, L2-warm): a k-tile takes
+    // ~1900 cycles per wave -- 400-700 waiting for its DMA pieces (issued one iteration earlier: ~1500 cycles of latency
+    // at ~9.5 TB/s of aggregate L2 -> LDS traffic), ~100 in the barrier, 360-530 issuing 4 pieces, 680 for 12 fragment
+    // reads + 16 MFMAs (256 of them matrix-core time).  A third / fourth stage (one block per CU) is slower (468 vs 602
+    // TFLOP/s): what is missing is FLOP per L2 byte, i.e. the 256x256 tile of gemm_big.hip, not pipeline depth.
     if (big && (nk >= 8 || big_env == 12) && t64 >= 1000) return glds_launch_cfg<128, 128, 4, 2, 0, 2>(p, st);
     if (big) {
         if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, 0, 3>(p, st);
@@ -441,4 +466,8 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     if (ns >= 4) return glds_launch_cfg<64, 64, 2, 2, 0, 4>(p, st);
     if (ns == 3) return glds_launch_cfg<64, 64, 2, 2, 0, 3>(p, st);
     return glds_launch_cfg<64, 64, 2, 2, 0, 2>(p, st);
+}
+
+extern "C" int cvft_debug_glds_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cvft_glds_stamps), sizeof(unsigned long long) * 2 * 16 * 8);
 }

@@ -284,6 +284,8 @@ int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream);
 /* Diagnostics (development only): cycle stamps recorded by the opt-in 256x256 GEMM when CVFT_BIG_STAMP=1
  * (csrc/gemm_big.hip, tools/big_stamps.py); host_out receives 256 uint64. */
 int cvft_debug_big_stamps(unsigned long long* host_out);
+/* same for the default 128x128 kernel (CVFT_GLDS_BIG=15 launches its stamped build; tools/glds_stamps.py) */
+int cvft_debug_glds_stamps(unsigned long long* host_out);
 
 #ifdef __cplusplus
 }
