@@ -351,7 +351,15 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
     p.residual = (const T*)a->residual; p.ldr = a->ldr; p.C = (T*)a->C; p.ldc = a->ldc;
     p.La = (const T*)a->La; p.ldla = a->ldla; p.lora_scale = a->lora_scale; p.Uout = (T*)a->Uout; p.fuse = a->La != nullptr; p.direct_epi = 0; p.xcd_nsplit = 1;
     p.bytesL = 0;
+    p.xdrop_p = a->xdrop_p; p.xdrop_seed = (const long long*)a->xdrop_seed;
+    for (int i = 0; i < 4; ++i) p.xdrop_sites[i] = a->xdrop_sites[i];
     if (p.fuse) { p.R = a->R; p.U = nullptr; }
+    if (p.xdrop_p > 0.f) {
+        if (sizeof(T) != 2 || p.fuse || !a->U || !p.xdrop_seed || p.R % 16 != 0 || p.R > 64 || p.xdrop_p >= 1.f) {
+            cvft_set_error("cvft_gemm: masked rank extension needs bf16, U / Bl with R %% 16 == 0, R <= 64, a seed and 0 < p < 1");
+            return -1;
+        }
+    }
     p.vecA = (a->K % VEC == 0) && (a->lda % VEC == 0) && al16<T>(a->A);
     p.vecW = (a->K % VEC == 0) && (a->ldw % VEC == 0) && al16<T>(a->W);
     p.vecU = p.R > 0 && (p.R % VEC == 0) && (a->ldu % VEC == 0) && al16<T>(a->U);
@@ -396,7 +404,7 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
         if constexpr (sizeof(T) == 2) {
             // LDS-DMA kernels take every eligible shape (CVFT_GLDS_CFG: -1 = off; experiments)
             static const int gcfg = getenv("CVFT_GLDS_CFG") ? atoi(getenv("CVFT_GLDS_CFG")) : 0;
-            if (gcfg >= 0 && p.N <= 64) {
+            if (gcfg >= 0 && p.N <= 64 && p.xdrop_p <= 0.f) {
                 int rc = skinny_launch(p, st);
                 if (rc != 1) return rc;
             }
@@ -405,6 +413,10 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
                 if (rc != 1) return rc;
             }
         }
+        if (p.xdrop_p > 0.f) {
+            cvft_set_error("cvft_gemm: masked rank extension: launch not eligible for the LDS-DMA register-epilogue kernels");
+            return -1;
+        }
         if (p.N <= 32) return gemm_launch_cfg<T, 32, 32, 2, 1, 4, true>(p, st);
         // measured on MI355X (tools/bench_kernels.py, CVFT_GEMM_CFG sweep): 64x64 tiles with 4 k-tiles in flight win
         // on every step shape up to K = 1024; long-K GEMMs (w_2 dgrad / forward, K = 4096) prefer 256x128 x 8 waves.
@@ -412,6 +424,10 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
             if (p.ntaps * p.K >= 2048 && t128 >= 256) return gemm_launch_cfg<T, 256, 128, 4, 2, 2, true>(p, st);
         }
         return gemm_launch_cfg<T, 64, 64, 2, 2, 4, true>(p, st);
+    }
+    if (p.xdrop_p > 0.f) {
+        cvft_set_error("cvft_gemm: masked rank extension needs 16-byte aligned operands");
+        return -1;
     }
     return gemm_launch_cfg<T, 64, 64, 2, 2, 2, false>(p, st);     // unaligned / odd-K operands: generic element loads
 }

@@ -36,6 +36,7 @@ struct GP {
     const T* La; int ldla; unsigned bytesL; float lora_scale; T* Uout; int fuse;
     int direct_epi;               // LDS-DMA kernels: register epilogue allowed (set by gemm_glds_launch)
     int xcd_nsplit;               // LDS-DMA kernels: XCDs across N (1 = linear tile ranges; 2/4/8 = rectangles, see kernel)
+    float xdrop_p; const long long* xdrop_seed; unsigned xdrop_sites[4];      // masked rank extension (cvft.h); 0 = off
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;

@@ -37,7 +37,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 __device__ unsigned long long cvft_glds_stamps[2 * 16 * 8];      // diagnostics (CVFT_GLDS_STAMP=1, tools/glds_stamps.py)
 
-template <int BM, int BN, int WM, int WN, int RT, int NS, bool DE, bool STAMP = false>
+template <int BM, int BN, int WM, int WN, int RT, int NS, bool DE, bool STAMP = false, bool DX = false>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     typedef bf16_t T;
     constexpr int NW = WM * WN, NT = NW * 64, BK = 64;
@@ -275,6 +275,45 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
             }
         }
     }
+    if constexpr (DX) {
+        // masked rank extension (lora_dropout dgrad): per 16-wide rank tile t, acc += mask_t / (1 - p) * (U_t . Bl_t^T), the
+        // mask taken over the OUTPUT elements -- a lane owns 4 consecutive n of one row, exactly one keep4 group
+        const unsigned thr = cvft_drop_thr(p.xdrop_p);
+        const float inv = 1.f / (1.f - p.xdrop_p);
+        const int ntile = p.R >> 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < ntile) {                                      // wave-uniform
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int s = t >> 1;
+                const unsigned keep = ((kg >> 1) == (t & 1)) ? 0xffffffffu : 0u;     // this tile's 16 k of the 32-wide step
+                bf16x8 fa[MI], fb[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    uint4 v = ua[s][i];
+                    v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+                    fa[i] = *reinterpret_cast<bf16x8*>(&v);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<bf16x8*>(&ub[s][j]);
+                const unsigned long long key = cvft_drop_key(p.xdrop_seed, p.xdrop_sites[t]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const unsigned long long m = (unsigned long long)min(m0 + wm * TM + i * 16 + l15, p.M - 1);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        Mma<T>::mma(a2, fb[j], fa[i]);
+                        const int n = min(n0 + wn * TN + j * 16 + 4 * kg, p.N - 4);
+                        bool k4[4];
+                        cvft_keep4(key, (m * (unsigned long long)p.N + n) >> 2, thr, k4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][e] += k4[e] ? a2[e] * inv : 0.f;
+                    }
+                }
+            }
+    } else {
 #pragma unroll
     for (int s = 0; s < RS; ++s)
         if (s < nrs) {
@@ -297,6 +336,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) Mma<T>::mma(acc[i][j], fb[j], fa[i]);
         }
+    }
 
     // acc[i][j][r] = C[m0 + wm*TM + i*16 + l15][n0 + wn*TN + j*16 + 4*kg + r]
     // DE (register epilogue) is a separate instantiation: with both epilogues in one kernel the LDS path lost ~6 %
@@ -324,13 +364,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int RT, int NS, bool DE>
+template <int BM, int BN, int WM, int WN, int RT, int NS, bool DE, bool DX = false>
 static int glds_launch_de(const GP<bf16_t>& p, hipStream_t st) {
     constexpr bool FU = RT > 0;
     size_t ring = (size_t)NS * (BM + BN + 16 * RT) * 128 + (size_t)BM * 32 * RT;
     size_t cs = DE ? 0 : (size_t)BM * (BN + 4) * sizeof(float);        // fp32 staging tile only for the LDS epilogue
     size_t sm = ring > cs ? ring : cs;
-    auto kern = gemm_glds_kernel<BM, BN, WM, WN, RT, NS, DE>;
+    auto kern = gemm_glds_kernel<BM, BN, WM, WN, RT, NS, DE, false, DX>;
     static bool attr_set = false;             // per instantiation; a host call per launch is visible in eager mode
     if (sm > 48 * 1024 && !attr_set) {
         attr_set = true;
@@ -361,13 +401,19 @@ static int glds_launch_de(const GP<bf16_t>& p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, q);
     if (FU) cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d,%s>,fusedU%d", BM, BN, WM, WN, NS, DE ? "regepi" : "ldsepi", 16 * RT);
-    else cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d,%s>", BM, BN, WM, WN, NS, DE ? "regepi" : "ldsepi");
+    else cvft_set_kernel_label("gemm_glds_kernel<bf16,%d,%d,%d,%d,ns%d,%s>%s", BM, BN, WM, WN, NS, DE ? "regepi" : "ldsepi", DX ? ",xdrop" : "");
     CVFT_LAUNCH_CHECK("cvft_gemm");
     return 0;
 }
 
 template <int BM, int BN, int WM, int WN, int RT = 0, int NS = 2>
 static int glds_launch_cfg(const GP<bf16_t>& p, hipStream_t st) {
+    if (p.xdrop_p > 0.f) {          // masked rank extension: register epilogue, non-fused instantiations only
+        if constexpr (RT == 0) {
+            if (glds_direct_epilogue(p)) return glds_launch_de<BM, BN, WM, WN, 0, NS, true, true>(p, st);
+        }
+        return 1;
+    }
     if (glds_direct_epilogue(p)) return glds_launch_de<BM, BN, WM, WN, RT, NS, true>(p, st);
     return glds_launch_de<BM, BN, WM, WN, RT, NS, false>(p, st);
 }
@@ -380,7 +426,7 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     p.direct_epi = direct_mode == 2 || (direct_mode == 1 && simple);
     const bool ident = p.ntaps == 1 && p.tap_off[0] == 0 && p.in_stride == 1 && p.Tin == p.Tm && !p.in_len;
     if (!ident || p.K % 64 != 0 || !p.vecA || !p.vecW || p.N <= 32) return 1;
-    if (!p.fuse && p.Tm == p.M && glds_direct_epilogue(p)) {
+    if (!p.fuse && p.Tm == p.M && p.xdrop_p <= 0.f && glds_direct_epilogue(p)) {
         const int rb = gemm_big_launch(p, st);
         if (rb != 1) return rb;
     }

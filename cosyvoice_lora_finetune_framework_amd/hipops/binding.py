@@ -51,6 +51,7 @@ class GemmArgs(C.Structure):
         ("residual", C.c_void_p), ("ldr", C.c_int),
         ("C", C.c_void_p), ("ldc", C.c_int),
         ("La", C.c_void_p), ("ldla", C.c_int), ("lora_scale", C.c_float), ("Uout", C.c_void_p),
+        ("xdrop_p", C.c_float), ("xdrop_seed", C.c_void_p), ("xdrop_sites", C.c_uint * 4),
     ]
 
 

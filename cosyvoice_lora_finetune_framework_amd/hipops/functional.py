@@ -56,8 +56,11 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
          residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
          geo: Optional[Geo] = None, nb: int = 1, in_len: Optional[torch.Tensor] = None,
          out_len: Optional[torch.Tensor] = None, out_rows: Optional[int] = None,
-         La: Optional[torch.Tensor] = None, lora_scale: float = 1.0, Uout: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """C = epi(alpha * (taps(x) @ W^T + U @ Bl^T) + bias); W is [N][ntaps*K] (k contiguous)."""
+         La: Optional[torch.Tensor] = None, lora_scale: float = 1.0, Uout: Optional[torch.Tensor] = None,
+         xdrop=None) -> torch.Tensor:
+    """C = epi(alpha * (taps(x) @ W^T + U @ Bl^T) + bias); W is [N][ntaps*K] (k contiguous).
+    xdrop = (p, sites): the U Bl^T term enters per 16-wide rank tile t as mask_t / (1 - p) * (U_t Bl_t^T), masks over the
+    output elements (the lora_dropout dgrad; include/cvft.h)."""
     assert x.dim() == 2 and W.dim() == 2 and x.dtype == W.dtype
     N = W.shape[0] if N is None else N
     a = GemmArgs()
@@ -103,6 +106,11 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
         assert residual.shape[0] == out.shape[0]
         a.residual, a.ldr = ptr(residual), residual.stride(0)
     a.C, a.ldc = ptr(out), out.stride(0)
+    if xdrop is not None:
+        assert U is not None and U.shape[1] % 16 == 0 and len(xdrop[1]) == U.shape[1] // 16
+        a.xdrop_p, a.xdrop_seed = float(xdrop[0]), ptr(_DROPOUT["seed"])
+        for i, st in enumerate(xdrop[1]):
+            a.xdrop_sites[i] = st
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -224,6 +232,20 @@ def side_dgrad(V: torch.Tensor, A: torch.Tensor, dx: torch.Tensor, p: float, sit
                                      dx.stride(0), ptr(dx), dx.stride(0), float(p), ptr(_DROPOUT["seed"]), _sites_arr(sites), stream()),
           "cvft_lora_side_dgrad")
     return dx
+
+
+def _can_xdrop(dz: torch.Tensor, Wb: torch.Tensor, V: torch.Tensor, At: torch.Tensor, residual) -> bool:
+    """dgrad with the masked rank extension inside the GEMM launch (gemm(..., xdrop=)): bf16, LDS-DMA register-epilogue
+    kernels only -- K % 64 == 0, N % 4 == 0, N > 64, rank a multiple of 16 (<= 64), 16-byte aligned operands."""
+    if not XDROP_ON or dz.dtype != torch.bfloat16:
+        return False
+    N, K, r = Wb.shape[0], Wb.shape[1], V.shape[1]
+    ok = (K % 64 == 0 and N % 8 == 0 and N > 64 and r % 16 == 0 and r <= 64 and dz.stride(0) % 8 == 0 and Wb.stride(0) % 8 == 0
+          and V.stride(0) % 8 == 0 and At.stride(0) % 8 == 0 and dz.data_ptr() % 16 == 0 and Wb.data_ptr() % 16 == 0
+          and V.data_ptr() % 16 == 0 and At.data_ptr() % 16 == 0 and dz.shape[1] >= K and At.shape[0] == N)
+    if residual is not None:
+        ok = ok and residual.stride(0) % 4 == 0 and residual.data_ptr() % 8 == 0
+    return ok
 
 
 def _can_drop_fuse(x: torch.Tensor, r: int) -> bool:
@@ -428,6 +450,7 @@ class LoraGradSink:
 
 
 import os as _os
+XDROP_ON = _os.environ.get('CVFT_XDROP', '1') != '0'        # lora_dropout dgrad: masked rank extension inside the GEMM launch
 SINK_DEFER = _os.environ.get('CVFT_SINK_DEFER', '1') != '0'
 SINK_DEFER_MAX = int(_os.environ.get('CVFT_SINK_DEFER_MAX', 12_000_000))      # x.numel() + dY.numel(): the flow branch's layers
 SINK_DEFER_RPB = int(_os.environ.get('CVFT_SINK_DEFER_RPB', 256))
@@ -567,8 +590,11 @@ def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_d
         Ac, At, Bc, Bt = ops
         V = gemm(dz, Bt, alpha=scale)
         if need_dx:
-            dx = gemm(dz, pack.Wb, residual=dx_residual)
-            dx = side_dgrad(V, Ac, dx, drop[0], [drop[1]])
+            if _can_xdrop(dz, pack.Wb, V, At, dx_residual):
+                dx = gemm(dz, pack.Wb, U=V, Bl=At, residual=dx_residual, xdrop=(drop[0], [drop[1]] * (V.shape[1] // 16)))
+            else:
+                dx = gemm(dz, pack.Wb, residual=dx_residual)
+                dx = side_dgrad(V, Ac, dx, drop[0], [drop[1]])
         if need_dAB:
             dA, dB = _lora_param_grads(dropout_raw(x, drop[0], drop[1]), U, V, dz, A_ref, B_ref, ops)
         return dx, dA, dB
@@ -755,7 +781,10 @@ class LinearQKVStackedFn(torch.autograd.Function):
         V = gemm(dY, Bbt, alpha=scale)                                  # [M, 3r]
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = side_dgrad(V, A, gemm(dY, w.Wb), p, sites)             # + sum_t mask_t/(1-p) (V_t A_t)
+            if V.shape[1] == 16 * len(sites) and _can_xdrop(dY, w.Wb, V, At, None):
+                dx = gemm(dY, w.Wb, U=V, Bl=At, xdrop=(p, list(sites)))  # + sum_t mask_t/(1-p) (V_t A_t), inside the launch
+            else:
+                dx = side_dgrad(V, A, gemm(dY, w.Wb), p, sites)
         r3 = V.shape[1]
         r = r3 // 3
         sink = LoraGradSink.active

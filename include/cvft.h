@@ -80,6 +80,12 @@ typedef struct {
      * launch itself computes  Uf = lora_scale * A . La^T  (La [R][ldla]) from the A tiles it streams anyway, uses it
      * in place of U for the rank-R extension, and writes it to Uout [M][ldu] (may be NULL).  `U` is ignored. */
     const void* La; int ldla; float lora_scale; void* Uout;
+    /* masked rank extension (dgrad of a LoRA layer with lora_dropout, lora.py:70-73): when xdrop_p > 0 the U . Bl^T term is
+     * added per 16-wide rank tile t as  mask_t[m, n] / (1 - p) * (U_t . Bl_t^T)[m, n],  mask_t = the counter-based keep mask
+     * of site xdrop_sites[t] over the OUTPUT elements (index m * N + n: the mask the forward applied to that layer's input).
+     * bf16, LDS-DMA kernels with the register epilogue only (identity rows, K % 64 == 0, N % 4 == 0, R % 16 == 0, R <= 64);
+     * any other launch is an error. */
+    float xdrop_p; const int64_t* xdrop_seed; unsigned xdrop_sites[4];
 } cvft_gemm_args;
 
 int cvft_gemm(const cvft_gemm_args* a, void* stream);

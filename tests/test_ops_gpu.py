@@ -795,6 +795,31 @@ def test_qkv_stacked_lora_dropout_matches_torch():
     assert rel(x.grad.float(), xf.grad) < 3e-2
 
 
+@pytest.mark.parametrize("M,N,K,R", [(300, 128, 192, 16), (1000, 256, 1536, 48), (5328, 1024, 1024, 16), (2056, 520, 256, 64)])
+def test_gemm_masked_rank_extension(M, N, K, R):
+    """cvft_gemm with xdrop (the lora_dropout dgrad inside the GEMM launch): C = A W^T + sum_t mask_t/(1-p) * (U_t Bl_t^T) with
+    one mask site per 16-wide rank tile, masks over the output elements -- against torch with the host-replicated masks.
+    W is small so that the masked term dominates; covers the 64x64, 128x64 and 128x128 tiles, a partial last tile, a residual."""
+    HF = HFmod()
+    g = torch.Generator().manual_seed(M + R)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    x, w = q(rn(M, K), torch.bfloat16), q(rn(N, K) * 0.01, torch.bfloat16)
+    u, bl = q(rn(M, R), torch.bfloat16), q(rn(N, R), torch.bfloat16)
+    res = q(rn(M, N), torch.bfloat16)
+    pdrop, nt = 0.15, R // 16
+    HF.dropout_begin_step()
+    sites = [HF._next_drop_site() for _ in range(nt)] if R != 64 else [HF._next_drop_site()] * nt
+    bd = lambda t: t.to(DEV, torch.bfloat16)
+    y = HF.gemm(bd(x), bd(w), U=bd(u), Bl=bd(bl), residual=bd(res), xdrop=(pdrop, sites))
+    assert HF.lib().cvft_gemm_last_kernel().decode().endswith(",xdrop")
+    seed = int(HF._DROPOUT["seed"].item())
+    ref = x.double() @ w.double().t() + res.double()
+    for t in range(nt):
+        mask = _keep_scale_host(seed, sites[t], M * N, pdrop).reshape(M, N)
+        ref = ref + mask * (u[:, 16 * t:16 * t + 16].double() @ bl[:, 16 * t:16 * t + 16].double().t())
+    assert rel(y, ref) < 6e-3, rel(y, ref)
+
+
 def test_gemm_big_tile_kernel_matches_default_path():
     """gemm_big.hip (256 x 256 tile, staggered wave rows; opt-in via CVFT_GEMM_BIG) against an fp32 torch reference and
     against the default kernels' tolerance: partial last M tile, partial last N tile, LoRA extension (R = 16 and 48), bias,
