@@ -115,8 +115,15 @@ template <int RB, int MT, int KS>
 __global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const bf16_t* __restrict__ X, int ldx,
                                                              const bf16_t* __restrict__ A, int lda, float alpha,
                                                              bf16_t* __restrict__ C, int ldc, float p,
-                                                             const long long* __restrict__ seed, uint4 sites) {
+                                                             const long long* __restrict__ seed, uint4 sites,
+                                                             bf16_t* __restrict__ xd0, bf16_t* __restrict__ xd1,
+                                                             bf16_t* __restrict__ xd2) {
+    // xd0..2 (optional, one per rank tile / mask site): the dropped input drop_t(X) = keep_t * X / (1 - p) is also written
+    // out, [M][K] each -- the backward pass needs it for dA_t = V_t^T drop_t(X) and would otherwise re-derive it in a pass
+    // of its own (one launch per adapter per step)
     __shared__ __attribute__((aligned(16))) float red[4][MT][RB][16][17];
+    bf16_t* const xd[3] = {xd0, xd1, xd2};
+    const float inv_keep = 1.f / (1.f - p);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
     const int m0 = blockIdx.x * 16 * MT;
     const int kper = ((K / 32 + 7) / 8) * 32;
@@ -167,7 +174,14 @@ __global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const
                     v.y &= (live && k0_[2] ? 0x0000ffffu : 0u) | (live && k0_[3] ? 0xffff0000u : 0u);
                     v.z &= (live && k1_[0] ? 0x0000ffffu : 0u) | (live && k1_[1] ? 0xffff0000u : 0u);
                     v.w &= (live && k1_[2] ? 0x0000ffffu : 0u) | (live && k1_[3] ? 0xffff0000u : 0u);
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&v), b, acc[t][j], 0, 0, 0);
+                    const bf16x8 vm = *reinterpret_cast<bf16x8*>(&v);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vm, b, acc[t][j], 0, 0, 0);
+                    if (j < 3 && xd[j < 3 ? j : 0] && live && m0 + t * 16 + l15 < M) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)vm[e] * inv_keep);
+                        *reinterpret_cast<bf16x8*>(xd[j] + (size_t)rows[t] * K + k) = o;
+                    }
                 }
             }
         }
@@ -202,7 +216,7 @@ __global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const
 
 // U[M, R] = alpha * sum_k drop_t(X)[m,k] A[16t + j][k]   (X contiguous rows of K: the mask index is m*K + k)
 extern "C" int cvft_skinny_dropout(int M, int K, int R, const void* X, int ldx, const void* A, int lda, float alpha, void* C,
-                                   int ldc, float p, const int64_t* seed, const unsigned* sites, void* stream) {
+                                   int ldc, float p, const int64_t* seed, const unsigned* sites, void* const* xd, void* stream) {
     CVFT_CHECK_ARG(M > 0 && K >= 32 && K % 32 == 0 && (R == 16 || R == 48) && X && A && C && seed && sites && ldx == K && lda >= K &&
                    ldc >= R && p > 0.f && p < 1.f && (((uintptr_t)X | (uintptr_t)A) & 15) == 0 && lda % 8 == 0,
                    "cvft_skinny_dropout: bad args (bf16, contiguous X rows, K %% 32 == 0, R in {16, 48})");
@@ -211,7 +225,8 @@ extern "C" int cvft_skinny_dropout(int M, int K, int R, const void* X, int ldx, 
     const int ksteps_per_wave = (K / 32 + 7) / 8;
     uint4 st = make_uint4(sites[0], R > 16 ? sites[1] : 0u, R > 16 ? sites[2] : 0u, 0u);
 #define SKD_LAUNCH(RBv, KSv) hipLaunchKernelGGL((skinny_dropout_kernel<RBv, MT, KSv>), grid, dim3(512), 0, (hipStream_t)stream, M, K, \
-                                                (const bf16_t*)X, ldx, (const bf16_t*)A, lda, alpha, (bf16_t*)C, ldc, p, (const long long*)seed, st)
+                                                (const bf16_t*)X, ldx, (const bf16_t*)A, lda, alpha, (bf16_t*)C, ldc, p, (const long long*)seed, st, \
+                                                (bf16_t*)(xd ? xd[0] : nullptr), (bf16_t*)(xd && R > 16 ? xd[1] : nullptr), (bf16_t*)(xd && R > 16 ? xd[2] : nullptr))
     if (R == 16) { if (ksteps_per_wave >= 2) SKD_LAUNCH(1, 2); else SKD_LAUNCH(1, 1); }
     else { if (ksteps_per_wave >= 2) SKD_LAUNCH(3, 2); else SKD_LAUNCH(3, 1); }
 #undef SKD_LAUNCH

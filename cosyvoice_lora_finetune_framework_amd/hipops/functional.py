@@ -161,6 +161,7 @@ def dropout_begin_step() -> None:
         _DROPOUT["seed"] = torch.full((1,), int(torch.initial_seed()) & 0x7fffffffffff, dtype=torch.int64, device="cuda")
     _DROPOUT["seed"].add_(1)
     _DROPOUT["site"] = 0
+    _DROPPED.clear()              # dropped inputs a previous forward wrote and no backward consumed
 
 
 class DropoutAddFn(torch.autograd.Function):
@@ -217,13 +218,29 @@ def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
     return y
 
 
-def skinny_dropout(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, sites) -> torch.Tensor:
-    """U[M, R] = alpha * drop_t(x) A_t^T per rank tile t (mask sites[t]); x bf16 contiguous [M, K], A [R, K]."""
+_DROPPED = {}       # mask site -> drop(x) written by the forward skinny kernel, consumed by that adapter's backward (dA = V^T drop(x))
+
+
+def skinny_dropout(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, sites, keep_dropped: bool = False) -> torch.Tensor:
+    """U[M, R] = alpha * drop_t(x) A_t^T per rank tile t (mask sites[t]); x bf16 contiguous [M, K], A [R, K].
+    keep_dropped: the kernel also writes the dropped inputs (one per site) for the backward pass (dropped_input)."""
     U = torch.empty((x.shape[0], A.shape[0]), dtype=x.dtype, device=x.device)
+    xd = None
+    if keep_dropped and KEEP_DROPPED:
+        outs = [torch.empty_like(x) for _ in sites]
+        for st, t in zip(sites, outs):
+            _DROPPED[st] = t
+        xd = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
     check(lib().cvft_skinny_dropout(x.shape[0], x.shape[1], A.shape[0], ptr(x), x.stride(0), ptr(A), A.stride(0), float(alpha),
-                                    ptr(U), U.stride(0), float(p), ptr(_DROPOUT["seed"]), _sites_arr(sites), stream()),
+                                    ptr(U), U.stride(0), float(p), ptr(_DROPOUT["seed"]), _sites_arr(sites), xd, stream()),
           "cvft_skinny_dropout")
     return U
+
+
+def dropped_input(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
+    """drop_site(x): what the forward kernel wrote for this mask site, else re-derived from the counter-based mask."""
+    t = _DROPPED.pop(site, None)
+    return t if t is not None else dropout_raw(x, p, site)
 
 
 def side_dgrad(V: torch.Tensor, A: torch.Tensor, dx: torch.Tensor, p: float, sites) -> torch.Tensor:
@@ -393,6 +410,14 @@ class LoraGradSink:
         self.keep.append((x, V, dY, U))
         self._note_stream()
 
+    def defer_one(self, M: int, r: int, C_: int, Wd, Rk, ws, transpose_out: int, rpb: int, keep=()):
+        """Postpone ONE slab product (slabs of Rk^T Wd, [r, C] or [C, r] when transpose_out) to flush()."""
+        assert (C_ % 8 == 0 and Wd.stride(0) % 8 == 0 and Rk.stride(0) % 8 == 0 and Wd.data_ptr() % 16 == 0 and Rk.data_ptr() % 16 == 0
+                and ws.data_ptr() % 16 == 0 and rpb % 32 == 0 and Wd.dtype == Rk.dtype == torch.bfloat16 and Rk.shape[1] == r)
+        self.deferred.setdefault(r, []).append((M, C_, Wd.data_ptr(), Wd.stride(0), Rk.data_ptr(), Rk.stride(0), ws.data_ptr(), transpose_out, rpb, 0))
+        self.keep.append((Wd, Rk, ws) + tuple(keep))
+        self._note_stream()
+
     def _launch_deferred(self):
         for r, rows in self.deferred.items():
             arr = (cb.RankProbM * len(rows))()
@@ -450,6 +475,8 @@ class LoraGradSink:
 
 
 import os as _os
+STACKED_DROP_DEFER = _os.environ.get('CVFT_STACKED_DROP_DEFER', '0') != '0'
+KEEP_DROPPED = _os.environ.get('CVFT_KEEP_DROPPED', '1') != '0'   # forward writes drop(x) for the backward's dA (no re-derivation launch)
 XDROP_ON = _os.environ.get('CVFT_XDROP', '1') != '0'        # lora_dropout dgrad: masked rank extension inside the GEMM launch
 SINK_DEFER = _os.environ.get('CVFT_SINK_DEFER', '1') != '0'
 SINK_DEFER_MAX = int(_os.environ.get('CVFT_SINK_DEFER_MAX', 12_000_000))      # x.numel() + dY.numel(): the flow branch's layers
@@ -511,7 +538,7 @@ def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residu
         ops = (Ac, At, Bc, Bt)
         fused = drop is None and _can_fuse(x, Ac, Bc, pack.N, pack.K)
         if drop is not None:              # lora_dropout: the side path sees drop(x); mask applied inside the skinny kernel
-            U = skinny_dropout(x, Ac, scale, drop[0], [drop[1]])
+            U = skinny_dropout(x, Ac, scale, drop[0], [drop[1]], keep_dropped=True)
         elif fused:
             U = torch.empty((x.shape[0], Ac.shape[0]), dtype=x.dtype, device=x.device)
         else:
@@ -596,7 +623,7 @@ def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_d
                 dx = gemm(dz, pack.Wb, residual=dx_residual)
                 dx = side_dgrad(V, Ac, dx, drop[0], [drop[1]])
         if need_dAB:
-            dA, dB = _lora_param_grads(dropout_raw(x, drop[0], drop[1]), U, V, dz, A_ref, B_ref, ops)
+            dA, dB = _lora_param_grads(dropped_input(x, drop[0], drop[1]), U, V, dz, A_ref, B_ref, ops)
         return dx, dA, dB
     if has_lora:
         Ac, At, Bc, Bt = ops
@@ -712,7 +739,7 @@ class LinearQKVStackedFn(torch.autograd.Function):
         A, At, Bb, Bbt = ops
         ctx.drop = (float(drop_p), [_next_drop_site() for _ in range(3)]) if drop_p > 0 else None
         if ctx.drop is not None:          # lora_dropout: three mask sites (each LoRALinear owns its nn.Dropout)
-            U = skinny_dropout(x, A, scale, ctx.drop[0], ctx.drop[1])
+            U = skinny_dropout(x, A, scale, ctx.drop[0], ctx.drop[1], keep_dropped=True)
             Y = gemm(x, wstack.Wf, bias=wstack.bias, U=U, Bl=Bb)
         elif QKV_FUSE_SIDE and x.shape[1] % 64 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
             U = torch.empty((x.shape[0], A.shape[0]), dtype=x.dtype, device=x.device)     # [M, 3r], written by the launch
@@ -790,25 +817,30 @@ class LinearQKVStackedFn(torch.autograd.Function):
         sink = LoraGradSink.active
         grads = [(a.grad, b.grad) for a, b in ctx.refs]
         direct = all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for pair in grads for g in pair)
-        xds = [dropout_raw(x, p, st) for st in sites]                   # the three dropped inputs, re-derived
+        xds = [dropped_input(x, p, st) for st in sites]                 # the three dropped inputs (written by the forward kernel)
         if sink is not None and direct and sink.side is None:
-            rpa, nsa = LoraGradSink.plan(M, K)
-            probs = (cb.RankProb * 3)()
-            keep = []
-            for i, (gA, _) in enumerate(grads):
-                ws = LoraGradSink.workspace(ctx.refs[i][0], nsa)
-                Vi = V[:, i * r:(i + 1) * r]
-                probs[i].C, probs[i].Wd, probs[i].ldw = K, xds[i].data_ptr(), xds[i].stride(0)
-                probs[i].Rk, probs[i].ldr, probs[i].part = Vi.data_ptr(), V.stride(0), ws.data_ptr()
-                probs[i].transpose_out, probs[i].rows_per_block = 0, rpa
-                keep.append(ws)
-            check(lib().cvft_lora_rank_partial_multi(M, r, 3, probs, stream()), "cvft_lora_rank_partial_multi")
+            # (measured: postponing these four products to the sink's batch launches is slower here -- 31.8 vs 31.1 ms/step)
+            defer = STACKED_DROP_DEFER and r == 16 and r3 == 48 and sink.will_defer(x, dY)
+            rpa, nsa = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, K)
+            rpb_, nsb = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, 3 * N)
+            wsB = LoraGradSink.workspace(ctx.refs[0][1], nsb * 9)
+            keep = [LoraGradSink.workspace(ctx.refs[i][0], nsa) for i in range(3)]
+            if defer:                       # the four slab products join the sink's end-of-backward batch launches
+                for i in range(3):
+                    sink.defer_one(M, r, K, xds[i], V[:, i * r:(i + 1) * r], keep[i], 0, rpa, keep=(V,))
+                sink.defer_one(M, r3, 3 * N, dY, U, wsB, 1, rpb_)
+            else:
+                probs = (cb.RankProb * 3)()
+                for i in range(3):
+                    Vi = V[:, i * r:(i + 1) * r]
+                    probs[i].C, probs[i].Wd, probs[i].ldw = K, xds[i].data_ptr(), xds[i].stride(0)
+                    probs[i].Rk, probs[i].ldr, probs[i].part = Vi.data_ptr(), V.stride(0), keep[i].data_ptr()
+                    probs[i].transpose_out, probs[i].rows_per_block = 0, rpa
+                check(lib().cvft_lora_rank_partial_multi(M, r, 3, probs, stream()), "cvft_lora_rank_partial_multi")
+                check(lib().cvft_lora_rank_partial(dt(dY), M, 3 * N, r3, ptr(dY), dY.stride(0), ptr(U), U.stride(0), ptr(wsB), 1, rpb_,
+                                                   stream()), "cvft_lora_rank_partial")
             for i, (gA, _) in enumerate(grads):
                 sink.add(keep[i], gA, gA.numel(), nsa)
-            rpb_, nsb = LoraGradSink.plan(M, 3 * N)
-            wsB = LoraGradSink.workspace(ctx.refs[0][1], nsb * 9)
-            check(lib().cvft_lora_rank_partial(dt(dY), M, 3 * N, r3, ptr(dY), dY.stride(0), ptr(U), U.stride(0), ptr(wsB), 1, rpb_,
-                                               stream()), "cvft_lora_rank_partial")
             for i, (_, gB) in enumerate(grads):
                 sink.add_block(wsB.data_ptr() + (i * N * r3 + i * r) * 4, gB, N, r, r3, 3 * N * r3, nsb)
             sink.keep.append((xds, V, U, dY))
