@@ -1,6 +1,7 @@
 // elementwise.hip -- small HBM-bound fused ops of the hot path (gathers, CFM prepare,
 // masked MSE, interpolation, depthwise conv, time embedding, optimiser pieces).
 // All are grid-stride, coalesced along the channel (fastest) axis.
+#include <type_traits>
 #include "common.cuh"
 
 static inline unsigned ew_grid(size_t total) {
@@ -490,39 +491,81 @@ extern "C" int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, voi
 // storing a mask tensor, and a captured hipGraph gets fresh masks on every replay because *seed lives on the device.
 // Not torch's Philox stream: equality with the reference is statistical (keep rate, scale), as for any RNG change.
 // ------------------------------------------------------------------------------
-template <typename T>
+// MODE 0: y = res + drop(x);  MODE 1: y = drop(act(x))  (forward of act -> dropout);  MODE 2: y = drop(g) * act'(x), g = `res`
+// (their backward in one pass).  VEC: n % 4 == 0 and 8-/16-byte aligned pointers -> one vector access per 4-element group.
+template <typename T, int MODE, bool VEC>
 __global__ void dropout_add_kernel(size_t n, const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, float p,
-                                   const long long* __restrict__ seed, unsigned site) {
+                                   const long long* __restrict__ seed, unsigned site, int act) {
     const unsigned long long key = cvft_drop_key(seed, site);
     const unsigned thr = cvft_drop_thr(p);                                    // keep when u32 >= thr
     const float scale = 1.f / (1.f - p);
     const size_t n4 = (n + 3) / 4;
+    typedef typename std::conditional<sizeof(T) == 2, uint2, uint4>::type V4;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (size_t)gridDim.x * blockDim.x) {
         bool kp[4];
         cvft_keep4(key, g, thr, kp);
+        T xv[4], rv[4], ov[4];
+        if (VEC) {
+            *reinterpret_cast<V4*>(xv) = *reinterpret_cast<const V4*>(x + 4 * g);
+            if (res) *reinterpret_cast<V4*>(rv) = *reinterpret_cast<const V4*>(res + 4 * g);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * g + e < n) { xv[e] = x[4 * g + e]; if (res) rv[e] = res[4 * g + e]; }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const size_t i = 4 * g + e;
-            if (i >= n) break;
-            float v = kp[e] ? to_f32(x[i]) * scale : 0.f;
-            if (res) v += to_f32(res[i]);
-            y[i] = from_f32<T>(v);
+            float v;
+            if (MODE == 0) {
+                v = kp[e] ? to_f32(xv[e]) * scale : 0.f;
+                if (res) v += to_f32(rv[e]);
+            } else if (MODE == 1) {
+                v = kp[e] ? act_apply(act, to_f32(xv[e])) * scale : 0.f;
+            } else {
+                v = kp[e] ? to_f32(rv[e]) * scale * act_grad(act, to_f32(xv[e])) : 0.f;
+            }
+            ov[e] = from_f32<T>(v);
+        }
+        if (VEC) {
+            *reinterpret_cast<V4*>(y + 4 * g) = *reinterpret_cast<const V4*>(ov);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * g + e < n) y[4 * g + e] = ov[e];
         }
     }
+}
+template <int MODE>
+static void dropout_launch(int dtype, int64_t n, const void* x, const void* res, void* y, float p, const int64_t* seed, unsigned site,
+                           int act, hipStream_t st) {
+    const size_t n4 = ((size_t)n + 3) / 4;
+    const uintptr_t al = (dtype == CVFT_F32) ? 15 : 7;
+    const bool vec = (n % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & al) == 0);
+#define DR_LAUNCH(TT, VV) hipLaunchKernelGGL((dropout_add_kernel<TT, MODE, VV>), dim3(ew_grid(n4)), dim3(256), 0, st, (size_t)n, (const TT*)x, \
+                                             (const TT*)res, (TT*)y, p, (const long long*)seed, site, act)
+    if (dtype == CVFT_F32) { if (vec) DR_LAUNCH(float, true); else DR_LAUNCH(float, false); }
+    else { if (vec) DR_LAUNCH(bf16_t, true); else DR_LAUNCH(bf16_t, false); }
+#undef DR_LAUNCH
 }
 extern "C" int cvft_dropout_add(int dtype, int64_t n, const void* x, const void* residual, void* y, float p,
                                 const int64_t* seed, unsigned site, void* stream) {
     CHECK_DTYPE("cvft_dropout_add", dtype);
     CVFT_CHECK_ARG(n >= 0 && x && y && seed && p >= 0.f && p < 1.f, "cvft_dropout_add: bad args (0 <= p < 1)");
     if (n == 0) return 0;
-    const size_t n4 = ((size_t)n + 3) / 4;
-    if (dtype == CVFT_F32)
-        hipLaunchKernelGGL((dropout_add_kernel<float>), dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (size_t)n, (const float*)x,
-                           (const float*)residual, (float*)y, p, (const long long*)seed, site);
-    else
-        hipLaunchKernelGGL((dropout_add_kernel<bf16_t>), dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (size_t)n, (const bf16_t*)x,
-                           (const bf16_t*)residual, (bf16_t*)y, p, (const long long*)seed, site);
+    dropout_launch<0>(dtype, n, x, residual, y, p, seed, site, 0, (hipStream_t)stream);
     CVFT_LAUNCH_CHECK("cvft_dropout_add");
+    return 0;
+}
+// h = dropout(act(z)) (positionwise_feed_forward.py:54) and its backward dz = keep/(1-p) * dh * act'(z), one pass each
+// (dh == NULL: forward).
+extern "C" int cvft_act_dropout(int dtype, int64_t n, int act, const void* z, const void* dh, void* y, float p,
+                                const int64_t* seed, unsigned site, void* stream) {
+    CHECK_DTYPE("cvft_act_dropout", dtype);
+    CVFT_CHECK_ARG(n >= 0 && z && y && seed && p >= 0.f && p < 1.f, "cvft_act_dropout: bad args (0 <= p < 1)");
+    if (n == 0) return 0;
+    if (dh) dropout_launch<2>(dtype, n, z, dh, y, p, seed, site, act, (hipStream_t)stream);
+    else dropout_launch<1>(dtype, n, z, nullptr, y, p, seed, site, act, (hipStream_t)stream);
+    CVFT_LAUNCH_CHECK("cvft_act_dropout");
     return 0;
 }
 

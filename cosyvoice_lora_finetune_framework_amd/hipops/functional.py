@@ -198,6 +198,36 @@ def dropout_add(x, p: float, residual=None):
     return DropoutAddFn.apply(x, residual, p, _DROPOUT["site"])
 
 
+class ActDropoutFn(torch.autograd.Function):
+    """h = dropout(act(z), p): one pass forward, one pass backward (dz = keep/(1-p) * dh * act'(z)) -- instead of the
+    activation in the GEMM epilogue + a dropout pass forward and a dropout pass + an activation-backward pass backward."""
+
+    @staticmethod
+    def forward(ctx, z, act: str, p: float, site: int):
+        z = _c(z)
+        h = torch.empty_like(z)
+        check(lib().cvft_act_dropout(dt(z), z.numel(), ACT[act], ptr(z), None, ptr(h), float(p), ptr(_DROPOUT["seed"]), site, stream()),
+              "cvft_act_dropout")
+        ctx.save_for_backward(z)
+        ctx.cfg = (act, float(p), site)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        (z,) = ctx.saved_tensors
+        act, p, site = ctx.cfg
+        dh = _c(dh)
+        dz = torch.empty_like(z)
+        check(lib().cvft_act_dropout(dt(z), z.numel(), ACT[act], ptr(z), ptr(dh), ptr(dz), p, ptr(_DROPOUT["seed"]), site, stream()),
+              "cvft_act_dropout")
+        return dz, None, None, None
+
+
+def act_dropout(z, act: str, p: float):
+    """dropout(act(z), p) with p > 0 (training)."""
+    return ActDropoutFn.apply(z, act, p, _next_drop_site())
+
+
 def _next_drop_site() -> int:
     if _DROPOUT["seed"] is None:
         dropout_begin_step()

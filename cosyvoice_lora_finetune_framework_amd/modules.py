@@ -489,7 +489,10 @@ class PositionwiseFeedForward(nn.Module):
     def forward(self, y, residual, out_dropout: float = 0.0):
         if self.training and (self.dropout_rate > 0 or out_dropout > 0):
             # w_2(dropout(act(w_1 x)))  (positionwise_feed_forward.py:54), then residual + dropout(.) (encoder_layer.py:104 / 234)
-            h = HF.dropout_add(hip_linear(self.w_1, y, act=self.activation), self.dropout_rate)
+            if self.dropout_rate > 0:         # activation and inner dropout in one pass (and one pass backward)
+                h = HF.act_dropout(hip_linear(self.w_1, y), self.activation, self.dropout_rate)
+            else:
+                h = hip_linear(self.w_1, y, act=self.activation)
             return HF.dropout_add(hip_linear(self.w_2, h), out_dropout, residual)
         return hip_ffn(self.w_1, self.w_2, y, self.activation, residual=residual)
 

@@ -236,6 +236,10 @@ int cvft_act_bwd(int dtype, int64_t n, int act, const void* z, const void* dy, v
  * backward pass calls the same entry point on dy with the same (seed, site) instead of storing a mask. */
 int cvft_dropout_add(int dtype, int64_t n, const void* x, const void* residual, void* y, float p,
                      const int64_t* seed, unsigned site, void* stream);
+/* h = dropout(act(z)) (positionwise_feed_forward.py:54: w_2(dropout(activation(w_1 x)))) in one pass, and (dh != NULL) its
+ * backward  y = keep/(1-p) * dh * act'(z)  in one pass; same mask generator and (seed, site) convention. */
+int cvft_act_dropout(int dtype, int64_t n, int act, const void* z, const void* dh, void* y, float p,
+                     const int64_t* seed, unsigned site, void* stream);
 /* LoRA side path under lora_dropout (lora.py:70-73), bf16, masks shared with cvft_dropout_add (element index m*K + k):
  *   cvft_skinny_dropout : U[M,R] = alpha/(1-p) * sum_k keep_t(m,k) X[m,k] A[16t+j][k]   (t = rank tile, sites[t]; R = 16 or 48);
  *                         xd (NULL or R/16 pointers, entries may be NULL): also writes drop_t(X) = keep_t X / (1-p), [M][K] each,

@@ -854,3 +854,23 @@ print("ok")
     env = dict(os.environ, CVFT_GEMM_BIG="2")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act,n", [("silu", 4096 * 3), ("relu", 1001)])
+def test_act_dropout_one_pass(dtype, act, n):
+    """cvft_act_dropout: h = dropout(act(z)) and dz = keep/(1-p) * dh * act'(z), each one pass, against torch on the
+    host-replicated mask (vector path n % 4 == 0 and the scalar tail path)."""
+    HF = HFmod()
+    pdrop = 0.1
+    z = q(rnd(n, seed=1) * 2, dtype)
+    gh = q(rnd(n, seed=2), dtype)
+    zd = z.to(DEV, dtype).requires_grad_(True)
+    HF.dropout_begin_step()
+    h = HF.act_dropout(zd, act, pdrop)
+    h.backward(gh.to(DEV, dtype))
+    mask = _keep_scale_host(int(HF._DROPOUT["seed"].item()), HF._DROPOUT["site"], n, pdrop)
+    zr = z.double().requires_grad_(True)
+    hr = (F.silu(zr) if act == "silu" else F.relu(zr)) * mask
+    hr.backward(gh.double())
+    assert rel(h, hr) < TOL[dtype] and rel(zd.grad, zr.grad) < TOL[dtype] * 2
