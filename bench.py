@@ -235,7 +235,8 @@ def main():
         torch.cuda.synchronize()
         groups = {}
         for rec in HF.PROFILE:
-            g = groups.setdefault(rec["kernel"], {"ms": 0.0, "flop": 0.0, "n": 0, "bytes": 0.0})
+            # the masked-extension instantiation (",xdrop": lora_dropout dgrad) is the same kernel with a different rank tail
+            g = groups.setdefault(rec["kernel"].replace(",xdrop", ""), {"ms": 0.0, "flop": 0.0, "n": 0, "bytes": 0.0})
             g["ms"] += rec["start"].elapsed_time(rec["end"])
             g["flop"] += rec["flop"]
             g["bytes"] += rec.get("bytes", 0.0)
