@@ -71,6 +71,9 @@ SIGNATURES = {
     "cvft_lora_rank_partial_batch": [_i, _i, _p, _p],
     "cvft_debug_big_stamps": [_p],
     "cvft_debug_glds_stamps": [_p],
+    "cvft_debug_mfma_fp8_probe": [_p, _p, _p, _p],
+    "cvft_quant_fp8_rows": [_i, _i, _p, _i, _p, _i, _p, _p],
+    "cvft_gemm_fp8": [_p, _p, _i, _p, _p, _i, _p, _p],
     "cvft_lora_grad_reduce": [_i, _p, _i, _p],
     "cvft_lora_shadow": [_i, _p, _p, _p],
     "cvft_layernorm_fwd": [_i, _i, _i, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p],

@@ -128,6 +128,42 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
     return out
 
 
+def quant_fp8_rows(x: torch.Tensor):
+    """(q uint8 [M, K] e4m3 bytes, scale fp32 [M]): q[m] = e4m3(x[m] / scale[m]), scale[m] = max|x[m]| / 448 (bf16 in)."""
+    assert x.dim() == 2 and x.dtype == torch.bfloat16 and x.stride(1) == 1
+    M, K = x.shape
+    qt = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib().cvft_quant_fp8_rows(M, K, ptr(x), x.stride(0), ptr(qt), qt.stride(0), ptr(sc), stream()), "cvft_quant_fp8_rows")
+    return qt, sc
+
+
+def gemm_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, bias=None, U=None, Bl=None, alpha: float = 1.0,
+             act: Optional[str] = None, residual=None, out=None) -> torch.Tensor:
+    """C[M, N] bf16 = epi(alpha * (xs[m] ws[n] (xq wq^T) + U Bl^T) + bias) on e4m3 operands (quant_fp8_rows); LoRA term, bias,
+    activation and residual as in gemm()."""
+    M, K = xq.shape
+    N = wq.shape[0]
+    assert wq.shape[1] == K and xs.numel() == M and ws.numel() >= N
+    a = GemmArgs()
+    a.dtype = cb.BF16
+    a.M, a.N, a.K = M, N, K
+    a.Tm = a.Tin = a.Tout = M
+    a.in_stride, a.out_stride, a.out_off, a.ntaps = 1, 1, 0, 1
+    if U is not None:
+        assert Bl is not None and U.shape[0] == M and Bl.shape[0] == N and U.shape[1] == Bl.shape[1]
+        a.U, a.ldu, a.R = ptr(U), U.stride(0), U.shape[1]
+        a.Bl, a.ldbl = ptr(Bl), Bl.stride(0)
+    a.bias, a.alpha, a.act = ptr(bias), float(alpha), ACT[act]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=xq.device)
+    if residual is not None:
+        a.residual, a.ldr = ptr(residual), residual.stride(0)
+    a.C, a.ldc = ptr(out), out.stride(0)
+    check(lib().cvft_gemm_fp8(C.byref(a), ptr(xq), xq.stride(0), ptr(xs), ptr(wq), wq.stride(0), ptr(ws), stream()), "cvft_gemm_fp8")
+    return out
+
+
 def tn_accum(P: torch.Tensor, Q: torch.Tensor, G: torch.Tensor) -> None:
     """G[p,q] += sum_m P[m,p] Q[m,q]  (G fp32)."""
     assert P.shape[0] == Q.shape[0] and G.dtype == torch.float32 and G.shape == (P.shape[1], Q.shape[1])

@@ -89,6 +89,17 @@ typedef struct {
 } cvft_gemm_args;
 
 int cvft_gemm(const cvft_gemm_args* a, void* stream);
+
+/* fp8 path for the frozen-W GEMMs (BASELINE configs[4]) -- OCP e4m3 operands, fp32 accumulation:
+ *   cvft_quant_fp8_rows : q[m][k] = e4m3(x[m][k] / s[m]),  s[m] = max_k |x[m][k]| / 448   (bf16 in; activation rows = per-token
+ *                         scales, weight rows = per-output-channel scales; W is frozen under LoRA, so its copy is made once)
+ *   cvft_gemm_fp8       : C = epilogue(alpha * (a_scale[m] * w_scale[n] * (A8 . W8^T) + U . Bl^T)) -- `a` as for cvft_gemm
+ *                         (dtype bf16: U / Bl / bias / residual / C stay bf16 / fp32; a->A, a->W, lda, ldw are ignored),
+ *                         identity row geometry, K % 128 == 0, N % 4 == 0.  Block-scaled MFMA (16x16x128) with unit block
+ *                         scales: twice the bf16 matrix rate and half the L2 -> LDS bytes per FLOP of cvft_gemm. */
+int cvft_quant_fp8_rows(int M, int K, const void* x, int ldx, void* q, int ldq, float* scale, void* stream);
+int cvft_gemm_fp8(const cvft_gemm_args* a, const void* A8, int lda8, const float* a_scale, const void* W8, int ldw8,
+                  const float* w_scale, void* stream);
 /* Name of the kernel the calling thread's most recent cvft_gemm launched, e.g. "gemm_glds_kernel<bf16,128,64,4,2>"
  * (profiling label only: bench.py groups its HIP-event timings by it). */
 const char* cvft_gemm_last_kernel(void);
@@ -298,6 +309,9 @@ int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream);
 int cvft_debug_big_stamps(unsigned long long* host_out);
 /* same for the default 128x128 kernel (CVFT_GLDS_BIG=15 launches its stamped build; tools/glds_stamps.py) */
 int cvft_debug_glds_stamps(unsigned long long* host_out);
+/* fp8 groundwork (BASELINE configs[4]): one v_mfma_scale_f32_16x16x128_f8f6f4 product, C[16][16] = A[16][128] . B[16][128]^T on
+ * OCP e4m3 bytes with unit block scales -- pins the operand layout the fp8 GEMM will use (tests/test_ops_gpu.py). */
+int cvft_debug_mfma_fp8_probe(const void* A, const void* B, float* C, void* stream);
 
 #ifdef __cplusplus
 }

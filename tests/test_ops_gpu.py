@@ -874,3 +874,46 @@ def test_act_dropout_one_pass(dtype, act, n):
     hr = (F.silu(zr) if act == "silu" else F.relu(zr)) * mask
     hr.backward(gh.double())
     assert rel(h, hr) < TOL[dtype] and rel(zd.grad, zr.grad) < TOL[dtype] * 2
+
+
+def test_fp8_mfma_operand_layout_probe():
+    """v_mfma_scale_f32_16x16x128_f8f6f4 (unit e8m0 scales, both operands OCP e4m3): lane l supplies row l & 15, bytes
+    32 (l >> 4) .. + 31 -- exact on exactly-representable data (csrc/gemm_fp8.hip; groundwork of BASELINE configs[4])."""
+    from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
+    g = torch.Generator().manual_seed(0)
+    vals = torch.tensor([-4., -3., -2., -1.5, -1., -.5, 0., .5, 1., 1.5, 2., 3., 4., 6., 8., .25])
+    A, B = vals[torch.randint(0, 16, (16, 128), generator=g)], vals[torch.randint(0, 16, (16, 128), generator=g)]
+    ad, bd = A.to(torch.float8_e4m3fn).view(torch.uint8).to(DEV), B.to(torch.float8_e4m3fn).view(torch.uint8).to(DEV)
+    Cd = torch.zeros(16, 16, device=DEV)
+    cb.check(cb.lib().cvft_debug_mfma_fp8_probe(ad.data_ptr(), bd.data_ptr(), Cd.data_ptr(), None), "probe")
+    assert torch.equal(Cd.cpu().double(), A.double() @ B.double().t())
+
+
+@pytest.mark.parametrize("M,N,K,R", [(300, 192, 256, 16), (1024, 512, 1024, 0), (5328, 1024, 1024, 16), (2056, 520, 384, 64)])
+def test_fp8_quant_and_gemm(M, N, K, R):
+    """cvft_quant_fp8_rows against torch's e4m3 conversion of the same scaled rows (bit-exact), and cvft_gemm_fp8 against the
+    fp64 product of the DEQUANTISED operands (+ LoRA term, bias, residual): the kernel's own error is fp32 accumulation only;
+    the quantisation error against the unquantised product is reported by the looser second check."""
+    HF = HFmod()
+    g = torch.Generator().manual_seed(M + N)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    bd = lambda t: t.to(DEV, torch.bfloat16)
+    x, w = bd(rn(M, K)), bd(rn(N, K) / K ** 0.5)
+    xq, xs = HF.quant_fp8_rows(x)
+    wq, ws = HF.quant_fp8_rows(w)
+    xf = x.float().cpu()
+    s_ref = xf.abs().amax(dim=1) * (1.0 / 448.0)
+    assert torch.equal(xs.cpu(), s_ref)
+    q_ref = (xf * (1.0 / s_ref).unsqueeze(1)).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(xq.cpu(), q_ref)
+    u, bl = (bd(rn(M, R)), bd(rn(N, R) * 0.1)) if R else (None, None)
+    b, res = rn(N).to(DEV), bd(rn(M, N))
+    y = HF.gemm_fp8(xq, xs, wq, ws, bias=b, U=u, Bl=bl, residual=res)
+    deq = lambda qt, sc: qt.cpu().view(torch.float8_e4m3fn).double() * sc.cpu().double().unsqueeze(1)
+    ref = deq(xq, xs) @ deq(wq, ws).t() + b.cpu().double() + res.cpu().double()
+    true = x.cpu().double() @ w.cpu().double().t() + b.cpu().double() + res.cpu().double()
+    if R:
+        ext = u.cpu().double() @ bl.cpu().double().t()
+        ref, true = ref + ext, true + ext
+    assert rel(y, ref) < 4e-3, rel(y, ref)                      # bf16 output rounding
+    assert rel(y, true) < 6e-2, rel(y, true)                    # e4m3 operands: a few per cent
