@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", type=int, default=1, help="capture fwd+bwd in a hipGraph (0 = eager launches)")
     ap.add_argument("--dropout", type=int, default=1, help="1 (default) = train() mode with all of the reference's training dropouts (LoRA 0.15 / 0.05, encoder 0.1), as trainer.fit runs the step; 0 = eval() mode, dropout off, like the parity fixtures; 2 / 3 = LoRA / encoder dropouts only (diagnostic)")
+    ap.add_argument("--fp8", type=int, default=0, help="1 = BASELINE configs[4] arithmetic: the frozen-W GEMMs of the LLM-sized linears in OCP e4m3 (per-token / per-channel scales); LoRA path, reductions and everything else stay bf16 / fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -159,6 +160,7 @@ def main():
     from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
     from cosyvoice_lora_finetune_framework_amd.synthetic import synth_batch
 
+    HF.FP8_ON = bool(a.fp8)
     rank, local, world = dp.init_from_env()
     if world != a.gpus:
         log(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
@@ -267,7 +269,7 @@ def main():
             "metric": "train utterances/sec (500-frame mel, LoRA r=16) at 1/2/4/8 MI355X",
             "value": utt / elapsed, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.dtype, "data": "synthetic",
+            "dtype": ("fp8-e4m3 frozen-W GEMMs + " + a.dtype) if a.fp8 else a.dtype, "data": "synthetic",
             "config": {"workload": f"{a.workload} LLM+Flow LoRA r={a.rank_lora} step (fwd+bwd+allreduce+clip+AdamW), "
                                    f"CosyVoice-300M dims random-init, {T}-frame x 80-mel clips, "
                                    f"{int(T * 50 * 256 / 22050)} speech tokens, 40 text tokens",

@@ -139,7 +139,7 @@ def quant_fp8_rows(x: torch.Tensor):
 
 
 def gemm_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, bias=None, U=None, Bl=None, alpha: float = 1.0,
-             act: Optional[str] = None, residual=None, out=None) -> torch.Tensor:
+             act: Optional[str] = None, preact=None, dact_src=None, dact: Optional[str] = None, residual=None, out=None) -> torch.Tensor:
     """C[M, N] bf16 = epi(alpha * (xs[m] ws[n] (xq wq^T) + U Bl^T) + bias) on e4m3 operands (quant_fp8_rows); LoRA term, bias,
     activation and residual as in gemm()."""
     M, K = xq.shape
@@ -157,11 +157,36 @@ def gemm_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Ten
     a.bias, a.alpha, a.act = ptr(bias), float(alpha), ACT[act]
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=xq.device)
+    if preact is not None:
+        a.preact, a.ldp = ptr(preact), preact.stride(0)
+    if dact_src is not None:
+        a.dact_src, a.ldd, a.dact = ptr(dact_src), dact_src.stride(0), ACT[dact]
     if residual is not None:
         a.residual, a.ldr = ptr(residual), residual.stride(0)
     a.C, a.ldc = ptr(out), out.stride(0)
     check(lib().cvft_gemm_fp8(C.byref(a), ptr(xq), xq.stride(0), ptr(xs), ptr(wq), wq.stride(0), ptr(ws), stream()), "cvft_gemm_fp8")
     return out
+
+
+FP8_ON = False                 # BASELINE configs[4]: the frozen-W GEMMs of the big linears in e4m3 (opt-in: bench.py --fp8 1, CVFT_FP8=1)
+FP8_MIN_WORK = 1 << 32         # M * N * K from which the activation quantisation pass pays (the LLM-sized linears)
+
+
+def _mm(x: torch.Tensor, holder, key: str, W: torch.Tensor, **kw) -> torch.Tensor:
+    """The frozen-weight GEMM of a linear (forward: holder.Wf, dgrad: holder.Wb) -- in e4m3 with per-row scales when FP8_ON and
+    the shape is eligible (the weight's quantised copy is made once and cached on `holder`), else cvft_gemm as is."""
+    N, K = W.shape
+    if (FP8_ON and x.dtype == torch.bfloat16 and K % 128 == 0 and N % 4 == 0 and x.shape[0] * N * K >= FP8_MIN_WORK
+            and x.shape[1] >= K and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and W.is_contiguous()
+            and not any(k in kw for k in ("La", "xdrop", "geo", "Uout"))):
+        cache = holder.__dict__.setdefault("_fp8_w", {})
+        ent = cache.get(key)
+        if ent is None or ent[2] is not W:
+            wq, ws = quant_fp8_rows(W)
+            ent = cache[key] = (wq, ws, W)
+        xq, xs = quant_fp8_rows(x[:, :K] if x.shape[1] != K else x)
+        return gemm_fp8(xq, xs, ent[0], ent[1], **kw)
+    return gemm(x, W, **kw)
 
 
 def tn_accum(P: torch.Tensor, Q: torch.Tensor, G: torch.Tensor) -> None:
@@ -541,6 +566,8 @@ class LoraGradSink:
 
 
 import os as _os
+if _os.environ.get('CVFT_FP8', '0') == '1':
+    FP8_ON = True
 STACKED_DROP_DEFER = _os.environ.get('CVFT_STACKED_DROP_DEFER', '0') != '0'
 KEEP_DROPPED = _os.environ.get('CVFT_KEEP_DROPPED', '1') != '0'   # forward writes drop(x) for the backward's dA (no re-derivation launch)
 XDROP_ON = _os.environ.get('CVFT_XDROP', '1') != '0'        # lora_dropout dgrad: masked rank extension inside the GEMM launch
@@ -615,7 +642,7 @@ def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residu
     if fused:
         y = gemm(x, pack.Wf, bias=pack.bias, La=ops[0], lora_scale=scale, Uout=U, Bl=ops[2], act=act, preact=z, residual=res)
     else:
-        y = gemm(x, pack.Wf, bias=pack.bias, U=U, Bl=None if ops is None else ops[2], act=act, preact=z, residual=res)
+        y = _mm(x, pack, 'f', pack.Wf, bias=pack.bias, U=U, Bl=None if ops is None else ops[2], act=act, preact=z, residual=res)
     return y, U, z, ops
 
 
@@ -700,7 +727,7 @@ def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_d
         elif need_dx or need_dAB:
             V = gemm(dz, Bt, alpha=scale)                         # [M, r] = s * dz B
     if need_dx and dx is None:
-        dx = gemm(dz, pack.Wb, U=V, Bl=None if V is None else ops[1], dact_src=dact_src, dact=dact, residual=dx_residual)
+        dx = _mm(dz, pack, 'b', pack.Wb, U=V, Bl=None if V is None else ops[1], dact_src=dact_src, dact=dact, residual=dx_residual)
     if has_lora and need_dAB:
         dA, dB = _lora_param_grads(x, U, V, dz, A_ref, B_ref, ops)
     return dx, dA, dB
@@ -812,7 +839,7 @@ class LinearQKVStackedFn(torch.autograd.Function):
             Y = gemm(x, wstack.Wf, bias=wstack.bias, La=A, lora_scale=scale, Uout=U, Bl=Bb)
         else:
             U = gemm(x, A, alpha=scale)
-            Y = gemm(x, wstack.Wf, bias=wstack.bias, U=U, Bl=Bb)       # [M, 3N]
+            Y = _mm(x, wstack, 'f', wstack.Wf, bias=wstack.bias, U=U, Bl=Bb)       # [M, 3N]
         ctx.w, ctx.ops, ctx.scale, ctx.refs = wstack, ops, scale, ((Aq, Bq), (Ak, Bk), (Av, Bv))
         ctx.save_for_backward(x, U)
         N = wstack.N
@@ -837,7 +864,7 @@ class LinearQKVStackedFn(torch.autograd.Function):
             dx = gemm(dY, w.Wb, La=Bbt, lora_scale=scale, Uout=V, Bl=At)   # V = s * dY B_blk produced by the same launch
         else:
             V = gemm(dY, Bbt, alpha=scale)                              # [M, 3r] = s * dY B_blk
-            dx = gemm(dY, w.Wb, U=V, Bl=At) if ctx.needs_input_grad[0] else None
+            dx = _mm(dY, w, 'b', w.Wb, U=V, Bl=At) if ctx.needs_input_grad[0] else None
         r3 = V.shape[1]
         r = r3 // 3
         sink = LoraGradSink.active

@@ -917,3 +917,35 @@ def test_fp8_quant_and_gemm(M, N, K, R):
         ref, true = ref + ext, true + ext
     assert rel(y, ref) < 4e-3, rel(y, ref)                      # bf16 output rounding
     assert rel(y, true) < 6e-2, rel(y, true)                    # e4m3 operands: a few per cent
+
+
+def test_fp8_linear_path_close_to_bf16():
+    """The opt-in fp8 arithmetic of the frozen-W GEMMs (HF.FP8_ON; BASELINE configs[4]) through LinearFn: forward, dgrad and the
+    LoRA gradients stay within e4m3 quantisation error of the bf16 path (the LoRA term itself is not quantised)."""
+    from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
+    from cosyvoice_lora_finetune_framework_amd.modules import hip_linear
+    HF = HFmod()
+    torch.manual_seed(11)
+    M, K, N = 4352, 512, 768                    # M * N above the in-launch side-path limit: the plain (U, Bl) main GEMM
+    mod = LoRALinear(torch.nn.Linear(K, N), r=16, lora_alpha=32, lora_dropout=0.0).to(DEV).eval()
+    torch.nn.init.normal_(mod.lora_B, std=0.05)
+    x0 = (torch.randn(M, K, device=DEV) * 0.7).to(torch.bfloat16)
+    gy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    outs = []
+    old = (HF.FP8_ON, HF.FP8_MIN_WORK)
+    try:
+        for on in (False, True):
+            HF.FP8_ON, HF.FP8_MIN_WORK = on, 0
+            x = x0.clone().requires_grad_(True)
+            for t in (mod.lora_A, mod.lora_B):
+                t.grad = None
+            y = hip_linear(mod, x, act="silu")
+            if on:
+                assert HF.lib().cvft_gemm_last_kernel().decode().startswith("gemm_fp8_kernel")
+            y.backward(gy)
+            outs.append([y.float(), x.grad.float(), mod.lora_A.grad.clone(), mod.lora_B.grad.clone()])
+    finally:
+        HF.FP8_ON, HF.FP8_MIN_WORK = old
+    for name, a, b in zip(("y", "dx", "dA", "dB"), outs[1], outs[0]):
+        assert rel(a, b) < 8e-2, (name, rel(a, b))
+    assert rel(outs[1][0], outs[0][0]) > 1e-4            # and it really ran in different arithmetic
