@@ -949,3 +949,30 @@ def test_fp8_linear_path_close_to_bf16():
     for name, a, b in zip(("y", "dx", "dA", "dB"), outs[1], outs[0]):
         assert rel(a, b) < 8e-2, (name, rel(a, b))
     assert rel(outs[1][0], outs[0][0]) > 1e-4            # and it really ran in different arithmetic
+
+
+@pytest.mark.parametrize("r", [16, 48])
+def test_lora_rank_partial_batch_matches_torch(r):
+    """cvft_lora_rank_partial_batch: slab products of MANY layers (each its own row count / width / orientation) in one
+    launch (70 problems -> two launches of <= 64), summed over their slabs and compared with torch."""
+    import ctypes
+    from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
+    HF = HFmod()
+    g = torch.Generator().manual_seed(r)
+    probs, keep, refs = [], [], []
+    shapes = [(1000, 256, 0), (777, 768, 1), (4000, 512, 0), (64, 64, 1), (2056, 1024, 0)] * 14
+    arr = (cb.RankProbM * len(shapes))()
+    for e, (M, Cn, tr) in zip(arr, shapes):
+        Wd = torch.randn(M, Cn, generator=g).to(DEV, torch.bfloat16)
+        Rk = torch.randn(M, r, generator=g).to(DEV, torch.bfloat16)
+        rpb = 256
+        ns = -(-M // rpb)
+        ws = torch.zeros(ns * r * Cn, dtype=torch.float32, device=DEV)
+        e.M, e.C, e.Wd, e.ldw, e.Rk, e.ldr, e.part, e.transpose_out, e.rows_per_block = M, Cn, Wd.data_ptr(), Cn, Rk.data_ptr(), r, ws.data_ptr(), tr, rpb
+        keep.append((Wd, Rk, ws, ns, tr, Cn))
+    cb.check(cb.lib().cvft_lora_rank_partial_batch(r, len(shapes), arr, None), "cvft_lora_rank_partial_batch")
+    torch.cuda.synchronize()
+    for Wd, Rk, ws, ns, tr, Cn in keep[::7]:
+        got = ws.view(ns, Cn, r).sum(0).t() if tr else ws.view(ns, r, Cn).sum(0)
+        ref = Rk.double().t() @ Wd.double()
+        assert rel(got, ref) < 1e-5, (Wd.shape, tr, rel(got, ref))
