@@ -153,6 +153,7 @@ __device__ __forceinline__ void gemm_epilogue_direct4(const GP<bf16_t>& p, const
         for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
     }
     bf16x4 o = {(bf16_t)(live ? v[0] : 0.f), (bf16_t)(live ? v[1] : 0.f), (bf16_t)(live ? v[2] : 0.f), (bf16_t)(live ? v[3] : 0.f)};
+    // (non-temporal stores here: +3 % on 5328x4096x1024, -3 % on 5328x1024x4096, -10 % on the estimator shapes, step 31.7 vs 30.7 ms)
     *reinterpret_cast<bf16x4*>(&p.C[orow * p.ldc + n]) = o;
 }
 

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_HERE, "libcvft.so")
+LIB_PATH = os.environ.get("CVFT_LIB_PATH") or os.path.join(_HERE, "libcvft.so")      # (override: A/B builds of the library)
 
 F32, BF16 = 0, 1
 ACT = {None: 0, "none": 0, "relu": 1, "silu": 2, "swish": 2, "gelu": 3, "gelu_erf": 3, "gelu_tanh": 4, "mish": 5}
