@@ -470,7 +470,7 @@ class LoraGradSink:
         colblocks = -(-Cn // 64)
         rpb = 64
         for cand in (128, 256, 512, 768, 1024, 2048):
-            if colblocks * (-(-M // cand)) >= 512:
+            if colblocks * (-(-M // cand)) >= SINK_PLAN_BLOCKS:
                 rpb = cand
         return rpb, -(-M // rpb)
 
@@ -571,6 +571,7 @@ if _os.environ.get('CVFT_FP8', '0') == '1':
 STACKED_DROP_DEFER = _os.environ.get('CVFT_STACKED_DROP_DEFER', '0') != '0'
 KEEP_DROPPED = _os.environ.get('CVFT_KEEP_DROPPED', '1') != '0'   # forward writes drop(x) for the backward's dA (no re-derivation launch)
 XDROP_ON = _os.environ.get('CVFT_XDROP', '1') != '0'        # lora_dropout dgrad: masked rank extension inside the GEMM launch
+SINK_PLAN_BLOCKS = int(_os.environ.get('CVFT_SINK_PLAN_BLOCKS', 512))
 SINK_DEFER = _os.environ.get('CVFT_SINK_DEFER', '1') != '0'
 SINK_DEFER_MAX = int(_os.environ.get('CVFT_SINK_DEFER_MAX', 12_000_000))      # x.numel() + dY.numel(): the flow branch's layers
 SINK_DEFER_RPB = int(_os.environ.get('CVFT_SINK_DEFER_RPB', 256))

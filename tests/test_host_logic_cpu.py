@@ -265,3 +265,17 @@ def test_merge_joint_weights_from_trainer_checkpoint(tiny_meta, tmp_path):
     want = sd[f"model.llm.{name}.original_layer.weight"] + (L["alpha"] / L["r"]) * sd[f"model.llm.{name}.lora_B"] @ sd[f"model.llm.{name}.lora_A"]
     assert torch.allclose(llm_m[f"{name}.weight"], want, rtol=1e-6, atol=1e-7)
     assert not torch.equal(llm_m["llm_decoder.bias"], torch.zeros_like(llm_m["llm_decoder.bias"]))
+
+
+def test_slab_plans_are_legal_for_the_rank_kernels():
+    """LoraGradSink.plan / plan_deferred (host side of the deterministic LoRA-gradient slabs): rows per block a multiple of 32
+    (the matrix-core slab kernel's k-step), slabs cover every row, and the block target is met whenever the shape allows."""
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    for M in (1, 31, 64, 4000, 5328, 8000, 9968, 100000):
+        for Cn in (64, 256, 768, 1024, 4096):
+            rpb, ns = HF.LoraGradSink.plan(M, Cn)
+            assert rpb % 32 == 0 and ns * rpb >= M > (ns - 1) * rpb
+            if rpb > 64:
+                assert -(-Cn // 64) * ns >= HF.SINK_PLAN_BLOCKS
+        rpb, ns = HF.LoraGradSink.plan_deferred(M)
+        assert rpb % 32 == 0 and ns * rpb >= M > (ns - 1) * rpb
