@@ -501,7 +501,8 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     // ~1900 cycles per wave -- 400-700 waiting for its DMA pieces (issued one iteration earlier: ~1500 cycles of latency
     // at ~9.5 TB/s of aggregate L2 -> LDS traffic), ~100 in the barrier, 360-530 issuing 4 pieces, 680 for 12 fragment
     // reads + 16 MFMAs (256 of them matrix-core time).  A third / fourth stage (one block per CU) is slower (468 vs 602
-    // TFLOP/s): what is missing is FLOP per L2 byte, i.e. the 256x256 tile of gemm_big.hip, not pipeline depth.
+    // TFLOP/s): what is missing is FLOP per L2 byte, i.e. the 256x256 tile of gemm_big.hip, not pipeline depth.  (Issuing the
+    // fragment reads before the DMA pieces, so that the issue time covers the LDS latency, regressed to 365 TFLOP/s.)
     if (big && (nk >= 8 || big_env == 12) && t64 >= 1000) return glds_launch_cfg<128, 128, 4, 2, 0, 2>(p, st);
     if (big) {
         if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, 0, 3>(p, st);
