@@ -29,7 +29,12 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
             backend = os.environ.get("CVFT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            try:        # bind the communicator to this rank's GPU up front (no device guessing in barrier / first collective)
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            except TypeError:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
 
