@@ -8,40 +8,7 @@
 //
 // Replaces (reference): modules.py:253-293 / diffusers Attention; attention.py:200-330, 82-127.
 #include <stdlib.h>
-#include "attn_common.cuh"
-
-template <typename T>
-struct AP {
-    int B, H, L;
-    const T *q, *k, *v; int ld;
-    const T* p; int ldp;
-    const float *bu, *bv;
-    const int* len;
-    int causal; float scale;
-    T* o; int ldo; float* lse;
-    const T* d_o; const float* delta;
-    T *dq, *dk, *dv; int ldg;
-    // attention-probability dropout (attention.py:118 `self.dropout(attn)`; DROP instantiations only)
-    float drop_p; const long long* seed; unsigned site;
-    int iso;      // REL = false: prompt-isolation split (modules.py:844-879); 0 = off
-};
-
-// keep-scale of score (b, h, i, j): 1/(1-p) or 0.  Counter-based (SplitMix64 finaliser, same as cvft_dropout_add), so
-// forward and both backward kernels re-derive the same mask from (*seed, site, element index).
-__device__ __forceinline__ float attn_keep_scale(unsigned long long key, unsigned long long idx, unsigned thr, float inv) {
-    unsigned long long z = key + idx + 0x9e3779b97f4a7c15ULL;
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-    z ^= z >> 31;
-    return (unsigned)z >= thr ? inv : 0.f;
-}
-__device__ __forceinline__ unsigned long long attn_drop_key(const long long* seed, unsigned site) {
-    unsigned long long z = (unsigned long long)seed[0] ^ ((unsigned long long)site << 32);
-    z += 0x9e3779b97f4a7c15ULL;
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-    return z ^ (z >> 31);
-}
+#include "attn_common.h"
 
 #define NEG_INF (-__builtin_inff())
 // The per-wave LDS regions (Gw skew buffer, P / dS tiles) are written and read by the SAME wavefront: a wave's LDS
@@ -625,6 +592,21 @@ template <typename T, bool REL, bool DROP = false>
 __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AP<T> p) { attn_bwd_dkv_body<T, REL, DROP>(p, blockIdx.x); }
 
 // ------------------------------------------------------------------------ host side
+// bf16 launches go to the 32x32 MFMA kernels of attn_mfma32.hip (CVFT_ATTN_V1=1 keeps the generic kernels below, which
+// also serve fp32 and the gradient w.r.t. the projected positional encoding).
+int cvft_attn32_fwd(const AP<bf16_t>& p, int rel, hipStream_t st);
+int cvft_attn32_bwd(const AP<bf16_t>& p, int rel, hipStream_t st);
+static bool attn_v1() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CVFT_ATTN_V1");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+static bool al8(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+    return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 7) == 0;
+}
 template <typename T> static size_t smem_fwd(bool rel) {
     typedef AttnCfg<T> A;
     size_t s = (size_t)(2 * A::TILE + 4 * 16 * A::LDK) * sizeof(T);
@@ -738,6 +720,7 @@ extern "C" int cvft_attn_bias_fwd(int dtype, int B, int H, int T_, const void* q
     }
     AP<bf16_t> a = make_ap<bf16_t>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
     a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse; a.iso = (iso_len > 0 && iso_len < T_) ? iso_len : 0;
+    if (!attn_v1() && al8(o) && ldo % 4 == 0) return cvft_attn32_fwd(a, 0, st);
     return launch_fwd<bf16_t, false>(a, st);
 }
 
@@ -757,6 +740,10 @@ extern "C" int cvft_attn_bias_bwd(int dtype, int B, int H, int T_, const void* q
     AP<bf16_t> a = make_ap<bf16_t>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
     a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const bf16_t*)d_o; a.delta = delta;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.iso = (iso_len > 0 && iso_len < T_) ? iso_len : 0;
+    if (!attn_v1() && al8(dq, dk, dv, o) && ldg % 4 == 0) {
+        a.o = (bf16_t*)o;
+        return cvft_attn32_bwd(a, 0, st);
+    }
     return launch_bwd<bf16_t, false>(a, delta, (const bf16_t*)o, st);
 }
 
@@ -779,6 +766,7 @@ extern "C" int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* 
     AP<bf16_t> a = make_ap<bf16_t>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
     a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse;
     a.drop_p = drop_p; a.seed = (const long long*)drop_seed; a.site = drop_site;
+    if (!attn_v1() && al8(o) && ldo % 4 == 0) return cvft_attn32_fwd(a, 1, st);
     return launch_fwd<bf16_t, true>(a, st);
 }
 
@@ -807,5 +795,9 @@ extern "C" int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* 
     a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const bf16_t*)d_o; a.delta = delta;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg;
     a.drop_p = drop_p; a.seed = (const long long*)drop_seed; a.site = drop_site;
+    if (!attn_v1() && al8(dq, dk, dv, o) && ldg % 4 == 0) {
+        a.o = (bf16_t*)o;
+        return cvft_attn32_bwd(a, 1, st);
+    }
     return launch_bwd<bf16_t, true>(a, delta, (const bf16_t*)o, st);
 }

@@ -1,11 +1,11 @@
-// attn_common.cuh -- shared pieces of the fused attention kernels (head_dim 64).
+// attn_common.h -- shared pieces of the fused attention kernels (head_dim 64).
 // LDS tiles are [64 rows][64 cols] with row stride LDK.  Every MFMA operand is read
 // through one of two loaders:
 //   ld_kc : operand stored with its reduction index contiguous  ([rc][k])  -> 16-byte read
 //   ld_km : operand stored reduction-index-major               ([k][rc])  -> strided gather
 // (MFMA lane maps: cdna_hip_programming.md section 3.)
 #pragma once
-#include "common.cuh"
+#include "common.h"
 
 template <typename T> struct AttnCfg {
     static constexpr int VEC = 16 / sizeof(T);
@@ -14,6 +14,41 @@ template <typename T> struct AttnCfg {
     static constexpr int NK = 64 / Mma<T>::K;    // MFMA k-steps across 64
     static constexpr int TILE = 64 * LDK;        // elements per staged tile
 };
+
+// ---- kernel parameter block shared by every attention kernel (generic T kernels: attention.hip; bf16 32x32 MFMA
+// kernels: attn_mfma32.hip)
+template <typename T>
+struct AP {
+    int B, H, L;
+    const T *q, *k, *v; int ld;
+    const T* p; int ldp;
+    const float *bu, *bv;
+    const int* len;
+    int causal; float scale;
+    T* o; int ldo; float* lse;
+    const T* d_o; const float* delta;
+    T *dq, *dk, *dv; int ldg;
+    // attention-probability dropout (attention.py:118 `self.dropout(attn)`; DROP instantiations only)
+    float drop_p; const long long* seed; unsigned site;
+    int iso;      // REL = false: prompt-isolation split (modules.py:844-879); 0 = off
+};
+
+// keep-scale of score (b, h, i, j): 1/(1-p) or 0.  Counter-based (SplitMix64 finaliser, same as cvft_dropout_add), so
+// forward and both backward kernels re-derive the same mask from (*seed, site, element index).
+__device__ __forceinline__ float attn_keep_scale(unsigned long long key, unsigned long long idx, unsigned thr, float inv) {
+    unsigned long long z = key + idx + 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    return (unsigned)z >= thr ? inv : 0.f;
+}
+__device__ __forceinline__ unsigned long long attn_drop_key(const long long* seed, unsigned site) {
+    unsigned long long z = (unsigned long long)seed[0] ^ ((unsigned long long)site << 32);
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
 
 // global rows r0..r0+63 (64 columns each, leading dim ld) -> LDS S[r][c]; rows outside [0,rlim) are zero
 template <typename T>

@@ -1,7 +1,7 @@
 // ce.hip -- token-mean cross entropy with ignore index + argmax accuracy, one block per row.
 // Never builds the dense (n, V) true_dist / KLDiv temporaries of the reference
 // (label_smoothing_loss.py:68-96 with smoothing 0; common.py:78-97).
-#include "common.cuh"
+#include "common.h"
 
 __device__ __forceinline__ float block_max(float v, float* sm) {
     v = wave_max(v);

@@ -1,4 +1,4 @@
-// common.cuh -- shared device helpers for libcvft (gfx950 / CDNA4 only).
+// common.h -- shared device helpers for libcvft (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,6 +1,6 @@
 // core.hip -- version + thread-local error string of libcvft.
 #include <stdarg.h>
-#include "common.cuh"
+#include "common.h"
 
 static thread_local char g_err[512] = "";
 

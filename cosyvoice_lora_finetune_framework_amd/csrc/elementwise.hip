@@ -2,7 +2,7 @@
 // masked MSE, interpolation, depthwise conv, time embedding, optimiser pieces).
 // All are grid-stride, coalesced along the channel (fastest) axis.
 #include <type_traits>
-#include "common.cuh"
+#include "common.h"
 
 static inline unsigned ew_grid(size_t total) {
     size_t g = (total + 255) / 256;

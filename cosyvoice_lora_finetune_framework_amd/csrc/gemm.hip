@@ -5,7 +5,7 @@
 // Replaces (reference): lora.py:64-76, nn.Linear/Conv1d/ConvTranspose1d calls of
 // modules.py:60-120 & matcha/models/components/decoder.py:35-158, and their dgrad.
 #include <stdlib.h>
-#include "gemm_common.cuh"
+#include "gemm_common.h"
 
 // Main loop: the K extent (all taps, then the rank-r LoRA segment) is cut into BK-wide tiles.  D tiles
 // are kept in flight in registers (these GEMMs are small and latency-bound: the lever is bytes in

@@ -42,11 +42,11 @@
 // prologue.  With K = 4096 the marginal k-tile already costs 1.0 us (2 PFLOP/s).
 //
 // The rank-R LoRA extension is applied after the main loop from fragment-shaped direct loads; the epilogue is the
-// register epilogue of gemm_common.cuh (swapped MFMA operands: a lane owns 4 consecutive output columns).
+// register epilogue of gemm_common.h (swapped MFMA operands: a lane owns 4 consecutive output columns).
 //
 // Replaces (reference): lora.py:64-76 / nn.Linear of the LLM's attention and feed-forward projections, and their dgrad.
 #include <stdlib.h>
-#include "gemm_common.cuh"
+#include "gemm_common.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;

@@ -1,6 +1,6 @@
-// gemm_common.cuh -- pieces shared by the tap-GEMM kernels (register-staged gemm.hip, LDS-DMA gemm_glds.hip).
+// gemm_common.h -- pieces shared by the tap-GEMM kernels (register-staged gemm.hip, LDS-DMA gemm_glds.hip).
 #pragma once
-#include "common.cuh"
+#include "common.h"
 
 #include <utility>
 template <int... I, typename F>

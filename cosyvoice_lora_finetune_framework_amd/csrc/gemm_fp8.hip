@@ -1,7 +1,7 @@
 // gemm_fp8.hip -- OCP fp8 (e4m3) building blocks for BASELINE configs[4] (frozen-W GEMMs in fp8).
 // Round 1: the block-scaled matrix instruction's operand layout, pinned by an exact-data probe
 // (v_mfma_scale_f32_16x16x128_f8f6f4 with unit e8m0 scales = plain e4m3 x e4m3 -> f32 at twice the bf16 rate).
-#include "common.cuh"
+#include "common.h"
 
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 
@@ -78,7 +78,7 @@ extern "C" int cvft_quant_fp8_rows(int M, int K, const void* x, int ldx, void* q
 // (8 waves as 4 x 2, two 32 KB stages, XOR-swizzled 128-byte rows, register epilogue) with 128 k per tile instead of 64:
 // the same bytes from L2 carry twice the FLOPs and the block-scaled MFMA retires them at twice the bf16 rate.
 // ------------------------------------------------------------------------------
-#include "gemm_common.cuh"
+#include "gemm_common.h"
 typedef __attribute__((address_space(3))) void lds_void8_t;
 typedef const __attribute__((address_space(1))) void glb_void8_t;
 

@@ -13,7 +13,7 @@
 //
 // Replaces (reference): lora.py:64-76 and the nn.Linear calls of the estimator / encoders, and their dgrad.
 #include <stdlib.h>
-#include "gemm_common.cuh"
+#include "gemm_common.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;

@@ -12,7 +12,7 @@
 // per 8 KB of input.
 //
 // Replaces (reference): the autograd of lora.py:71-76 (grad of lora_A / lora_B).
-#include "common.cuh"
+#include "common.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;

@@ -6,7 +6,7 @@
 // subsampling.py:69-113/338-383, matcha transformer.py:255-316; Block1D /
 // ResnetBlock1D GroupNorm(8)+Mish (modules.py:60-94) and InterpolateRegulator's
 // GroupNorm(1)+Mish (length_regulator.py:34-41).
-#include "common.cuh"
+#include "common.h"
 
 // One wavefront per row.  VP (C % VEC == 0, C <= 64*VEC*NCH, aligned): the row is read ONCE with 16-byte loads
 // into registers (NCH chunks per lane) and every later pass runs on registers; otherwise strided scalar passes.

@@ -6,7 +6,7 @@
 // the eight partial tiles are summed through LDS.  M/32 blocks x 8 waves: 1000+ waves in flight.
 //
 // Replaces (reference): the x @ lora_A.T product of lora.py:71-73 (and its transpose in backward).
-#include "gemm_common.cuh"
+#include "gemm_common.h"
 
 template <int RB, int MT, int KS>      // RB = R / 16 column tiles, MT = 16-row tiles per block, KS = k-steps in flight per wave
 __global__ void __launch_bounds__(512) skinny_kernel(int M, int K, const bf16_t* __restrict__ X, int ldx,

@@ -701,7 +701,7 @@ def test_attn_relpos_probability_dropout(dtype, causal):
 
 
 def _keep_scale_host(seed: int, site: int, n: int, p: float) -> torch.Tensor:
-    """Host replica of common.cuh cvft_drop_key / cvft_keep4 (the mask of cvft_dropout_add, cvft_skinny_dropout and
+    """Host replica of common.h cvft_drop_key / cvft_keep4 (the mask of cvft_dropout_add, cvft_skinny_dropout and
     cvft_lora_side_dgrad): flat [n] tensor of {0, 1/(1-p)}."""
     import numpy as np
     M = np.uint64(0xFFFFFFFFFFFFFFFF)
