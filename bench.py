@@ -10,6 +10,9 @@ A "step" = one pass of the hot path over one per-GPU batch of synthetic utteranc
 (500-frame x 80-mel clips, 290 speech tokens, 40 text tokens; random-init CosyVoice-300M dims,
 LoRA r=16 alpha=32): forward + backward + LoRA-gradient all-reduce + clip + AdamW.  Weak
 scaling: per-GPU batch fixed (default 16 = BASELINE configs[2] at N=1, configs[3] at N=8).
+By default the steps are the product loop's: train_joint.Trainer.fit over W + K host batches (per step: index maps,
+host -> device copies, replay of the trainer's captured micro-step hipGraph, all-reduce, clip + AdamW);
+--via-trainer 0 replays one pre-staged batch instead (within 2 % of each other on one MI355X).
 
 Extra objects on the JSON line:
   roofline     -- dominant kernel (by time) of an event-instrumented step run right after the timed
@@ -151,6 +154,8 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="capture fwd+bwd in a hipGraph (0 = eager launches)")
     ap.add_argument("--dropout", type=int, default=1, help="1 (default) = train() mode with all of the reference's training dropouts (LoRA 0.15 / 0.05, encoder 0.1), as trainer.fit runs the step; 0 = eval() mode, dropout off, like the parity fixtures; 2 / 3 = LoRA / encoder dropouts only (diagnostic)")
     ap.add_argument("--fp8", type=int, default=0, help="1 = BASELINE configs[4] arithmetic: the frozen-W GEMMs of the LLM-sized linears in OCP e4m3 (per-token / per-channel scales); LoRA path, reductions and everything else stay bf16 / fp32")
+    ap.add_argument("--via-trainer", type=int, default=1, help="1 (default) = time the steps inside train_joint.Trainer.fit (fresh host batch every step: index maps + H2D copies + the trainer's captured micro-step graph + all-reduce + clip + AdamW) ; 0 = replay one pre-staged batch (no trainer, no per-step host work)")
+    ap.add_argument("--ragged", type=int, default=0, help="--via-trainer: utterance lengths uniform in [0.6 T, T] (one utterance keeps T)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -168,7 +173,8 @@ def main():
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     jm = build(a.workload, dtype, dev, a.rank_lora, 2 * a.rank_lora, a.dropout)
-    opt = FlatAdamW([p for p in jm.parameters() if p.requires_grad], lr=2e-4, weight_decay=0.01, max_grad_norm=1.0)
+    opt = None if a.via_trainer else FlatAdamW([p for p in jm.parameters() if p.requires_grad], lr=2e-4, weight_decay=0.01,
+                                              max_grad_norm=1.0)
     B, T = a.batch, a.frames
     batch = jm.prepare_batch(synth_batch([T] * B, seed=1234 + rank), dev)
 
@@ -180,7 +186,46 @@ def main():
 
     graph = None
     static_loss = None
-    if a.graph:
+    trainer_stats = None
+    if a.via_trainer:
+        # the product loop: train_joint.Trainer.fit over W + K fresh synthetic batches; the timed region is bracketed
+        # from the trainer's per-step hook (barrier + synchronize on both sides, like the direct mode below)
+        from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+        from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, SyntheticLoader, Trainer
+        if a.warmup < 2:
+            log("[bench] --via-trainer captures a batch shape the second time it is seen: raising --warmup to 2")
+            a.warmup = 2
+        module = JointLightningModule(a.workload, learning_rate=2e-4, min_lr=1e-6, warmup_steps=10, weight_decay=0.01,
+                                      model=jm, numerics=Numerics(dtype=dtype))
+        torch.set_num_threads(min(host_cores(), 16))
+        loader = SyntheticLoader(a.warmup + a.steps, B, T, seed=1234, ragged=bool(a.ragged), rank=rank, cache=True)
+        marks = {}
+
+        def hook(tr):
+            if tr.global_step == a.warmup:
+                dp.barrier()
+                torch.cuda.synchronize()
+                marks["t0"] = time.perf_counter()
+            elif tr.global_step == a.warmup + a.steps:
+                torch.cuda.synchronize()
+                dp.barrier()
+                torch.cuda.synchronize()
+                marks["t1"] = time.perf_counter()
+
+        tr = Trainer(max_epochs=1, accumulate_grad_batches=1, gradient_clip_val=1.0, save_checkpoints=False,
+                     log_every_n_steps=0, train_mode=bool(a.dropout), use_graph=bool(a.graph), on_step_end=hook)
+        log(f"[bench] rank {rank}: Trainer.fit ({'hipGraph micro-step' if a.graph else 'eager'}); warm-up {a.warmup}, timing {a.steps} steps")
+        with contextlib.redirect_stdout(sys.stderr):
+            tr.fit(module, loader)
+        opt = tr.optimizer
+        trainer_stats = dict(tr.graph_stats)
+        el = torch.tensor([marks["t1"] - marks["t0"]], device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(el)
+        final_loss = float(tr.callback_metrics.get("train_loss_epoch", float("nan")))
+        graph = True if (a.graph and trainer_stats["replays"] > 0) else None
+    elif a.graph:
         try:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -210,22 +255,23 @@ def main():
         opt.zero_grad()
         return loss
 
-    log(f"[bench] rank {rank}: model ready ({'hipGraph' if graph is not None else 'eager'}); warm-up {a.warmup}, timing {a.steps} steps")
-    for _ in range(a.warmup):
-        step()
-    dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dp.barrier()
-    torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(el)
-    final_loss = float(loss)
+    if not a.via_trainer:
+        log(f"[bench] rank {rank}: model ready ({'hipGraph' if graph is not None else 'eager'}); warm-up {a.warmup}, timing {a.steps} steps")
+        for _ in range(a.warmup):
+            step()
+        dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dp.barrier()
+        torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(el)
+        final_loss = float(loss)
 
     log(f"[bench] timed region done: {elapsed / a.steps * 1e3:.2f} ms/step")
     roof = None
@@ -274,8 +320,9 @@ def main():
                                    f"CosyVoice-300M dims random-init, {T}-frame x 80-mel clips, "
                                    f"{int(T * 50 * 256 / 22050)} speech tokens, 40 text tokens",
                        "per_gpu_batch": B, "global_batch": world * B, "frames": T, "lora_r": a.rank_lora,
-                       "parallelism": f"dp{world}", "launch": "hipGraph" if graph is not None else "eager", "dropout": bool(a.dropout),
-                       "final_loss": final_loss},
+                       "parallelism": f"dp{world}", "launch": ("Trainer.fit + " if a.via_trainer else "") + ("hipGraph" if graph is not None else "eager"),
+                       "dropout": bool(a.dropout), "final_loss": final_loss,
+                       **({"trainer": trainer_stats, "ragged": bool(a.ragged)} if a.via_trainer else {})},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -219,7 +219,10 @@ def dropout_begin_step() -> None:
     """Advance the device-side dropout seed (a captured op: every hipGraph replay draws new masks) and restart the
     call-site numbering.  JointLLMFlowModel.forward calls it once per training forward."""
     if _DROPOUT["seed"] is None:
-        _DROPOUT["seed"] = torch.full((1,), int(torch.initial_seed()) & 0x7fffffffffff, dtype=torch.int64, device="cuda")
+        # per-rank stream: data-parallel replicas must not draw the same masks for their shards of the global batch
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        seed0 = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * rank) & 0x7fffffffffff
+        _DROPOUT["seed"] = torch.full((1,), seed0, dtype=torch.int64, device="cuda")
     _DROPOUT["seed"].add_(1)
     _DROPOUT["site"] = 0
     _DROPPED.clear()              # dropped inputs a previous forward wrote and no backward consumed

@@ -105,13 +105,13 @@ class JointLLMFlowModel(nn.Module):
             losses['loss'] = losses['flow_loss']
         return losses
 
-    def _prepare_one(self, batch: dict, device) -> dict:
+    def _prepare_one(self, batch: dict, device, lm_pad: int = 1) -> dict:
         out = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
         for k in ('speech_token_len', 'speech_feat_len', 'text_token_len'):
             if k in out:
                 out[k] = out[k].to(torch.int32)
         if self.training_mode in ('joint', 'llm_only') and hasattr(self.llm, 'prepare_batch') and 'text_token' in batch:
-            out.update(self.llm.prepare_batch(batch, device))
+            out.update(self.llm.prepare_batch(batch, device, lm_pad))
         return out
 
     def _split_parts(self, batch: dict, device, nparts: int):
@@ -132,10 +132,10 @@ class JointLLMFlowModel(nn.Module):
             parts.append(part)
         return parts
 
-    def prepare_batch(self, batch: dict, device) -> dict:
+    def prepare_batch(self, batch: dict, device, lm_pad: int = 1) -> dict:
         """Move a collated batch to `device` and attach the host-computed LLM index maps (and the sub-batch split), so
         that the training step itself performs no host<->device transfers (hipGraph-capturable)."""
-        out = self._prepare_one(batch, device)
+        out = self._prepare_one(batch, device, lm_pad)
         n = min(BATCH_SPLIT, batch['speech_token'].shape[0])
         out['_parts'] = self._split_parts(batch, device, n) if n > 1 else [dict(out, _w_llm=1.0, _w_flow=1.0)]
         return out

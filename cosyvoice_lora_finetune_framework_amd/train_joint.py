@@ -108,20 +108,132 @@ class JointLightningModule:
         return self.learning_rate * lr_lambda(step, self.warmup_steps, total_steps, self.min_lr, self.learning_rate)
 
 
-def _batch_denoms(batch) -> Dict[str, float]:
-    d = {"flow": float(batch['speech_feat_len'].sum()) * 80.0}
-    if 'speech_token_len' in batch:
-        d["llm"] = float(batch['speech_token_len'].sum() + batch['speech_token_len'].numel())   # tokens + EOS
+def _batch_denoms(batch, training_mode: str = 'joint') -> Dict[str, float]:
+    """Loss denominators of the local batch; the key set depends on the training mode only (never on the batch), so that
+    every rank all-reduces a vector of the same length.  A missing batch / loss term contributes 0."""
+    d: Dict[str, float] = {}
+    if training_mode in ('joint', 'flow_only'):
+        d["flow"] = float(batch['speech_feat_len'].sum()) * 80.0 if batch is not None else 0.0
+    if training_mode in ('joint', 'llm_only'):
+        ok = batch is not None and 'text_token' in batch
+        d["llm"] = float(batch['speech_token_len'].sum() + batch['speech_token_len'].numel()) if ok else 0.0   # tokens + EOS
     return d
+
+
+TEXT_BUCKET = 16      # graph path: text tokens padded to a multiple of this (masked by text_token_len)
+LM_BUCKET = 32        # graph path: LM sequence length L rounded up to a multiple of this (masked by lm_len)
+# (mel frames T and speech tokens Lt are NOT bucketed: the length regulator interpolates Lt_max -> T_max of the padded
+#  batch, length_regulator.py:44-50, so padding them would change the result)
+
+
+def _record_stream(obj, stream) -> None:
+    """tensors allocated on the copy stream are consumed on `stream`: tell the caching allocator"""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (tuple, list)):
+        for v in obj:
+            _record_stream(v, stream)
+    elif isinstance(obj, dict):
+        for k, v in obj.items():
+            if k != '_parts':
+                _record_stream(v, stream)
+
+
+class _Prefetcher:
+    """Background thread that pulls the next batches from the dataloader and runs their host-side preparation (index
+    maps, padding, host -> device copies on the copy stream) while the main thread is inside the current step: replaying
+    a captured step blocks the host for most of the step (the launch queue is much shorter than the ~2 700-node graph),
+    so preparation done on the main thread would add to the step time instead of hiding under it."""
+
+    def __init__(self, iterable, fn, depth: int = 2):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=depth)
+        self._end = object()
+
+        def work():
+            try:
+                for item in iterable:
+                    self.q.put(fn(item))
+                self.q.put(self._end)
+            except BaseException as e:          # forwarded to the consumer
+                self.q.put(e)
+        self.t = threading.Thread(target=work, daemon=True)
+        self.t.start()
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is self._end:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+
+class _StepGraph:
+    """One captured micro-step -- forward + backward into the flat LoRA-gradient buffer -- for one batch shape.  The
+    batch lives in static device buffers that the trainer refreshes before every replay; the per-rank loss weights (DP)
+    and the injected CFM draws are static inputs too."""
+
+    def __init__(self, module, prepared: dict, draws, w: torch.Tensor, accum: int, flat_g: torch.Tensor):
+        self.batch, self.draws, self.w = prepared, draws, w
+        model, dev = module.model, module.device
+        keys = [k for k in ("llm", "flow") if (k == "llm" and module.training_mode in ('joint', 'llm_only')) or
+                (k == "flow" and module.training_mode in ('joint', 'flow_only'))]
+
+        def run():
+            losses = model(self.batch, dev, self.draws)
+            total = sum(losses[f"{k}_loss"] * self.w[i] for i, k in enumerate(keys))
+            with LoraGradSink():
+                (total / accum).backward()
+            return {k: v.detach() for k, v in losses.items()}
+
+        saved = flat_g.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()                                   # allocator / pack warm-up off the capture
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = run()
+        flat_g.copy_(saved)                          # the warm-up run accumulated once; capture itself executes nothing
+
+    @staticmethod
+    def _copy(dst, src):
+        if torch.is_tensor(dst):
+            dst.copy_(src, non_blocking=True)
+        elif isinstance(dst, (tuple, list)):
+            for a, b in zip(dst, src):
+                _StepGraph._copy(a, b)
+        elif isinstance(dst, dict):
+            for k in dst:
+                if k != '_parts':                    # (_parts aliases the same tensors when BATCH_SPLIT == 1)
+                    _StepGraph._copy(dst[k], src[k])
+
+    def replay(self, prepared: dict, draws, w: torch.Tensor):
+        self._copy(self.batch, prepared)
+        if self.draws is not None:
+            self._copy(self.draws, draws)
+        self.w.copy_(w)
+        self.graph.replay()
+        return self.out
 
 
 class Trainer:
     """The slice of pl.Trainer that train_joint.py:349-368 uses: max_epochs, accumulate_grad_batches,
-    gradient_clip_val, callbacks, checkpoints (save_last + best), resume, step-level LR schedule."""
+    gradient_clip_val, callbacks, checkpoints (save_last + best), resume, step-level LR schedule.
+
+    On a GPU the micro-step (forward + backward) replays a captured hipGraph per batch shape (`use_graph`, default on;
+    CVFT_TRAINER_GRAPH=0 or use_graph=False launches eagerly): a shape is captured the second time it is seen, the
+    batch is copied into the graph's static buffers, all-reduce / clip / AdamW stay outside the graph."""
 
     def __init__(self, max_epochs: int = 100, accumulate_grad_batches: int = 1, gradient_clip_val: float = 1.0,
                  callbacks: Optional[list] = None, default_root_dir: str = OUTPUT_DIR, log_every_n_steps: int = 10,
-                 draws_fn=None, save_checkpoints: bool = True, train_mode: bool = True):
+                 draws_fn=None, save_checkpoints: bool = True, train_mode: bool = True, use_graph: Optional[bool] = None,
+                 max_graphs: int = 8, on_step_end=None):
         self.max_epochs, self.accum, self.clip = max_epochs, max(1, accumulate_grad_batches), gradient_clip_val
         self.train_mode = train_mode       # pl.Trainer.fit puts the module tree in .train() (dropouts active); False keeps the caller's mode
         self.callbacks = callbacks or []
@@ -131,14 +243,30 @@ class Trainer:
         self.global_step = 0
         self.current_epoch = 0
         self.history: List[dict] = []
+        self.best = math.inf
+        if use_graph is None:
+            use_graph = os.environ.get("CVFT_TRAINER_GRAPH", "1") != "0"
+        self.use_graph = bool(use_graph) and torch.cuda.is_available()
+        self.max_graphs = max_graphs
+        self.on_step_end = on_step_end     # optional hook(trainer) after every optimiser step (bench.py --via-trainer)
+        self.graph_stats = {"replays": 0, "eager": 0, "captures": 0}
+        self._copy_stream = None
+        self._graphs: Dict[tuple, _StepGraph] = {}
+        self._seen: Dict[tuple, int] = {}
         self.rank, _, self.world = (0, 0, 1) if not torch.distributed.is_initialized() else \
             (torch.distributed.get_rank(), 0, torch.distributed.get_world_size())
 
     # -- checkpoint (Lightning key layout) ------------------------------------------------
     def _ckpt(self, module, opt):
+        from .hipops import functional as HF
         sd = {f"model.{k}": v.detach().cpu() for k, v in module.model.state_dict().items()}
+        seed = HF._DROPOUT["seed"]
         return {"state_dict": sd, "optimizer": opt.state_dict(), "epoch": self.current_epoch,
-                "global_step": self.global_step, "hyper_parameters": dict(training_mode=module.training_mode,
+                "global_step": self.global_step, "best": self.best,
+                "callbacks": [dict(type=type(c).__name__, **{k: v for k, v in vars(c).items() if isinstance(v, (int, float))})
+                              for c in self.callbacks],
+                "dropout_seed": None if seed is None else int(seed.item()),
+                "hyper_parameters": dict(training_mode=module.training_mode,
                 learning_rate=module.learning_rate, min_lr=module.min_lr, warmup_steps=module.warmup_steps,
                 weight_decay=module.weight_decay)}
 
@@ -149,6 +277,9 @@ class Trainer:
         torch.save(self._ckpt(module, opt), os.path.join(self.root, name))
 
     def load_checkpoint(self, module, opt, path: str):
+        """Resume like Lightning: the stored epoch has finished, training continues with the next one; the best-loss
+        mark, the callbacks' counters and the dropout seed continue too."""
+        from .hipops import functional as HF
         ck = torch.load(path, map_location="cpu")
         own = module.model.state_dict()
         for k, v in ck["state_dict"].items():
@@ -156,7 +287,69 @@ class Trainer:
             if kk in own:
                 own[kk].copy_(v)
         opt.load_state_dict(ck["optimizer"])
-        self.current_epoch, self.global_step = ck.get("epoch", 0), ck.get("global_step", 0)
+        self.current_epoch, self.global_step = ck.get("epoch", -1) + 1, ck.get("global_step", 0)
+        self.best = ck.get("best", math.inf)
+        for c, st in zip(self.callbacks, ck.get("callbacks", [])):
+            if st.get("type") == type(c).__name__:
+                for k, v in st.items():
+                    if k != "type" and hasattr(c, k):
+                        setattr(c, k, v)
+        if ck.get("dropout_seed") is not None and torch.cuda.is_available():
+            HF._DROPOUT["seed"] = torch.full((1,), int(ck["dropout_seed"]), dtype=torch.int64, device="cuda")
+
+    # -- one micro-step ---------------------------------------------------------------------
+    def _prepare(self, module, batch):
+        """Host side of a micro-step (runs on the prefetch thread): bucket the text length, build the LM index maps,
+        copy the batch to the device on the copy stream.  Returns (batch, prepared, ready-event)."""
+        if batch is None or not (self.use_graph and hasattr(module.model, 'prepare_batch')):
+            return batch, None, None
+        dev = module.device
+        if 'text_token' in batch and batch['text_token'].shape[1] % TEXT_BUCKET:
+            tt = batch['text_token']
+            batch = dict(batch, text_token=torch.nn.functional.pad(tt, (0, TEXT_BUCKET - tt.shape[1] % TEXT_BUCKET)))
+        # host -> device copies on a side stream: a pageable-memory copy blocks the host until every earlier operation
+        # of ITS stream has finished -- on the compute stream that would be the whole previous step
+        with torch.cuda.stream(self._copy_stream):
+            prepared = module.model.prepare_batch(batch, dev, LM_BUCKET)
+            ev = torch.cuda.Event()
+            ev.record()
+        return batch, prepared, ev
+
+    def _micro_step(self, module, opt, batch, draws, w, prepared=None, ready=None):
+        """forward + backward of one local batch; returns the dict of detached loss scalars.  `w` = per-term loss weights
+        (device tensor, ones at world == 1)."""
+        dev = module.device
+        keys = [k for k in ("llm", "flow") if (k == "llm" and module.training_mode in ('joint', 'llm_only')) or
+                (k == "flow" and module.training_mode in ('joint', 'flow_only'))]
+        if prepared is not None:
+            main = torch.cuda.current_stream()
+            if draws is not None:
+                with torch.cuda.stream(self._copy_stream):
+                    draws = {k: v.to(dev) for k, v in draws.items()}
+                    ready = torch.cuda.Event()
+                    ready.record()
+            main.wait_event(ready)
+            _record_stream(prepared, main)
+            _record_stream(draws, main)
+            maps = prepared.get('_lm_maps')
+            key = (tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(prepared.items()) if torch.is_tensor(v)),
+                   None if maps is None else maps[3], draws is not None and tuple(sorted(draws)))
+            g = self._graphs.get(key)
+            if g is None:
+                self._seen[key] = self._seen.get(key, 0) + 1
+                if self._seen[key] >= 2 and len(self._graphs) < self.max_graphs:
+                    g = self._graphs[key] = _StepGraph(module, prepared, draws, w.clone(), self.accum, opt.flat_g)
+                    self.graph_stats["captures"] += 1
+            if g is not None:
+                self.graph_stats["replays"] += 1
+                return g.replay(prepared, draws, w)
+            batch = prepared
+        self.graph_stats["eager"] += 1
+        losses = module.model(batch, dev, draws)
+        total = sum(losses[f"{k}_loss"] * w[i] for i, k in enumerate(keys))
+        with LoraGradSink():
+            (total / self.accum).backward()
+        return {k: v.detach() for k, v in losses.items()}
 
     # -- fit ------------------------------------------------------------------------------
     def fit(self, module: JointLightningModule, dataloader, ckpt_path: Optional[str] = None):
@@ -174,38 +367,45 @@ class Trainer:
         if self.rank == 0 and self.save_ckpt:
             os.makedirs(self.root, exist_ok=True)
             logf = open(os.path.join(self.root, f"joint_{module.training_mode}_log.jsonl"), "a")
-        best = math.inf
         keys = ("loss", "llm_loss", "flow_loss", "llm_acc")
+        term_keys = [k for k in ("llm", "flow") if k in _batch_denoms(None, module.training_mode)]   # order of _micro_step
+        ones = torch.ones(len(term_keys), device=dev)
         for epoch in range(self.current_epoch, self.max_epochs):
             self.current_epoch = epoch
+            sampler = getattr(dataloader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):           # DP shards: a new common shuffle every epoch (ShardSampler)
+                sampler.set_epoch(epoch)
             ep_sum = torch.zeros(len(keys), device=dev)
             ep_cnt = 0
             t0 = time.time()
-            for bi, batch in enumerate(dataloader):
-                if batch is None:                      # collate_fn: every sample of this batch failed to decode
-                    continue
-                draws = self.draws_fn(epoch, bi, batch) if self.draws_fn else None
-                losses = module.training_step(batch, bi, draws)
-                w = dp.loss_weights(_batch_denoms(batch), dev) if self.world > 1 else None
-                if w is None:
-                    total = losses['loss']
-                else:
-                    total = sum(losses[f"{k}_loss"] * w[k] for k in ("llm", "flow") if f"{k}_loss" in losses)
-                with LoraGradSink():
-                    (total / self.accum).backward()
-                ep_sum += torch.stack([losses[k].detach().float() if k in losses else ep_sum.new_zeros(()) for k in keys])
-                ep_cnt += 1
+            losses = None
+            if self.use_graph and self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream()
+            for bi, (batch, prepared, ready) in enumerate(_Prefetcher(dataloader, lambda b: self._prepare(module, b))):
+                # A rank whose batch failed to decode (collate_fn -> None) still takes part in every collective of the
+                # step with a zero-weight contribution: no rank ever skips an all-reduce the others enter.
+                w = ones
+                if self.world > 1:
+                    lw = dp.loss_weights(_batch_denoms(batch, module.training_mode), dev)
+                    w = torch.stack([torch.as_tensor(lw[k], dtype=torch.float32, device=dev) for k in term_keys])
+                if batch is not None:
+                    draws = self.draws_fn(epoch, bi, batch) if self.draws_fn else None
+                    losses = self._micro_step(module, opt, batch, draws, w, prepared, ready)
+                    ep_sum += torch.stack([losses[k].float() if k in losses else ep_sum.new_zeros(()) for k in keys])
+                    ep_cnt += 1
                 rec = None
                 if (bi + 1) % self.accum == 0 or bi + 1 == nb:
                     lr = module.lr_at(self.global_step, total_steps)
                     opt.set_lr(lr)
                     gscale = dp.allreduce_flat_grads(opt.flat_g)
                     opt.step(gscale)
-                    if self.log_every and self.global_step % self.log_every == 0:
+                    if self.log_every and self.global_step % self.log_every == 0 and losses is not None:
                         rec = dict(epoch=epoch, step=self.global_step, lr=lr, grad_norm=float(opt.grad_norm(gscale)),
                                    **{k: float(losses[k]) for k in keys if k in losses})
                     opt.zero_grad()
                     self.global_step += 1
+                    if self.on_step_end is not None:
+                        self.on_step_end(self)
                 if rec is not None:
                     self.history.append(rec)
                     if logf:
@@ -214,7 +414,7 @@ class Trainer:
                 if self.should_stop:
                     break
             means = dp.reduce_metrics(torch.cat([ep_sum, ep_sum.new_tensor([float(ep_cnt)])]))
-            means = (means[:-1] / means[-1]).tolist()
+            means = (means[:-1] / means[-1].clamp_min(1.0)).tolist()      # (an epoch with no decodable batch: zeros, not NaN)
             self.callback_metrics = {"train_loss_epoch": means[0], "train_loss": means[0]}
             if module.training_mode in ("joint", "llm_only"):
                 self.callback_metrics.update(llm_loss_epoch=means[1], llm_acc_epoch=means[3])
@@ -224,8 +424,8 @@ class Trainer:
                 print(f"epoch {epoch}: " + "  ".join(f"{k}={v:.4f}" for k, v in self.callback_metrics.items()) +
                       f"  ({time.time() - t0:.1f}s)")
             self.save_checkpoint(module, opt, f"joint_{module.training_mode}_last.ckpt")
-            if means[0] < best:
-                best = means[0]
+            if means[0] < self.best:
+                self.best = means[0]
                 self.save_checkpoint(module, opt, f"joint_{module.training_mode}_best.ckpt")
             for cb_ in self.callbacks:
                 cb_.on_train_epoch_end(self, module)
@@ -237,15 +437,19 @@ class Trainer:
 
 
 class SyntheticLoader:
-    """Deterministic synthetic batches in the reference batch format (synthetic.py); per-rank shard."""
+    """Deterministic synthetic batches in the reference batch format (synthetic.py); per-rank shard.  `cache=True` builds
+    the epoch's batches once (a dataset already decoded in host memory, what DataLoader workers hand over): the CPU
+    random-number generation of a 16 x 500 x 80 batch costs more than a whole GPU step."""
 
-    def __init__(self, n_batches: int, batch_size: int, T: int, seed: int = 1234, ragged: bool = False, rank: int = 0):
+    def __init__(self, n_batches: int, batch_size: int, T: int, seed: int = 1234, ragged: bool = False, rank: int = 0,
+                 cache: bool = False):
         self.n, self.bs, self.T, self.seed, self.ragged, self.rank = n_batches, batch_size, T, seed, ragged, rank
+        self._cache = list(self._gen()) if cache else None
 
     def __len__(self):
         return self.n
 
-    def __iter__(self):
+    def _gen(self):
         from .synthetic import synth_batch
         g = torch.Generator().manual_seed(self.seed + 7919 * self.rank)
         for i in range(self.n):
@@ -254,6 +458,9 @@ class SyntheticLoader:
                 lens = [int(self.T * (0.6 + 0.4 * float(torch.rand(1, generator=g)))) for _ in range(self.bs)]
                 lens[0] = self.T
             yield synth_batch(lens, seed=self.seed + 1000 * self.rank + i)
+
+    def __iter__(self):
+        return iter(self._cache) if self._cache is not None else self._gen()
 
 
 def main():

@@ -279,3 +279,36 @@ def test_slab_plans_are_legal_for_the_rank_kernels():
                 assert -(-Cn // 64) * ns >= HF.SINK_PLAN_BLOCKS
         rpb, ns = HF.LoraGradSink.plan_deferred(M)
         assert rpb % 32 == 0 and ns * rpb >= M > (ns - 1) * rpb
+
+
+def test_shard_sampler_reshuffles_per_epoch_and_ranks_stay_disjoint():
+    """Trainer.fit calls sampler.set_epoch(epoch); every epoch is a new common shuffle, the ranks' shards are
+    disjoint and together cover whole global batches only."""
+    from cosyvoice_lora_finetune_framework_amd.dataset import ShardSampler
+    n, bs, world = 37, 2, 3
+    per_epoch = []
+    for epoch in range(2):
+        shards = []
+        for rank in range(world):
+            s = ShardSampler(n, bs, rank, world, seed=5)
+            s.set_epoch(epoch)
+            shards.append(list(s))
+        flat = [i for sh in shards for i in sh]
+        assert len(set(flat)) == len(flat) == (n // (bs * world)) * bs * world
+        assert all(len(sh) == len(shards[0]) for sh in shards)
+        per_epoch.append(shards)
+    assert per_epoch[0] != per_epoch[1]
+
+
+def test_trainer_denominators_have_a_fixed_key_set():
+    """the all-reduced denominator vector has the same length on every rank whatever the local batch holds
+    (None batch, or no text tokens): a missing term contributes 0."""
+    import torch
+    from cosyvoice_lora_finetune_framework_amd.train_joint import _batch_denoms
+    full = {"speech_feat_len": torch.tensor([10, 7]), "speech_token_len": torch.tensor([5, 4]), "text_token": torch.zeros(2, 3)}
+    no_text = {k: v for k, v in full.items() if k != "text_token"}
+    for mode, keys in (("joint", {"flow", "llm"}), ("flow_only", {"flow"}), ("llm_only", {"llm"})):
+        for b in (full, no_text, None):
+            assert set(_batch_denoms(b, mode)) == keys
+    assert _batch_denoms(full, "joint") == {"flow": 17 * 80.0, "llm": 11.0}
+    assert _batch_denoms(None, "joint") == {"flow": 0.0, "llm": 0.0} and _batch_denoms(no_text, "joint")["llm"] == 0.0

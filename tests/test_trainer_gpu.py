@@ -82,3 +82,37 @@ def test_trainer_runs_on_parquet_shard(tmp_path):
     tr = Trainer(max_epochs=2, accumulate_grad_batches=1, default_root_dir=str(tmp_path), log_every_n_steps=1, save_checkpoints=False)
     tr.fit(mod, loader)
     assert tr.global_step == 4 and all(math.isfinite(h["loss"]) for h in tr.history)
+
+
+def test_trainer_graph_path_equals_eager_path(tiny_meta):
+    """Trainer.fit with the captured micro-step graph (shape seen twice -> capture, then replay from static buffers,
+    text / LM lengths bucketed) reproduces the eager trainer: same losses, lr, grad-norm per step and same final LoRA
+    tensors, on ragged batches with gradient accumulation (reference loop: train_joint.py:349-368)."""
+    from cosyvoice_lora_finetune_framework_amd.llm_flow_model import JointLLMFlowModel
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, Trainer
+    num = Numerics(dtype=torch.float32)
+    shapes = [(24, 5, 10), (24, 7, 10), (17, 5, 8), (24, 5, 10), (17, 6, 8), (24, 9, 10)]     # (T, Lx, Lt): repeats + bucket-mates
+    hist, finals, stats = [], [], []
+    for use_graph in (False, True):
+        flow = build_flow_product(tiny_meta["flow"], DEV, num)
+        llm = build_llm_product(tiny_meta["llm"], DEV, num)
+        jm = JointLLMFlowModel(llm, flow, 'joint', llm_loss_weight=2.0, flow_loss_weight=1.0)
+        module = JointLightningModule('joint', learning_rate=1e-3, min_lr=1e-5, warmup_steps=2, weight_decay=0.01, model=jm,
+                                      numerics=num)
+        batches = [synth_batch([T, max(4, T - 5)], text_lens=[Lx, max(2, Lx - 2)], token_lens=[Lt, max(3, Lt - 3)],
+                               seed=300 + i, text_vocab=100, speech_vocab=50) for i, (T, Lx, Lt) in enumerate(shapes)]
+        tr = Trainer(max_epochs=2, accumulate_grad_batches=2, gradient_clip_val=1.0, train_mode=False, log_every_n_steps=1,
+                     save_checkpoints=False, use_graph=use_graph,
+                     draws_fn=lambda ep, bi, b: cfm_draws(2, b["speech_feat"].shape[1], 1000 * ep + bi))
+        tr.fit(module, batches)
+        hist.append(tr.history)
+        finals.append({k: v.detach().clone() for k, v in jm.named_parameters() if v.requires_grad})
+        stats.append(tr.graph_stats)
+    assert stats[0]["replays"] == 0 and stats[1]["replays"] >= 6 and stats[1]["captures"] >= 2, stats
+    assert len(hist[0]) == len(hist[1]) == 6
+    for a, b in zip(*hist):
+        for k in ("loss", "llm_loss", "flow_loss", "lr", "grad_norm"):
+            assert abs(a[k] - b[k]) <= 1e-5 * abs(a[k]) + 1e-9, (k, a, b)
+    assert max(rel(finals[1][k], finals[0][k]) for k in finals[0]) < 1e-5
