@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AP<T> p) {
 }
 
 // ------------------------------------------------------------------------ backward: dQ
-template <typename T, bool REL, bool DROP = false>
+template <typename T, bool REL, bool DROP = false, bool DPOS = false>
 __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
     typedef AttnCfg<T> A;
     typedef Mma<T> MM;
@@ -207,6 +207,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
     T* Pb = Ds + 4 * 16 * LDK;            // REL: 192 x LDK
     float* Gs = reinterpret_cast<float*>(Pb + (REL ? 192 * LDK : 0));   // REL: 4 x 16 x LDG
     T* Kt = reinterpret_cast<T*>(Gs + (REL ? 4 * 16 * LDG : 0));        // TR: K^T tile [d][kv]
+    // DPOS (gradient w.r.t. p, i.e. LoRA on linear_pos -- lora.py:155-166 default targets): the wave's 16 rows of q + v,
+    // [i][d], padded with zero rows to the MFMA k-step; B operand of  dP[m,:] += sum_i dS_skewed[i,m] (q_i + v)
+    constexpr int QVR = (sizeof(T) == 2) ? 32 : 16;
+    T* QVs = Kt;                          // 4 x QVR x LDK   (TR is retired: Kt has no other user)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q0 = bx * 64, h = blockIdx.y, b = blockIdx.z;
@@ -299,6 +303,16 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
     for (int r = 0; r < 4; ++r) dqacc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     T* Dw = Ds + w * 16 * LDK;
     float* Gw = Gs + w * 16 * LDG;
+    T* QVw = QVs + w * QVR * LDK;
+    if (REL && DPOS) {
+        for (int e = lane; e < QVR * 64; e += 64) {
+            const int row = e >> 6, c = e & 63, i = q0 + 16 * w + row;
+            float v = 0.f;
+            if (row < 16 && i < L) v = to_f32(qg[(size_t)i * p.ld + c]) + p.bv[h * 64 + c];
+            QVw[row * LDK + c] = from_f32<T>(v);
+        }
+        WAVE_LDS_SYNC();
+    }
 
     for (int j0 = 0; j0 < jmax; j0 += 64) {
         if (TR) tile_store_tr<T>(kr, Ks, Kt, LDK, 0, tid);
@@ -378,6 +392,27 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
                 for (int dt = 0; dt < 4; ++dt)
                     MM::mma(dqacc[dt], a, FragLd<T, T>::km(Pb, LDK, dt * 16, (48 - 16 * w) + k0, lane));
             }
+            if (DPOS) {
+                // Gw column c is p row  mband + c;  dP[mband + c, :] += sum_i Gw[i][c] (q_i + v)   (fp32 atomics:
+                // the sum runs over query blocks, heads' batches and key tiles)
+                const int mband = (L - 1) - (q0 + 63) + j0 + (48 - 16 * w);
+#pragma unroll 1
+                for (int mt = 0; mt < KB / 16; ++mt) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k0 = 0; k0 < QVR; k0 += MM::K)
+                            MM::mma(acc, frag_km_f32(Gw, LDG, mt * 16, k0, 16, lane, T()), FragLd<T, T>::km(QVw, LDK, dt * 16, k0, lane));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = mband + mt * 16 + (lane >> 4) * 4 + r;
+                            if (m >= 0 && m <= 2 * L - 2)
+                                atomicAdd(p.dpos + (size_t)m * p.lddpos + h * 64 + dt * 16 + (lane & 15), acc[r]);
+                        }
+                    }
+                }
+            }
         }
         __syncthreads();
     }
@@ -392,8 +427,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AP<T>& p, const int bx) {
 }
 
 // ------------------------------------------------------------------------ backward: dK, dV
-template <typename T, bool REL, bool DROP = false>
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) { attn_bwd_dq_body<T, REL, DROP>(p, blockIdx.x); }
+template <typename T, bool REL, bool DROP = false, bool DPOS = false>
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AP<T> p) { attn_bwd_dq_body<T, REL, DROP, DPOS>(p, blockIdx.x); }
 
 template <typename T, bool REL, bool DROP = false>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AP<T>& p, const int bx) {
@@ -613,10 +648,11 @@ template <typename T> static size_t smem_fwd(bool rel) {
     if (rel) s += (size_t)128 * A::LDK * sizeof(T) + 4 * 16 * 84 * sizeof(float);
     return s;
 }
-template <typename T> static size_t smem_dq(bool rel) {
+template <typename T> static size_t smem_dq(bool rel, bool dpos = false) {
     typedef AttnCfg<T> A;
     size_t s = (size_t)(2 * A::TILE + 4 * 16 * A::LDK) * sizeof(T);
     if (rel) s += (size_t)192 * A::LDK * sizeof(T) + 4 * 16 * 100 * sizeof(float);
+    if (dpos) s += (size_t)4 * (sizeof(T) == 2 ? 32 : 16) * A::LDK * sizeof(T);
     return s;
 }
 template <typename T> static size_t smem_dkv(bool rel) {
@@ -667,6 +703,25 @@ static int launch_bwd(const AP<T>& p_in, float* delta, const T* o, hipStream_t s
     // (one merged launch for both roles was measured slower than two launches: 36.8 vs 36.5 ms/step)
     dim3 grid((p.L + 63) / 64, p.H, p.B);
     if constexpr (REL) {
+        if (p.dpos) {      // gradient w.r.t. p requested: the dQ kernel also scatters dP
+            const size_t s1p = smem_dq<T>(true, true);
+            if (p.drop_p > 0.f) {
+                if (set_smem(attn_bwd_dq_kernel<T, true, true, true>, s1p, "attn_bwd_dq")) return -2;
+                if (set_smem(attn_bwd_dkv_kernel<T, true, true>, s2, "attn_bwd_dkv")) return -2;
+                hipLaunchKernelGGL((attn_bwd_dq_kernel<T, true, true, true>), grid, dim3(256), s1p, st, p);
+                CVFT_LAUNCH_CHECK("attn_bwd_dq");
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true, true>), grid, dim3(256), s2, st, p);
+                CVFT_LAUNCH_CHECK("attn_bwd_dkv");
+                return 0;
+            }
+            if (set_smem(attn_bwd_dq_kernel<T, true, false, true>, s1p, "attn_bwd_dq")) return -2;
+            if (set_smem(attn_bwd_dkv_kernel<T, true, false>, s2, "attn_bwd_dkv")) return -2;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, true, false, true>), grid, dim3(256), s1p, st, p);
+            CVFT_LAUNCH_CHECK("attn_bwd_dq");
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true, false>), grid, dim3(256), s2, st, p);
+            CVFT_LAUNCH_CHECK("attn_bwd_dkv");
+            return 0;
+        }
         if (p.drop_p > 0.f) {
             if (set_smem(attn_bwd_dq_kernel<T, true, true>, s1, "attn_bwd_dq")) return -2;
             if (set_smem(attn_bwd_dkv_kernel<T, true, true>, s2, "attn_bwd_dkv")) return -2;
@@ -704,7 +759,7 @@ static AP<T> make_ap(int B, int H, int L, const void* q, const void* k, const vo
     a.B = B; a.H = H; a.L = L; a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.ld = ld;
     a.p = (const T*)pp; a.ldp = ldp; a.bu = bu; a.bv = bv; a.len = len; a.causal = causal; a.scale = scale;
     a.o = nullptr; a.ldo = 0; a.lse = nullptr; a.d_o = nullptr; a.delta = nullptr; a.dq = a.dk = a.dv = nullptr; a.ldg = 0;
-    a.drop_p = 0.f; a.seed = nullptr; a.site = 0; a.iso = 0;
+    a.drop_p = 0.f; a.seed = nullptr; a.site = 0; a.iso = 0; a.dpos = nullptr; a.lddpos = 0;
     return a;
 }
 
@@ -782,20 +837,21 @@ extern "C" int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* 
                    "cvft_attn_relpos_bwd: bad p");
     CVFT_CHECK_ARG(o && d_o && lse && delta && dq && dk && dv && ldg >= H * 64, "cvft_attn_relpos_bwd: bad args");
     CVFT_CHECK_ARG((((uintptr_t)d_o) & 15) == 0, "cvft_attn_relpos_bwd: dO must be 16-byte aligned");
-    CVFT_CHECK_ARG(dp == nullptr, "cvft_attn_relpos_bwd: gradient w.r.t. p (LoRA on linear_pos) is not implemented");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CVFT_F32) {
         AP<float> a = make_ap<float>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
         a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const float*)d_o; a.delta = delta;
         a.dq = (float*)dq; a.dk = (float*)dk; a.dv = (float*)dv; a.ldg = ldg;
         a.drop_p = drop_p; a.seed = (const long long*)drop_seed; a.site = drop_site;
+        a.dpos = dp; a.lddpos = H * 64;
         return launch_bwd<float, true>(a, delta, (const float*)o, st);
     }
     AP<bf16_t> a = make_ap<bf16_t>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
     a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const bf16_t*)d_o; a.delta = delta;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg;
     a.drop_p = drop_p; a.seed = (const long long*)drop_seed; a.site = drop_site;
-    if (!attn_v1() && al8(dq, dk, dv, o) && ldg % 4 == 0) {
+    a.dpos = dp; a.lddpos = H * 64;
+    if (!dp && !attn_v1() && al8(dq, dk, dv, o) && ldg % 4 == 0) {      // (dP is served by the generic kernels)
         a.o = (bf16_t*)o;
         return cvft_attn32_bwd(a, 1, st);
     }

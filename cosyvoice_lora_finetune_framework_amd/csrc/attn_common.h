@@ -31,6 +31,7 @@ struct AP {
     // attention-probability dropout (attention.py:118 `self.dropout(attn)`; DROP instantiations only)
     float drop_p; const long long* seed; unsigned site;
     int iso;      // REL = false: prompt-isolation split (modules.py:844-879); 0 = off
+    float* dpos; int lddpos;      // REL backward: fp32 gradient w.r.t. p [2L-1, lddpos] (accumulated with atomics), or null
 };
 
 // keep-scale of score (b, h, i, j): 1/(1-p) or 0.  Counter-based (SplitMix64 finaliser, same as cvft_dropout_add), so
@@ -145,6 +146,20 @@ template <> struct FragLd<bf16_t, float> {
         return f;
     }
 };
+// A[row = rc0 + (lane&15)][k] from an fp32 image stored [k][rc]; k >= klim reads as 0 (short reduction, padded k-step)
+__device__ __forceinline__ bf16x8 frag_km_f32(const float* base, int ld, int rc0, int k0, int klim, int lane, bf16_t) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + 8 * (lane >> 4) + j;
+        f[j] = (k < klim) ? (bf16_t)base[k * ld + rc0 + (lane & 15)] : (bf16_t)0.f;
+    }
+    return f;
+}
+__device__ __forceinline__ float frag_km_f32(const float* base, int ld, int rc0, int k0, int klim, int lane, float) {
+    const int k = k0 + (lane >> 4);
+    return (k < klim) ? base[k * ld + rc0 + (lane & 15)] : 0.f;
+}
 template <> struct FragLd<float, float> {
     static __device__ __forceinline__ float kc(const float* base, int ld, int rc0, int k0, int lane) {
         return base[(rc0 + (lane & 15)) * ld + k0 + (lane >> 4)];

@@ -1327,18 +1327,20 @@ class AttnRelPosFn(torch.autograd.Function):
     def backward(ctx, do):
         q, k, v, p, bu, bv, o, lse = ctx.saved_tensors
         B, H, L, length, causal, scale = ctx.args
-        if ctx.needs_input_grad[3]:
-            raise cb.CvftError("gradient w.r.t. the projected positional encoding (LoRA on linear_pos) is not implemented")
         do = _c(do)
+        dpos = None
+        if ctx.needs_input_grad[3]:       # LoRA on linear_pos (reference lora.py:155-166 default targets): fp32 accumulator
+            dpos = torch.zeros((2 * L - 1, H * 64), dtype=torch.float32, device=q.device)
         dqkv = torch.empty((B * L, 3 * H * 64), dtype=q.dtype, device=q.device)
         dq, dk, dv = dqkv[:, :H * 64], dqkv[:, H * 64:2 * H * 64], dqkv[:, 2 * H * 64:]
         delta = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
         check(lib().cvft_attn_relpos_bwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
                                          ptr(bu), ptr(bv), ptr(length), int(causal), scale, ptr(o), ptr(do), o.stride(0),
-                                         ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), None,
+                                         ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), ptr(dpos),
                                          ctx.drop[0], ptr(ctx.drop[1]), ctx.drop[2], stream()),
               "cvft_attn_relpos_bwd")
-        return dq, dk, dv, None, None, None, None, None, None, None, None, None, None, None
+        dp_out = None if dpos is None else dpos.to(p.dtype)
+        return dq, dk, dv, dp_out, None, None, None, None, None, None, None, None, None, None
 
 
 def attn_relpos(q, k, v, p, bias_u, bias_v, B: int, H: int, L: int, length, causal: bool, scale: float, dropout_p: float = 0.0):

@@ -432,6 +432,7 @@ class EspnetRelPositionalEncoding(nn.Module):
             if len(self._cache) > 64:
                 self._cache.clear()
             self._cache[key] = pe.to(device=device, dtype=dtype).contiguous()
+            self._cache[key]._cvft_const = True      # (a frozen linear_pos caches its projection of this table)
         return self._cache[key]
 
 
@@ -470,7 +471,14 @@ class RelPositionMultiHeadedAttention(nn.Module):
 
     def forward(self, y, residual, pos_emb, B, L, length, causal, out_dropout: float = 0.0):
         q, k, v = hip_qkv(self.linear_q, self.linear_k, self.linear_v, y)
-        p = hip_linear(self.linear_pos, pos_emb)
+        if isinstance(self.linear_pos, nn.Linear) and not self.linear_pos.weight.requires_grad and \
+                getattr(pos_emb, "_cvft_const", False):
+            # frozen projection of a constant table (eval mode: no positional dropout): once per (table, dtype), not once
+            # per layer and step
+            p = _cached(self, "p", self.linear_pos.weight, (pos_emb.dtype, pos_emb.data_ptr(), tuple(pos_emb.shape)),
+                        lambda: hip_linear(self.linear_pos, pos_emb).detach())
+        else:
+            p = hip_linear(self.linear_pos, pos_emb)
         o = HF.attn_relpos(q, k, v, p, _f32(self.pos_bias_u), _f32(self.pos_bias_v), B, self.h, L, length, causal,
                            1.0 / math.sqrt(self.d_k), dropout_p=self.dropout_rate if self.training else 0.0)
         if out_dropout > 0:       # x = residual + dropout(linear_out(.))  (encoder_layer.py:95 / 205)

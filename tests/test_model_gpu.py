@@ -70,6 +70,37 @@ def test_llm_tiny_loss_and_grads(tiny_meta):
     assert worst < GRAD_TOL, worst
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_llm_default_lora_targets_train_linear_pos(dtype):
+    """apply_lora_to_model(model) with the DEFAULT target list (reference lora.py:155-166) wraps linear_pos; the rel-pos
+    attention backward then returns the gradient w.r.t. the projected positional encoding (cvft_attn_relpos_bwd dp).
+    fp32: loss 1e-4 and all LoRA gradients (linear_pos included) vs the reference run; bf16: aggregate closeness."""
+    from conftest import load_json
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    g = load_npz("llm_tiny_pos.npz")
+    lm = load_json("tiny_pos_meta.json")["llm"]
+    num = Numerics(dtype=dtype)
+    m = build_llm_product(lm, DEV, num)
+    assert type(m.llm.encoders[0].self_attn.linear_pos).__name__ == "LoRALinear"
+    assert [k for k, _ in m.state_dict().items()] == [k for k, _ in lm["spec"]]      # same key set / order as the reference
+    out = m.forward_no_prompt(_batch(g), DEV)
+    ref = float(g["loss"])
+    out["loss"].backward()
+    grads = lora_grads(m)
+    refg = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith("grad/")}
+    assert set(grads) == set(refg)
+    if dtype == torch.float32:
+        assert abs(float(out["loss"]) - ref) / ref < LOSS_TOL, (float(out["loss"]), ref)
+        worst = max(rel(grads[k], refg[k]) for k in refg)
+        assert worst < GRAD_TOL, worst
+        assert max(rel(grads[k], refg[k]) for k in refg if "linear_pos" in k) < GRAD_TOL
+    else:
+        assert abs(float(out["loss"]) - ref) / ref < 2e-2
+        num_ = sum(float((grads[k].double().cpu() - refg[k].double()).norm() ** 2) for k in refg) ** 0.5
+        den_ = sum(float(refg[k].double().norm() ** 2) for k in refg) ** 0.5
+        assert num_ / den_ < 0.1, num_ / den_
+
+
 def test_joint_model_contract(tiny_meta):
     """JointLLMFlowModel.forward dict contract + loss weighting (llm_flow_model.py:77-107)."""
     from cosyvoice_lora_finetune_framework_amd.llm_flow_model import JointLLMFlowModel

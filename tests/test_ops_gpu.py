@@ -262,7 +262,8 @@ def test_attn_relpos(dtype, causal, L, lens):
     gy = q(rnd(B, L, d, seed=5), dtype)
     qr = qkv.double().requires_grad_(True)
     qq, kk, vv = (t.reshape(B, L, H, 64) for t in qr.split(d, dim=-1))
-    pp = p.double().view(1, -1, H, 64).transpose(1, 2)
+    pr = p.double().requires_grad_(True)
+    pp = pr.view(1, -1, H, 64).transpose(1, 2)
     ac = (qq + bu.double()).transpose(1, 2) @ kk.transpose(1, 2).transpose(-1, -2)
     bd = R.rel_shift((qq + bv.double()).transpose(1, 2) @ pp.transpose(-1, -2))
     mask = _masks(lens, L).bool().unsqueeze(1)
@@ -279,6 +280,14 @@ def test_attn_relpos(dtype, causal, L, lens):
     o.backward(gy.reshape(B * L, -1).to(DEV, dtype))
     assert rel(o.reshape(B, L, -1), orf) < TOL[dtype]
     assert rel(qd.grad.reshape(B, L, -1), qr.grad) < TOL[dtype] * 3
+    # gradient w.r.t. the projected positional encoding (LoRA on linear_pos, lora.py:155-166): same q/k/v gradients, plus dP
+    qd2 = qkv.reshape(B * L, -1).to(DEV, dtype).requires_grad_(True)
+    pd = p.to(DEV, dtype).requires_grad_(True)
+    o2 = HF.attn_relpos(qd2[:, :d], qd2[:, d:2 * d], qd2[:, 2 * d:], pd, bu.to(DEV), bv.to(DEV), B, H, L,
+                        torch.tensor(lens, dtype=torch.int32, device=DEV), causal, 0.125)
+    o2.backward(gy.reshape(B * L, -1).to(DEV, dtype))
+    assert rel(qd2.grad.reshape(B, L, -1), qr.grad) < TOL[dtype] * 3
+    assert rel(pd.grad, pr.grad) < TOL[dtype] * 3
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

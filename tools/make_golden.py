@@ -209,6 +209,28 @@ def gen_tiny():
         json.dump(meta, f, indent=0)
 
 
+def gen_pos():
+    """LLM tiny with the reference's DEFAULT target list (lora.py:155-166: target_modules=None), which wraps linear_pos:
+    the gradient then also flows into the projected positional encoding (rel-pos attention's p operand)."""
+    batch = synth_batch([24, 17], text_lens=[7, 5], token_lens=[13, 9], seed=11, text_vocab=100, speech_vocab=50)
+    torch.manual_seed(0)
+    llm = build_ref_llm(TINY_LLM)
+    lspec, lstats = wrap_and_fill(llm, r=4, alpha=8, targets=None, seed=5)
+    assert any('linear_pos.lora_A' in k for k, _ in lspec)
+    jm = ref_joint.JointLLMFlowModel(llm, nn.Identity(), 'llm_only')
+    out = jm(batch, torch.device('cpu'))
+    out['loss'].backward()
+    lg = lora_grads(llm)
+    print(f"tiny llm, default targets: loss={out['loss'].item():.8f} acc={out['llm_acc'].item():.6f} stats={lstats}")
+    arr = dict(loss=out['loss'].detach(), acc=out['llm_acc'], **{f"in_{k}": v for k, v in batch.items()})
+    for k, g in lg.items():
+        arr[f"grad/{k}"] = g
+    npz_save(os.path.join(GOLD, "llm_tiny_pos.npz"), **arr)
+    with open(os.path.join(GOLD, "tiny_pos_meta.json"), "w") as f:
+        json.dump(dict(llm=dict(build=TINY_LLM, lora=dict(r=4, alpha=8, targets=None), weight_seed=5,
+                                spec=[[k, list(s)] for k, s in lspec], stats=lstats)), f, indent=0)
+
+
 def gen_sampler():
     """CFM sampler fixture: reference ConditionalCFM.forward on the tiny vendored flow model."""
     torch.manual_seed(0)
@@ -538,6 +560,8 @@ if __name__ == "__main__":
         gen_ops()
     if a.only in ("all", "tiny"):
         gen_tiny()
+    if a.only in ("all", "pos"):
+        gen_pos()
     if a.only in ("all", "sampler"):
         gen_sampler()
     if a.only in ("all", "data"):
