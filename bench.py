@@ -90,7 +90,8 @@ def build(workload, dtype, device, r, alpha, dropout=False):
 
 
 def cpu_baseline(jm, workload, T, seconds_budget=30.0):
-    """Time the CPU oracle (port of the reference math) on a bounded sample: B=1 utterances/step."""
+    """Time the CPU oracle (port of the reference math) on a bounded sample: 4 utterances per step (the GPU's batch of
+    16 would take ~15 s per CPU step: over the ~30 s budget; utterances/s is flat in B on the CPU between 1 and 4)."""
     from oracle import ref_math as R
     from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
     cores = host_cores()
@@ -103,7 +104,7 @@ def cpu_baseline(jm, workload, T, seconds_budget=30.0):
             if 'lora_' in k:
                 v.requires_grad_(True)
     cfg = R.OracleConfig(flow_lora_scale=2.0, llm_lora_scale=2.0)
-    B = 1
+    B = 4
     batch = synth_batch([T] * B, seed=99)
     draws = cfm_draws(B, T, 5)
 
@@ -116,7 +117,7 @@ def cpu_baseline(jm, workload, T, seconds_budget=30.0):
     one()
     first = time.time() - t0
     log(f"[bench] cpu_baseline: warm-up step took {first:.1f} s")
-    n = max(1, min(3, int((seconds_budget - first) / max(first, 1e-3))))
+    n = max(1, min(5, int((seconds_budget - first) / max(first, 1e-3))))
     t0 = time.time()
     for _ in range(n):
         one()

@@ -423,6 +423,39 @@ __global__ void __launch_bounds__(256) sumsq_kernel(size_t n, const float* __res
     s = block_sum(s, sm);
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
+// Order-fixed form: per-block partials written to a caller buffer, then ONE block adds them in index order.
+// The gradient norm -- hence the clip coefficient and the AdamW update -- is bitwise reproducible run to run and
+// identical on every data-parallel replica (the atomic form above depends on the order blocks finish in).
+__global__ void __launch_bounds__(256) sumsq_part_kernel(size_t n, const float* __restrict__ g, float* __restrict__ part) {
+    __shared__ float sm[16];
+    float s = 0.f;
+    EW_LOOP(i, n) s += g[i] * g[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) sumsq_final_kernel(int nparts, const float* __restrict__ part, float* __restrict__ out) {
+    __shared__ float sm[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];       // fixed assignment, fixed order
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+extern "C" int cvft_sumsq_ordered(int64_t n, const float* g, float* partials, float* out, void* stream) {
+    CVFT_CHECK_ARG(n >= 0 && g && out && partials, "cvft_sumsq_ordered: bad args");
+    unsigned grid = n > 0 ? ew_grid((size_t)n) : 1;
+    if (grid > CVFT_SUMSQ_PARTS) grid = CVFT_SUMSQ_PARTS;
+    hipLaunchKernelGGL(sumsq_part_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (size_t)n, g, partials);
+    CVFT_LAUNCH_CHECK("cvft_sumsq_ordered");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (int)grid, partials, out);
+    CVFT_LAUNCH_CHECK("cvft_sumsq_ordered");
+    return 0;
+}
+
 extern "C" int cvft_sumsq(int64_t n, const float* g, float* out, void* stream) {
     CVFT_CHECK_ARG(n >= 0 && g && out, "cvft_sumsq: bad args");
     if (n == 0) return 0;

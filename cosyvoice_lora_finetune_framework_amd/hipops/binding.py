@@ -106,6 +106,7 @@ SIGNATURES = {
     "cvft_dwconv1d_fwd": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "cvft_dwconv1d_bwd": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     "cvft_sumsq": [_i64, _p, _p, _p],
+    "cvft_sumsq_ordered": [_i64, _p, _p, _p, _p],
     "cvft_adamw_flat": [_i64, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _f, _f, _p],
     "cvft_cast_f32_to_bf16": [_i64, _p, _p, _p],
 }

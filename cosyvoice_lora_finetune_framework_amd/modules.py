@@ -15,6 +15,7 @@ matcha/models/components/{decoder,transformer}.py (vendored); cosyvoice/transfor
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
@@ -471,13 +472,18 @@ class RelPositionMultiHeadedAttention(nn.Module):
 
     def forward(self, y, residual, pos_emb, B, L, length, causal, out_dropout: float = 0.0):
         q, k, v = hip_qkv(self.linear_q, self.linear_k, self.linear_v, y)
-        if isinstance(self.linear_pos, nn.Linear) and not self.linear_pos.weight.requires_grad and \
-                getattr(pos_emb, "_cvft_const", False):
-            # frozen projection of a constant table (eval mode: no positional dropout): once per (table, dtype), not once
-            # per layer and step
-            p = _cached(self, "p", self.linear_pos.weight, (pos_emb.dtype, pos_emb.data_ptr(), tuple(pos_emb.shape)),
-                        lambda: hip_linear(self.linear_pos, pos_emb).detach())
-        else:
+        p = None
+        w = self.linear_pos.weight if isinstance(self.linear_pos, nn.Linear) else None
+        if w is not None and not w.requires_grad and getattr(pos_emb, "_cvft_const", False):
+            # frozen projection of a constant table (eval mode: no positional dropout): once per table, not once per layer
+            # and step.  Entries are never evicted -- a captured hipGraph may hold the address of one -- so the cache
+            # simply stops growing at 16 tables.
+            cache = self.__dict__.setdefault("_cvft_pcache", {})
+            key = (pos_emb.data_ptr(), tuple(pos_emb.shape), pos_emb.dtype, w._version, w.data_ptr())
+            p = cache.get(key)
+            if p is None and len(cache) < 16:
+                p = cache[key] = hip_linear(self.linear_pos, pos_emb).detach()
+        if p is None:
             p = hip_linear(self.linear_pos, pos_emb)
         o = HF.attn_relpos(q, k, v, p, _f32(self.pos_bias_u), _f32(self.pos_bias_v), B, self.h, L, length, causal,
                            1.0 / math.sqrt(self.d_k), dropout_p=self.dropout_rate if self.training else 0.0)

@@ -71,6 +71,7 @@ class FlatAdamW:
         self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gnorm_part = torch.zeros(1024, dtype=torch.float32, device=dev)      # CVFT_SUMSQ_PARTS
         self.step_count = 0
         self.refresh_shadows()
 
@@ -128,12 +129,12 @@ class FlatAdamW:
         return self.gnorm_sq.sqrt() * abs(grad_scale)
 
     def step(self, grad_scale: float = 1.0):
-        """clip_grad_norm_(max_grad_norm) on grad_scale*g, then AdamW -- two kernels, no host sync."""
+        """clip_grad_norm_(max_grad_norm) on grad_scale*g, then AdamW -- three kernels, no host sync."""
         self.step_count += 1
         self.step_dev.add_(1.0)
-        self.gnorm_sq.zero_()
         L = cb.lib()
-        cb.check(L.cvft_sumsq(self.n, cb.ptr(self.flat_g), cb.ptr(self.gnorm_sq), cb.stream()), "cvft_sumsq")
+        cb.check(L.cvft_sumsq_ordered(self.n, cb.ptr(self.flat_g), cb.ptr(self.gnorm_part), cb.ptr(self.gnorm_sq), cb.stream()),
+                 "cvft_sumsq_ordered")       # fixed summation order: the clip is bitwise equal on every DP replica
         cb.check(L.cvft_adamw_flat(self.n, cb.ptr(self.flat_p), cb.ptr(self.flat_g), cb.ptr(self.m), cb.ptr(self.v),
                                    cb.ptr(self.lr_dev), self.betas[0], self.betas[1], self.eps, self.wd,
                                    cb.ptr(self.step_dev), cb.ptr(self.gnorm_sq), float(self.max_grad_norm or 0.0),

@@ -296,6 +296,10 @@ int cvft_dwconv1d_bwd(int dtype, int B, int T, int C, int Kw, int pad_left, cons
 /* flat-buffer optimiser pieces (train_joint.py:198-226, 349-360): */
 /* out[0] += sum(g^2) */
 int cvft_sumsq(int64_t n, const float* g, float* out, void* stream);
+/* out[0] = sum(g^2), summed in a fixed order (bitwise reproducible; what torch.nn.utils.clip_grad_norm_ feeds the
+ * clip at train_joint.py:349-360 needs to be identical on every data-parallel replica); partials: CVFT_SUMSQ_PARTS floats */
+#define CVFT_SUMSQ_PARTS 1024
+int cvft_sumsq_ordered(int64_t n, const float* g, float* partials, float* out, void* stream);
 /* AdamW on a flat fp32 buffer; clip coefficient = min(1, max_norm/(sqrt(gnorm_sq[0])*inv_scale + 1e-6)),
  * lr read from device lr[0]; step count from device step[0] (float, already incremented). */
 int cvft_adamw_flat(int64_t n, float* p, const float* g, float* m, float* v, const float* lr, float beta1, float beta2,

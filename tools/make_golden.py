@@ -439,6 +439,49 @@ def gen_full():
         json.dump(dict(flow=[[k, list(s)] for k, s in fspec], llm=[[k, list(s)] for k, s in lspec]), f)
 
 
+def pick_grad_tensors(grads, n=6):
+    """a handful of whole LoRA gradient tensors, spread over the model (first / middle / last adapters, A and B)"""
+    keys = sorted(grads)
+    idx = sorted({0, 1, len(keys) // 2, len(keys) // 2 + 1, len(keys) - 2, len(keys) - 1})[:n]
+    return {keys[i]: grads[keys[i]] for i in idx}
+
+
+def gen_full_grads():
+    """Whole LoRA gradient tensors of a few adapters at full CosyVoice-300M size, for the bf16 BACKWARD checks (the
+    scalar fixtures of gen_full pin losses and gradient norms only), and the BASELINE configs[4] shape (T = 1000,
+    r = 64, B = 2): losses, accuracy, gradient norms and the same picked tensors."""
+    arrs, meta = {}, {}
+    for tag, T, r, feat_lens, text_lens in (("t500_r16", 500, 16, [500, 437], [40, 33]),
+                                            ("t1000_r64", 1000, 64, [1000, 871], [40, 33])):
+        batch = synth_batch(feat_lens, text_lens=text_lens, seed=1234)
+        torch.manual_seed(0)
+        flow = build_ref_flow('vendored')
+        fspec, fstats = wrap_and_fill(flow, r=r, alpha=2 * r, targets=FLOW_TARGETS, seed=1)
+        loss, grads = run_flow(flow, batch, seed=4321)
+        meta[f"flow/{tag}"] = dict(loss=float(loss), draw_seed=4321, batch_seed=1234, feat_lens=feat_lens, text_lens=text_lens,
+                                   r=r, alpha=2 * r, weight_seed=1, grads=grad_summary(grads), stats=fstats)
+        for k, g in pick_grad_tensors(grads).items():
+            arrs[f"flow/{tag}/{k}"] = g
+        print(tag, "flow loss", float(loss), meta[f"flow/{tag}"]['grads']['total_norm'])
+        del flow, grads
+        torch.manual_seed(0)
+        llm = build_ref_llm(FULL_LLM)
+        lspec, lstats = wrap_and_fill(llm, r=r, alpha=2 * r, targets=LLM_TARGETS, seed=2)
+        jm = ref_joint.JointLLMFlowModel(llm, nn.Identity(), 'llm_only')
+        out = jm(batch, torch.device('cpu'))
+        out['loss'].backward()
+        grads = lora_grads(llm)
+        meta[f"llm/{tag}"] = dict(loss=float(out['loss']), acc=float(out['llm_acc']), batch_seed=1234, feat_lens=feat_lens,
+                                  text_lens=text_lens, r=r, alpha=2 * r, weight_seed=2, grads=grad_summary(grads), stats=lstats)
+        for k, g in pick_grad_tensors(grads).items():
+            arrs[f"llm/{tag}/{k}"] = g
+        print(tag, "llm loss", float(out['loss']), float(out['llm_acc']), meta[f"llm/{tag}"]['grads']['total_norm'])
+        del llm, jm, grads
+    npz_save(os.path.join(GOLD, "full_grads.npz"), **arrs)
+    with open(os.path.join(GOLD, "full_grads_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def gen_ops():
     """Op-level known answers from the reference's own classes."""
     g = torch.Generator().manual_seed(5)
@@ -562,6 +605,8 @@ if __name__ == "__main__":
         gen_tiny()
     if a.only in ("all", "pos"):
         gen_pos()
+    if a.only in ("all", "fullgrads"):
+        gen_full_grads()
     if a.only in ("all", "sampler"):
         gen_sampler()
     if a.only in ("all", "data"):
