@@ -142,6 +142,29 @@ def pmc_traffic(kernel: str):
     return None, None
 
 
+def pmc_mfma_busy(kernel: str):
+    """MFMA-busy fraction of `kernel` (share of the chip's matrix-pipe cycles a launch keeps busy) from the committed
+    counter run of the same step: profiles/*counters.json, written by tools/counters.py (SQ_VALU_MFMA_BUSY_CYCLES /
+    (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
+    import glob
+    import re
+    m = re.match(r"gemm_glds_kernel<bf16,(\d+),(\d+),(\d+),(\d+),ns(\d+)", kernel)
+    if not m:
+        return None, None
+    bm, bn, wm, wn, ns = m.groups()
+    key = f"gemm_glds<{bm}ELi{bn}ELi{wm}ELi{wn}ELi0ELi{ns}E"
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*counters.json")), reverse=True):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        hit = [v for k, v in ks.items() if k.startswith(key)]
+        if hit:
+            n = sum(v["launches_sampled"] for v in hit)
+            return sum(v["mfma_busy"] * v["launches_sampled"] for v in hit) / n, os.path.join("profiles", os.path.basename(f))
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,8 +319,10 @@ def main():
             peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = g["flop"] / (g["ms"] * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic(name)
+            busy, busy_src = pmc_mfma_busy(name)
             roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                     "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                    "mfma_busy": busy, "mfma_busy_source": busy_src,
                     "alg_bytes_per_launch": g["bytes"] / g["n"], "launches_per_step": g["n"],
                     "avg_launch_us": g["ms"] * 1e3 / g["n"], "alg_gflop_per_launch": g["flop"] / g["n"] / 1e9,
                     "all_gemm_kernels": {k: {"ms": v["ms"], "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12, "n": v["n"]}
