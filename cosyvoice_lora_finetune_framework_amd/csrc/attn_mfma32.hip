@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(256) attn32_fwd_kernel(AP<bf16_t> p) {
 // backward dQ: block = 4 waves x 32 queries, 64 keys per step
 // =====================================================================================================================
 template <bool REL, bool DROP, int NBUF>
-__global__ void __launch_bounds__(256) attn32_bwd_dq_kernel(AP<bf16_t> p) {
+DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256) attn32_bwd_dq_kernel(AP<bf16_t> p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     const int L = p.L, nblk = (L + 127) >> 7;
     int bh, blk;
-    block_map(blockIdx.x, nblk, p.B * p.H, bh, blk);
+    block_map(bid, nblk, p.B * p.H, bh, blk);
     if (REL && p.causal) blk = nblk - 1 - blk;      // longest blocks first
     const int i0 = blk * 128, hh = bh % p.H, b = bh / p.H;
     const int iw = i0 + 32 * w, i = iw + l31;
@@ -704,11 +704,16 @@ __global__ void __launch_bounds__(256) attn32_bwd_dq_kernel(AP<bf16_t> p) {
     }
 }
 
-// =====================================================================================================================
-// backward dK, dV: block = 4 waves x 32 keys, 64 queries per step
-// =====================================================================================================================
 template <bool REL, bool DROP, int NBUF>
-__global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p) {
+__global__ void __launch_bounds__(256) attn32_bwd_dq_kernel(AP<bf16_t> p) { attn32_bwd_dq_body<REL, DROP, NBUF>(p, blockIdx.x); }
+
+// =====================================================================================================================
+// backward dK, dV: block = 4 waves x 32 keys, 64 queries per step.  OWN_DELTA: delta = rowsum(dO * O) of each staged
+// query tile is formed here from the prefetch registers instead of read from the dQ kernel's output -- the two backward
+// roles then have no dependency and can share one launch (attn32_bwd_fused_kernel).
+// =====================================================================================================================
+template <bool REL, bool DROP, int NBUF, bool OWN_DELTA>
+DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
@@ -720,7 +725,7 @@ __global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     const int L = p.L, nblk = (L + 127) >> 7;
     int bh, blk;
-    block_map(blockIdx.x, nblk, p.B * p.H, bh, blk);      // (causal: key block 0 is the longest and already first)
+    block_map(bid, nblk, p.B * p.H, bh, blk);      // (causal: key block 0 is the longest and already first)
     const int j0b = blk * 128, hh = bh % p.H, b = bh / p.H;
     const int jw = j0b + 32 * w, j = jw + l31;
     const size_t rowbase = (size_t)b * L;
@@ -774,15 +779,17 @@ __global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p) {
             ptile(pb_, mlo + 32);
         }
 
-        Tile2 qr, dor;
+        Tile2 qr, dor, orr;
         float lse_n = 0.f, del_n = 0.f;
+        const bf16_t* og = p.o + rowbase * p.ldo + hh * 64;
 #define A32_KV_PREFETCH(I0_)                                                               \
     do {                                                                                   \
         tload(qr, qg, p.ld, (I0_), L, tid);                                                \
         tload(dor, dog, p.ldo, (I0_), L, tid);                                             \
         const int ii_ = min((I0_) + (tid & 63), L - 1);      /* every thread loads */      \
         lse_n = p.lse[((size_t)b * p.H + hh) * L + ii_];                                   \
-        del_n = p.delta[((size_t)b * p.H + hh) * L + ii_];                                 \
+        if (OWN_DELTA) tload(orr, og, p.ldo, (I0_), L, tid);                               \
+        else del_n = p.delta[((size_t)b * p.H + hh) * L + ii_];                            \
     } while (0)
 #define A32_KV_PUBLISH(BUF_, I0_)                                                          \
     do {                                                                                   \
@@ -791,7 +798,19 @@ __global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p) {
         if (tid < 64) {                                                                    \
             const bool ok_ = (I0_) + tid < L;                                              \
             lse_s[(BUF_) * 64 + tid] = ok_ ? lse_n * LOG2E : __builtin_inff();             \
-            del_s[(BUF_) * 64 + tid] = ok_ ? del_n * p.scale : 0.f;                        \
+            if (!OWN_DELTA) del_s[(BUF_) * 64 + tid] = ok_ ? del_n * p.scale : 0.f;        \
+        }                                                                                  \
+        if (OWN_DELTA) {      /* thread: 8 columns of rows tid/8 and tid/8 + 32 */          \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                             \
+                const bf16x8 d8_ = __builtin_bit_cast(bf16x8, dor[i_]), o8_ = __builtin_bit_cast(bf16x8, orr[i_]); \
+                float s_ = 0.f;                                                            \
+                _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) s_ += (float)d8_[e_] * (float)o8_[e_]; \
+                s_ += __shfl_xor(s_, 1);                                                   \
+                s_ += __shfl_xor(s_, 2);                                                   \
+                s_ += __shfl_xor(s_, 4);                                                   \
+                const int row_ = (tid >> 3) + 32 * i_;                                     \
+                if ((tid & 7) == 0) del_s[(BUF_) * 64 + row_] = ((I0_) + row_ < L) ? s_ * p.scale : 0.f; \
+            }                                                                              \
         }                                                                                  \
     } while (0)
         A32_KV_PREFETCH(ibeg);
@@ -949,6 +968,20 @@ __global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p) {
     }
 }
 
+template <bool REL, bool DROP, int NBUF>
+__global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p) {
+    attn32_bwd_dkv_body<REL, DROP, NBUF, false>(p, blockIdx.x);
+}
+
+// Both backward roles in ONE launch (blocks [0, nq): dQ, blocks [nq, 2 nq): dK/dV with its own delta): at the estimator's
+// sizes a role alone is one 4-wave block per CU (T = 250: 256 blocks), i.e. one wave per SIMD with every latency
+// exposed; together they put two waves on a SIMD, and one launch boundary per attention backward disappears.
+template <bool REL, bool DROP, int NBUF>
+__global__ void __launch_bounds__(256) attn32_bwd_fused_kernel(AP<bf16_t> p, int nq) {
+    if ((int)blockIdx.x < nq) attn32_bwd_dq_body<REL, DROP, NBUF>(p, blockIdx.x);
+    else attn32_bwd_dkv_body<REL, DROP, NBUF, true>(p, blockIdx.x - nq);
+}
+
 // =====================================================================================================================
 // host side
 // =====================================================================================================================
@@ -994,6 +1027,19 @@ int cvft_attn32_bwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
     using namespace a32;
     int rc;
     if (!rel) {
+        static int split = -1;
+        if (split < 0) {
+            const char* e = getenv("CVFT_ATTN_BWD_SPLIT");
+            split = (e && e[0] == '1') ? 1 : 0;
+        }
+        if (!split) {
+            const size_t sm = smem_dq(false, 2) > smem_dkv(false, 2) ? smem_dq(false, 2) : smem_dkv(false, 2);
+            if (set_smem(attn32_bwd_fused_kernel<false, false, 2>, sm, "attn32_bwd_fused")) return -2;
+            const int nq = ((p.L + 127) / 128) * p.H * p.B;
+            hipLaunchKernelGGL((attn32_bwd_fused_kernel<false, false, 2>), dim3(2u * nq), dim3(256), sm, st, p, nq);
+            CVFT_LAUNCH_CHECK("attn32_bwd_fused");
+            return 0;
+        }
         rc = launch(attn32_bwd_dq_kernel<false, false, 2>, smem_dq(false, 2), p, st, "attn32_bwd_dq");
         if (rc) return rc;
         return launch(attn32_bwd_dkv_kernel<false, false, 2>, smem_dkv(false, 2), p, st, "attn32_bwd_dkv");
