@@ -259,7 +259,7 @@ def main():
                     opt.zero_grad()
             torch.cuda.current_stream().wait_stream(s)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (the RCCL watchdog thread keeps running)
                 static_loss = fwd_bwd()
             opt.zero_grad()
         except Exception as e:                      # still the HIP path, just launched eagerly

@@ -197,7 +197,10 @@ class _StepGraph:
             run()                                   # allocator / pack warm-up off the capture
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: the prefetch thread (allocations, host -> device copies on the copy stream) and, under DP, the
+        # RCCL watchdog keep running during capture; in the default "global" mode any such call from another thread
+        # invalidates the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = run()
         flat_g.copy_(saved)                          # the warm-up run accumulated once; capture itself executes nothing
 
