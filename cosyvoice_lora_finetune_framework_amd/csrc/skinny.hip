@@ -111,7 +111,9 @@ int skinny_launch(const GP<bf16_t>& p, hipStream_t st) {
 // one mask site per rank tile t (the stacked q|k|v adapters each have their own nn.Dropout).  The mask is applied to
 // the X fragments in registers (bitwise AND; the 1/(1-p) scale rides in alpha), so drop(x) is never materialised.
 // ------------------------------------------------------------------------------
-template <int RB, int MT, int KS>
+// SHARED: every rank tile uses the mask of site 0 (ONE adapter of rank 16*RB, e.g. r = 64 of BASELINE configs[4]): the mask
+// is derived once per fragment instead of once per rank tile, and drop(X) is written once (xd0).
+template <int RB, int MT, int KS, bool SHARED = false>
 __global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const bf16_t* __restrict__ X, int ldx,
                                                              const bf16_t* __restrict__ A, int lda, float alpha,
                                                              bf16_t* __restrict__ C, int ldc, float p,
@@ -160,27 +162,44 @@ __global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const
         for (int s = 0; s < KS; ++s) {
             const bool live = k0 + 32 * s < ke;
             const int k = min(k0 + 32 * s, K - 32) + kg * 8;     // first of this lane's 8 consecutive k
+            auto masked = [&](int t, unsigned long long key) __attribute__((always_inline)) {
+                const unsigned long long g = ((unsigned long long)rows[t] * K + k) >> 2;
+                bool k0_[4], k1_[4];
+                cvft_keep4(key, g, thr, k0_);
+                cvft_keep4(key, g + 1, thr, k1_);
+                uint4 v = xv[s][t];
+                v.x &= (live && k0_[0] ? 0x0000ffffu : 0u) | (live && k0_[1] ? 0xffff0000u : 0u);
+                v.y &= (live && k0_[2] ? 0x0000ffffu : 0u) | (live && k0_[3] ? 0xffff0000u : 0u);
+                v.z &= (live && k1_[0] ? 0x0000ffffu : 0u) | (live && k1_[1] ? 0xffff0000u : 0u);
+                v.w &= (live && k1_[2] ? 0x0000ffffu : 0u) | (live && k1_[3] ? 0xffff0000u : 0u);
+                return *reinterpret_cast<bf16x8*>(&v);
+            };
+            auto keep = [&](int t, int j, const bf16x8& vm) __attribute__((always_inline)) {
+                if (xd[j] && live && m0 + t * 16 + l15 < M) {
+                    bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                const bf16x8 b = *reinterpret_cast<bf16x8*>(&av[s][j]);
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)vm[e] * inv_keep);
+                    *reinterpret_cast<bf16x8*>(xd[j] + (size_t)rows[t] * K + k) = o;
+                }
+            };
+            if (SHARED) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
-                    const unsigned long long g = ((unsigned long long)rows[t] * K + k) >> 2;
-                    bool k0_[4], k1_[4];
-                    cvft_keep4(keys[j], g, thr, k0_);
-                    cvft_keep4(keys[j], g + 1, thr, k1_);
-                    uint4 v = xv[s][t];
-                    v.x &= (live && k0_[0] ? 0x0000ffffu : 0u) | (live && k0_[1] ? 0xffff0000u : 0u);
-                    v.y &= (live && k0_[2] ? 0x0000ffffu : 0u) | (live && k0_[3] ? 0xffff0000u : 0u);
-                    v.z &= (live && k1_[0] ? 0x0000ffffu : 0u) | (live && k1_[1] ? 0xffff0000u : 0u);
-                    v.w &= (live && k1_[2] ? 0x0000ffffu : 0u) | (live && k1_[3] ? 0xffff0000u : 0u);
-                    const bf16x8 vm = *reinterpret_cast<bf16x8*>(&v);
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vm, b, acc[t][j], 0, 0, 0);
-                    if (j < 3 && xd[j < 3 ? j : 0] && live && m0 + t * 16 + l15 < M) {
-                        bf16x8 o;
+                    const bf16x8 vm = masked(t, keys[0]);
+                    keep(t, 0, vm);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)vm[e] * inv_keep);
-                        *reinterpret_cast<bf16x8*>(xd[j] + (size_t)rows[t] * K + k) = o;
+                    for (int j = 0; j < RB; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vm, *reinterpret_cast<bf16x8*>(&av[s][j]), acc[t][j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const bf16x8 b = *reinterpret_cast<bf16x8*>(&av[s][j]);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        const bf16x8 vm = masked(t, keys[j]);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vm, b, acc[t][j], 0, 0, 0);
+                        if (j < 3) keep(t, j < 3 ? j : 0, vm);
                     }
                 }
             }
@@ -217,18 +236,27 @@ __global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const
 // U[M, R] = alpha * sum_k drop_t(X)[m,k] A[16t + j][k]   (X contiguous rows of K: the mask index is m*K + k)
 extern "C" int cvft_skinny_dropout(int M, int K, int R, const void* X, int ldx, const void* A, int lda, float alpha, void* C,
                                    int ldc, float p, const int64_t* seed, const unsigned* sites, void* const* xd, void* stream) {
-    CVFT_CHECK_ARG(M > 0 && K >= 32 && K % 32 == 0 && (R == 16 || R == 48) && X && A && C && seed && sites && ldx == K && lda >= K &&
-                   ldc >= R && p > 0.f && p < 1.f && (((uintptr_t)X | (uintptr_t)A) & 15) == 0 && lda % 8 == 0,
-                   "cvft_skinny_dropout: bad args (bf16, contiguous X rows, K %% 32 == 0, R in {16, 48})");
+    CVFT_CHECK_ARG(M > 0 && K >= 32 && K % 32 == 0 && (R == 16 || R == 32 || R == 48 || R == 64) && X && A && C && seed && sites &&
+                   ldx == K && lda >= K && ldc >= R && p > 0.f && p < 1.f && (((uintptr_t)X | (uintptr_t)A) & 15) == 0 && lda % 8 == 0,
+                   "cvft_skinny_dropout: bad args (bf16, contiguous X rows, K %% 32 == 0, R in {16, 32, 48, 64})");
+    const int nt = R / 16;
+    bool shared = true;                 // one adapter: every rank tile under the same mask site
+    for (int t = 1; t < nt; ++t) shared = shared && sites[t] == sites[0];
+    CVFT_CHECK_ARG(shared || R == 48, "cvft_skinny_dropout: distinct mask sites per rank tile only for R = 48 (stacked q|k|v)");
     constexpr int MT = 2;
     dim3 grid((M + 16 * MT - 1) / (16 * MT));
     const int ksteps_per_wave = (K / 32 + 7) / 8;
-    uint4 st = make_uint4(sites[0], R > 16 ? sites[1] : 0u, R > 16 ? sites[2] : 0u, 0u);
-#define SKD_LAUNCH(RBv, KSv) hipLaunchKernelGGL((skinny_dropout_kernel<RBv, MT, KSv>), grid, dim3(512), 0, (hipStream_t)stream, M, K, \
+    uint4 st = make_uint4(sites[0], nt > 1 ? sites[1] : 0u, nt > 2 ? sites[2] : 0u, nt > 3 ? sites[3] : 0u);
+    const bool per_tile = !shared;
+#define SKD_LAUNCH(RBv, KSv, SHv) hipLaunchKernelGGL((skinny_dropout_kernel<RBv, MT, KSv, SHv>), grid, dim3(512), 0, (hipStream_t)stream, M, K, \
                                                 (const bf16_t*)X, ldx, (const bf16_t*)A, lda, alpha, (bf16_t*)C, ldc, p, (const long long*)seed, st, \
-                                                (bf16_t*)(xd ? xd[0] : nullptr), (bf16_t*)(xd && R > 16 ? xd[1] : nullptr), (bf16_t*)(xd && R > 16 ? xd[2] : nullptr))
-    if (R == 16) { if (ksteps_per_wave >= 2) SKD_LAUNCH(1, 2); else SKD_LAUNCH(1, 1); }
-    else { if (ksteps_per_wave >= 2) SKD_LAUNCH(3, 2); else SKD_LAUNCH(3, 1); }
+                                                (bf16_t*)(xd ? xd[0] : nullptr), (bf16_t*)(xd && per_tile ? xd[1] : nullptr), (bf16_t*)(xd && per_tile ? xd[2] : nullptr))
+    const bool k2 = ksteps_per_wave >= 2;
+    if (R == 16) { if (k2) SKD_LAUNCH(1, 2, false); else SKD_LAUNCH(1, 1, false); }
+    else if (per_tile) { if (k2) SKD_LAUNCH(3, 2, false); else SKD_LAUNCH(3, 1, false); }
+    else if (R == 32) { if (k2) SKD_LAUNCH(2, 2, true); else SKD_LAUNCH(2, 1, true); }
+    else if (R == 48) { if (k2) SKD_LAUNCH(3, 2, true); else SKD_LAUNCH(3, 1, true); }
+    else { if (k2) SKD_LAUNCH(4, 2, true); else SKD_LAUNCH(4, 1, true); }
 #undef SKD_LAUNCH
     CVFT_LAUNCH_CHECK("cvft_skinny_dropout");
     return 0;

@@ -320,11 +320,14 @@ def skinny_dropout(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, sit
     keep_dropped: the kernel also writes the dropped inputs (one per site) for the backward pass (dropped_input)."""
     U = torch.empty((x.shape[0], A.shape[0]), dtype=x.dtype, device=x.device)
     xd = None
+    if len(sites) == 1 and A.shape[0] > 16:
+        sites = list(sites) * (A.shape[0] // 16)          # ONE adapter of rank > 16: every rank tile under the same mask
     if keep_dropped and KEEP_DROPPED:
-        outs = [torch.empty_like(x) for _ in sites]
-        for st, t in zip(sites, outs):
+        uniq = list(dict.fromkeys(sites))                 # one dropped copy per distinct mask site
+        outs = [torch.empty_like(x) for _ in uniq]
+        for st, t in zip(uniq, outs):
             _DROPPED[st] = t
-        xd = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+        xd = (C.c_void_p * 3)(*([t.data_ptr() for t in outs] + [None] * (3 - len(outs))))
     check(lib().cvft_skinny_dropout(x.shape[0], x.shape[1], A.shape[0], ptr(x), x.stride(0), ptr(A), A.stride(0), float(alpha),
                                     ptr(U), U.stride(0), float(p), ptr(_DROPOUT["seed"]), _sites_arr(sites), xd, stream()),
           "cvft_skinny_dropout")
@@ -361,7 +364,7 @@ def _can_xdrop(dz: torch.Tensor, Wb: torch.Tensor, V: torch.Tensor, At: torch.Te
 
 def _can_drop_fuse(x: torch.Tensor, r: int) -> bool:
     """The fused lora_dropout path (mask inside the skinny / side-dgrad kernels): bf16, contiguous rows, K % 32 == 0."""
-    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and x.shape[1] % 32 == 0 and r in (16, 48)
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and x.shape[1] % 32 == 0 and r in (16, 32, 48, 64)
             and x.data_ptr() % 16 == 0)
 
 

@@ -252,9 +252,10 @@ int cvft_dropout_add(int dtype, int64_t n, const void* x, const void* residual, 
 int cvft_act_dropout(int dtype, int64_t n, int act, const void* z, const void* dh, void* y, float p,
                      const int64_t* seed, unsigned site, void* stream);
 /* LoRA side path under lora_dropout (lora.py:70-73), bf16, masks shared with cvft_dropout_add (element index m*K + k):
- *   cvft_skinny_dropout : U[M,R] = alpha/(1-p) * sum_k keep_t(m,k) X[m,k] A[16t+j][k]   (t = rank tile, sites[t]; R = 16 or 48);
- *                         xd (NULL or R/16 pointers, entries may be NULL): also writes drop_t(X) = keep_t X / (1-p), [M][K] each,
- *                         for the backward's dA_t = V_t^T drop_t(X)
+ *   cvft_skinny_dropout : U[M,R] = alpha/(1-p) * sum_k keep_t(m,k) X[m,k] A[16t+j][k]   (t = rank tile, sites[t], R/16 entries;
+ *                         R in {16, 32, 48, 64}: all sites equal = ONE adapter of rank R; distinct sites only for R = 48, the
+ *                         stacked q|k|v adapters); xd (NULL or 3 pointers, one per DISTINCT site, entries may be NULL): also
+ *                         writes drop_t(X) = keep_t X / (1-p), [M][K] each, for the backward's dA_t = V_t^T drop_t(X)
  *   cvft_lora_side_dgrad: out[m,k] = dx[m,k] + sum_t keep_t(m,k)/(1-p) * sum_j V[m,16t+j] A[16t+j][k] */
 int cvft_skinny_dropout(int M, int K, int R, const void* X, int ldx, const void* A, int lda, float alpha, void* C, int ldc,
                         float p, const int64_t* seed, const unsigned* sites, void* const* xd, void* stream);

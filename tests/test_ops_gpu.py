@@ -729,16 +729,18 @@ def _keep_scale_host(seed: int, site: int, n: int, p: float) -> torch.Tensor:
     return torch.from_numpy((u >= np.uint64(thr)).astype(np.float64)) / (1.0 - float(np.float32(p)))
 
 
+@pytest.mark.parametrize("r", [16, 64])
 @pytest.mark.parametrize("act", [None, "silu"])
-def test_lora_dropout_fused_path_matches_torch(act):
+def test_lora_dropout_fused_path_matches_torch(act, r):
     """lora.py:64-76 in train mode on the fused bf16 path: the mask lives inside cvft_skinny_dropout (forward) and
-    cvft_lora_side_dgrad / cvft_dropout_add (backward); compared with torch math on the host-replicated mask."""
+    cvft_lora_side_dgrad / cvft_dropout_add (backward); compared with torch math on the host-replicated mask.
+    r = 64 (BASELINE configs[4]): ONE adapter whose four rank tiles share the mask site."""
     from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
     from cosyvoice_lora_finetune_framework_amd.modules import hip_linear
     HF = HFmod()
     torch.manual_seed(5)
     M, K, N, pdrop = 300, 128, 192, 0.15
-    mod = LoRALinear(torch.nn.Linear(K, N), r=16, lora_alpha=32, lora_dropout=pdrop).to(DEV)
+    mod = LoRALinear(torch.nn.Linear(K, N), r=r, lora_alpha=2 * r, lora_dropout=pdrop).to(DEV)
     torch.nn.init.normal_(mod.lora_B, std=0.1)
     mod.train()
     x = (torch.randn(M, K, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
