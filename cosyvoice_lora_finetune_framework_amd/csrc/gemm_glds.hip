@@ -193,7 +193,12 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         const unsigned char* Ab = smem + buf * BUF + (wm * TM) * 128;
         const unsigned char* Wb = smem + buf * BUF + A_BYTES + (wn * TN) * 128;
         // all fragment reads of the k-tile are issued before its first MFMA: the second k-step's reads complete under
-        // the first k-step's MFMAs (hipcc places the partial lgkmcnt waits)
+        // the first k-step's MFMAs (hipcc places the partial lgkmcnt waits).
+        // Measured round 2 (tools/bench_cfg.py, 5328 x {4096x1024, 3072x1024, 1024x4096, 1024x1024}): s_setprio(1) around
+        // this MFMA block 603 -> 392 TF/s (the MFMA waves then starve their partners' DMA issue and LDS reads: the
+        // kernel is bound by memory-op issue and LDS bandwidth -- 12 KB of fragment reads per wave and k-tile, 192 KB per
+        // CU and round against 1 024 MFMA cycles -- not by the matrix core); fragment reads hoisted above the DMA issue
+        // 603 -> 385; s_setprio(2) on the DMA-issue segment instead: no change.
         bf16x8 a[2][MI], b[2][NI];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
