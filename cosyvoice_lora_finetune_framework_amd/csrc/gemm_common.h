@@ -159,8 +159,5 @@ __device__ __forceinline__ void gemm_epilogue_direct4(const GP<bf16_t>& p, const
 
 // LDS-DMA (global_load_lds) bf16 kernels for identity-geometry GEMMs; returns 1 when the shape is not eligible.
 int gemm_glds_launch(const GP<bf16_t>& p, hipStream_t st, int cfg);
-// 256 x 256 staggered LDS-DMA kernel for the LLM-sized linears (gemm_big.hip); caller guarantees identity geometry,
-// 16-byte operand alignment and a legal register epilogue.  Returns 1 when not eligible.
-int gemm_big_launch(const GP<bf16_t>& p, hipStream_t st);
 // rank-side products C[M, R<=64] = alpha * A W^T without epilogue (skinny.hip); returns 1 when not eligible.
 int skinny_launch(const GP<bf16_t>& p, hipStream_t st);

@@ -431,10 +431,6 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     p.direct_epi = direct_mode == 2 || (direct_mode == 1 && simple);
     const bool ident = p.ntaps == 1 && p.tap_off[0] == 0 && p.in_stride == 1 && p.Tin == p.Tm && !p.in_len;
     if (!ident || p.K % 64 != 0 || !p.vecA || !p.vecW || p.N <= 32) return 1;
-    if (!p.fuse && p.Tm == p.M && p.xdrop_p <= 0.f && glds_direct_epilogue(p)) {
-        const int rb = gemm_big_launch(p, st);
-        if (rb != 1) return rb;
-    }
     const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     // Stage count: a deep DMA pipeline only pays while the CU still holds every block that wants to run there
     // (16 / 24 KB per stage), measured on cold operands (tools/bench_cold.py): <= 2 blocks per CU and >= 4 k-tiles ->
@@ -498,7 +494,7 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     }
     // LLM-sized launches with a deep k-loop: 128x128 tile, 8 waves as 4x2 (32x64 wave tiles), 2 stages = 64 KB, two
     // blocks per CU.  Per k-tile a wave issues 12 fragment reads + 4 DMA pieces for 16 MFMAs instead of 8 + 3 for 8
-    // (in-kernel stamps, gemm_big.hip: ~23 cycles per ds_read_b128 and ~60 per DMA piece against 16 per MFMA -- the
+    // (in-kernel stamps of the retired 256x256 prototype: ~23 cycles per ds_read_b128 and ~60 per DMA piece against 16 per MFMA -- the
     // 32x32 wave tile is issue-bound), and a byte from L2 feeds 64 FLOP instead of 43.  Measured cold (tools/bench_cfg.py):
     // 5328x4096x1024 541 -> 616 TFLOP/s, 5328x3072x1024 514 -> 613, 5328x1024x4096 581 -> 604, 5328x1024x1024 equal;
     // 4 waves (64x64 wave tiles) or 192-row / 192-column tiles at one block per CU are slower.
@@ -506,7 +502,7 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     // ~1900 cycles per wave -- 400-700 waiting for its DMA pieces (issued one iteration earlier: ~1500 cycles of latency
     // at ~9.5 TB/s of aggregate L2 -> LDS traffic), ~100 in the barrier, 360-530 issuing 4 pieces, 680 for 12 fragment
     // reads + 16 MFMAs (256 of them matrix-core time).  A third / fourth stage (one block per CU) is slower (468 vs 602
-    // TFLOP/s): what is missing is FLOP per L2 byte, i.e. the 256x256 tile of gemm_big.hip, not pipeline depth.  (Issuing the
+    // TFLOP/s): what is missing is FLOP per L2 byte, i.e. a 256-wide tile (retired prototype: DESIGN.md section 9), not pipeline depth.  (Issuing the
     // fragment reads before the DMA pieces, so that the issue time covers the LDS latency, regressed to 365 TFLOP/s.)
     if (big && (nk >= 8 || big_env == 12) && t64 >= 1000) return glds_launch_cfg<128, 128, 4, 2, 0, 2>(p, st);
     if (big) {

@@ -69,7 +69,6 @@ SIGNATURES = {
     "cvft_lora_rank_partial_pair": [_i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "cvft_lora_rank_partial_multi": [_i, _i, _i, _p, _p],
     "cvft_lora_rank_partial_batch": [_i, _i, _p, _p],
-    "cvft_debug_big_stamps": [_p],
     "cvft_debug_glds_stamps": [_p],
     "cvft_debug_mfma_fp8_probe": [_p, _p, _p, _p],
     "cvft_quant_fp8_rows": [_i, _i, _p, _i, _p, _i, _p, _p],

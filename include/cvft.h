@@ -309,10 +309,8 @@ int cvft_adamw_flat(int64_t n, float* p, const float* g, float* m, float* v, con
 /* fp32 -> bf16 cast of a flat buffer */
 int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream);
 
-/* Diagnostics (development only): cycle stamps recorded by the opt-in 256x256 GEMM when CVFT_BIG_STAMP=1
- * (csrc/gemm_big.hip, tools/big_stamps.py); host_out receives 256 uint64. */
-int cvft_debug_big_stamps(unsigned long long* host_out);
-/* same for the default 128x128 kernel (CVFT_GLDS_BIG=15 launches its stamped build; tools/glds_stamps.py) */
+/* Diagnostics (development only): cycle stamps of the default 128x128 LDS-DMA GEMM kernel (CVFT_GLDS_BIG=15 launches its
+ * stamped build; tools/glds_stamps.py); host_out receives 256 uint64. */
 int cvft_debug_glds_stamps(unsigned long long* host_out);
 /* fp8 groundwork (BASELINE configs[4]): one v_mfma_scale_f32_16x16x128_f8f6f4 product, C[16][16] = A[16][128] . B[16][128]^T on
  * OCP e4m3 bytes with unit block scales -- pins the operand layout the fp8 GEMM will use (tests/test_ops_gpu.py). */

@@ -831,42 +831,6 @@ def test_gemm_masked_rank_extension(M, N, K, R):
     assert rel(y, ref) < 6e-3, rel(y, ref)
 
 
-def test_gemm_big_tile_kernel_matches_default_path():
-    """gemm_big.hip (256 x 256 tile, staggered wave rows; opt-in via CVFT_GEMM_BIG) against an fp32 torch reference and
-    against the default kernels' tolerance: partial last M tile, partial last N tile, LoRA extension (R = 16 and 48), bias,
-    GELU + pre-activation, residual.  Runs in a child process: the switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import sys, torch
-sys.path.insert(0, %r)
-from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
-dev, dt = "cuda", torch.bfloat16
-g = torch.Generator().manual_seed(0)
-rn = lambda *s: torch.randn(*s, generator=g).to(dev, dt)
-for (M, N, K, R, act, res) in [(2056, 520, 256, 16, None, False), (1024, 768, 512, 48, "gelu", True), (777 * 8, 1024, 1024, 0, None, True)]:
-    x, w, b = rn(M, K), rn(N, K) / K ** 0.5, torch.randn(N, generator=g).to(dev)
-    u, bl = (rn(M, R), rn(N, R)) if R else (None, None)
-    r = rn(M, N) if res else None
-    y = HF.gemm(x, w, U=u, Bl=bl, bias=b, act=act, residual=r)
-    assert HF.lib().cvft_gemm_last_kernel().decode().startswith("gemm_big_kernel"), HF.lib().cvft_gemm_last_kernel()
-    ref = x.float() @ w.float().t() + b
-    if R:
-        ref = ref + u.float() @ bl.float().t()
-    if act == "gelu":
-        ref = torch.nn.functional.gelu(ref)
-    if res:
-        ref = ref + r.float()
-    err = float((y.float() - ref).norm() / ref.norm())
-    assert err < 4e-3, (M, N, K, R, err)
-print("ok")
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CVFT_GEMM_BIG="2")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("act,n", [("silu", 4096 * 3), ("relu", 1001)])
 def test_act_dropout_one_pass(dtype, act, n):
