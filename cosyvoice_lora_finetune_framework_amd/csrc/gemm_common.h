@@ -157,6 +157,52 @@ __device__ __forceinline__ void gemm_epilogue_direct4(const GP<bf16_t>& p, const
     *reinterpret_cast<bf16x4*>(&p.C[orow * p.ldc + n]) = o;
 }
 
+// 8-wide form of the register epilogue: the LDS-DMA kernels lay the W image out so that a lane's accumulators of the
+// tile pair (j, j + 1) are 8 CONSECUTIVE output columns (gemm_glds.hip, "column map"): one 16-byte access per lane and
+// operand, 64 contiguous bytes per output row and wave instruction instead of 32 (measured with the stores elided: the
+// 8-byte epilogue was 7.4 of 28.9 us at 2048x4096x1024 and 11.5 of 23.3 us at 8000x1536x256).
+// Caller guarantees m < M, n + 7 < N, n % 8 == 0 and 16-byte alignment of every row pitch (glds_wide_epilogue).
+__device__ __forceinline__ void gemm_epilogue_direct8(const GP<bf16_t>& p, const f32x4& a0, const f32x4& a1, int m, int n) {
+    int b = 0, to = m;
+    if (!((p.Tm == p.M) && p.out_stride == 1 && p.out_off == 0)) {
+        b = m / p.Tm;
+        to = (m - b * p.Tm) * p.out_stride + p.out_off;
+        if (to >= p.Tout) return;
+    }
+    const size_t orow = (size_t)b * p.Tout + to;
+    const bool live = p.out_len ? (to < p.out_len[b]) : true;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a0[e] * p.alpha; v[4 + e] = a1[e] * p.alpha; }
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (p.preact) {
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x8*>(&p.preact[orow * p.ldp + n]) = t;
+    }
+    act_apply_vec<8>(p.act, v);
+    if (p.dact_src) {
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(&p.dact_src[orow * p.ldd + n]);
+        float ds[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ds[e] = (float)d[e];
+        act_grad_mul_vec<8>(p.dact, v, ds);
+    }
+    if (p.residual) {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(&p.residual[orow * p.ldr + n]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(live ? v[e] : 0.f);
+    *reinterpret_cast<bf16x8*>(&p.C[orow * p.ldc + n]) = o;
+}
+
 // LDS-DMA (global_load_lds) bf16 kernels for identity-geometry GEMMs; returns 1 when the shape is not eligible.
 int gemm_glds_launch(const GP<bf16_t>& p, hipStream_t st, int cfg);
 // rank-side products C[M, R<=64] = alpha * A W^T without epilogue (skinny.hip); returns 1 when not eligible.

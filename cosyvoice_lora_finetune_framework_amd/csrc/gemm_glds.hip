@@ -7,7 +7,8 @@
 // LDS image of one k-tile: unpadded 128-byte rows (64 bf16), rows in tile order, so one wave-instruction
 // (64 lanes x 16 B) fills 8 consecutive rows -- the DMA's "wave-uniform base + lane * 16" rule.  Bank conflicts of
 // the ds_read_b128 fragment reads are removed by an XOR on the SOURCE side: slot s of row r holds global chunk
-// s ^ ((r >> 1) & 7); readers apply the same XOR.  Two LDS buffers, one barrier per k-tile.
+// s ^ ((r >> 1) & 7) in the A image, s ^ glds_wswz(r) in the W image (whose fragments read permuted rows, see the
+// column map below); readers apply the same XOR.  NS LDS buffers, one barrier per k-tile.
 // The rank-R LoRA extension runs on fragment-shaped direct loads (16 rows x 16 B per lane group) issued before the
 // main loop.  Everything else (row geometry, taps, masks, fp32, odd shapes) stays on gemm.hip's register-staged kernel.
 //
@@ -33,6 +34,26 @@ __host__ __device__ inline bool glds_direct_epilogue(const GP<bf16_t>& p) {
            (!p.residual || ((p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 7) == 0)));
 }
 
+// register epilogue in its 8-wide form (gemm_epilogue_direct8): 16-byte aligned rows and bias
+__host__ __device__ inline bool glds_wide_epilogue(const GP<bf16_t>& p) {
+    return (p.N % 8 == 0) && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+           (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
+           (!p.preact || ((p.ldp % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.preact) & 15) == 0))) &&
+           (!p.dact_src || ((p.ldd % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.dact_src) & 15) == 0))) &&
+           (!p.residual || ((p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
+}
+
+// Column map of the W image.  The MFMA is issued with swapped operands, so lane (kg, l15) of output tile j owns row
+// l15 and the four n-slots 4*kg .. 4*kg+3 of that tile.  Slot s of tile j is NOT column 16*j + s: it is
+//     col(j, s) = 32*(j >> 1) + 8*(s >> 2) + 4*(j & 1) + (s & 3)
+// so that the lane's accumulators of the tile pair (j, j+1) are the 8 consecutive columns 32*(j>>1) + 8*kg .. +7: the
+// epilogue moves 16 bytes per lane and the 4 kg-lanes of a row cover 64 contiguous bytes.  Only the W side knows: the
+// fragment of tile j reads image rows col(j, 0..15) (four runs of 4 rows, 8 apart), and the source-side XOR of the W
+// image is wswz(r) = bit1(r) | bits3..4(r) << 1, which keeps those reads bank-conflict free (the A image keeps
+// (r >> 1) & 7 for its 16 consecutive rows).
+__host__ __device__ constexpr int glds_col(int j, int s) { return 32 * (j >> 1) + 8 * (s >> 2) + 4 * (j & 1) + (s & 3); }
+__host__ __device__ constexpr int glds_wswz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ unsigned long long cvft_glds_stamps[2 * 16 * 8];      // diagnostics (CVFT_GLDS_STAMP=1, tools/glds_stamps.py)
@@ -54,7 +75,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     static_assert(LP_MAX <= 2, "wait dispatch below handles 0, 1 or 2 La pieces per wave");
     constexpr int CLD = BN + 4;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA pieces per wave");
-    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
+    static_assert(TM % 16 == 0 && TN % 32 == 0, "wave tile: 16-row x 32-column units (column map pairs the n tiles)");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Cs = reinterpret_cast<float*>(smem);
@@ -102,7 +123,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
 #pragma unroll
     for (int i = 0; i < W_INS; ++i) {
         const int r = (wid * W_INS + i) * 8 + (lane >> 3);
-        const int gc = (lane & 7) ^ ((r >> 1) & 7);
+        const int gc = (lane & 7) ^ glds_wswz(r);
         const int n = min(n0 + r, p.N - 1);
         gw[i] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw + gc * 8);
     }
@@ -168,7 +189,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
                 }
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    const int n = min(n0 + wn * TN + j * 16 + l15, p.N - 1);
+                    const int n = min(n0 + wn * TN + glds_col(j, l15), p.N - 1);
                     ub[s][j] = *reinterpret_cast<const uint4*>(p.Bl + (size_t)n * p.ldbl + kkc);
                 }
             }
@@ -189,6 +210,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     const int fx = l15 >> 1;
     const int rd0 = l15 * 128 + ((kg ^ fx) << 4);
     const int rd1 = l15 * 128 + (((4 + kg) ^ fx) << 4);
+    // W side (column map): slot l15 of tile j is image row glds_col(j, l15); its XOR is lane-constant
+    const int wrow = 8 * (l15 >> 2) + (l15 & 3), fw = ((l15 >> 1) & 1) | ((l15 >> 2) << 1);
+    const int rw0 = wrow * 128 + ((kg ^ fw) << 4);
+    const int rw1 = wrow * 128 + (((4 + kg) ^ fw) << 4);
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* Ab = smem + buf * BUF + (wm * TM) * 128;
         const unsigned char* Wb = smem + buf * BUF + A_BYTES + (wn * TN) * 128;
@@ -202,11 +227,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         bf16x8 a[2][MI], b[2][NI];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int rd = ks ? rd1 : rd0;
+            const int rd = ks ? rd1 : rd0, rw = ks ? rw1 : rw0;
 #pragma unroll
             for (int i = 0; i < MI; ++i) a[ks][i] = *reinterpret_cast<const bf16x8*>(Ab + i * 2048 + rd);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[ks][j] = *reinterpret_cast<const bf16x8*>(Wb + j * 2048 + rd);
+            for (int j = 0; j < NI; ++j) b[ks][j] = *reinterpret_cast<const bf16x8*>(Wb + glds_col(j, 0) * 128 + rw);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -310,7 +335,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
                     for (int j = 0; j < NI; ++j) {
                         f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
                         Mma<T>::mma(a2, fb[j], fa[i]);
-                        const int n = min(n0 + wn * TN + j * 16 + 4 * kg, p.N - 4);
+                        const int n = min(n0 + wn * TN + glds_col(j, 4 * kg), p.N - 4);
                         bool k4[4];
                         cvft_keep4(key, (m * (unsigned long long)p.N + n) >> 2, thr, k4);
 #pragma unroll
@@ -343,17 +368,24 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         }
     }
 
-    // acc[i][j][r] = C[m0 + wm*TM + i*16 + l15][n0 + wn*TN + j*16 + 4*kg + r]
+    // acc[i][j][r] = C[m0 + wm*TM + i*16 + l15][n0 + wn*TN + glds_col(j, 4*kg) + r]
     // DE (register epilogue) is a separate instantiation: with both epilogues in one kernel the LDS path lost ~6 %
     // (accumulators left the AGPRs, twice the code)
     if constexpr (DE) {
+        const bool wide = glds_wide_epilogue(p);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wm * TM + i * 16 + l15;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int n = n0 + wn * TN + j * 16 + 4 * kg;
-                if (m < p.M && n < p.N) gemm_epilogue_direct4(p, acc[i][j], m, n);
+            for (int jp = 0; jp < NI / 2; ++jp) {
+                const int n = n0 + wn * TN + 32 * jp + 8 * kg;           // = glds_col(2 * jp, 4 * kg); tile 2*jp+1 holds n+4 .. n+7
+                if (m >= p.M) continue;
+                if (wide) {                                               // block-uniform
+                    if (n < p.N) gemm_epilogue_direct8(p, acc[i][2 * jp], acc[i][2 * jp + 1], m, n);
+                } else {
+                    if (n < p.N) gemm_epilogue_direct4(p, acc[i][2 * jp], m, n);
+                    if (n + 4 < p.N) gemm_epilogue_direct4(p, acc[i][2 * jp + 1], m, n + 4);
+                }
             }
         }
     } else {
@@ -362,7 +394,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)    // one ds_write_b128 per tile: rows 272 B apart -> 16 lanes hit 16 distinct 16-byte slots
-                *reinterpret_cast<float4*>(&Cs[(wm * TM + i * 16 + l15) * CLD + wn * TN + j * 16 + 4 * kg]) =
+                *reinterpret_cast<float4*>(&Cs[(wm * TM + i * 16 + l15) * CLD + wn * TN + glds_col(j, 4 * kg)]) =
                     make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         __syncthreads();
         gemm_epilogue_store<T, BM, BN, NT>(p, Cs, m0, n0, tid);
