@@ -69,12 +69,18 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     constexpr int LP_MAX = (L_PIECES + NW - 1) / NW;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, L_BYTES = RP * 128, BUF = A_BYTES + W_BYTES + L_BYTES;
     constexpr int UP_OFF = NS * BUF;                              // FU: [BM][RP] bf16 panel behind the ring
-    constexpr int A_INS = BM / 8 / NW, W_INS = BN / 8 / NW;      // DMA wave-instructions per wave per k-tile
+    // 8-row DMA pieces of the A / W tile, dealt round-robin to the waves (piece = wid + i * NW).  RAGGED: the piece count
+    // is not a multiple of the wave count (96-row tiles on 12 waves) -- the last round is guarded (wave-uniform) and
+    // the vmcnt immediates below are picked per wave
+    constexpr int A_PIECES = BM / 8, W_PIECES = BN / 8;
+    constexpr int A_INS = (A_PIECES + NW - 1) / NW, W_INS = (W_PIECES + NW - 1) / NW;      // DMA wave-instructions per wave per k-tile (max)
+    constexpr bool RAGGED = (A_PIECES % NW != 0) || (W_PIECES % NW != 0);
+    static_assert(!(RAGGED && FU), "ragged piece deal: plain kernels only");
     constexpr int INS = A_INS + W_INS;                            // DMA instructions per wave per tile (+ its La pieces)
     static_assert(NS >= 2 && (NS - 2) * (INS + LP_MAX) < 64, "vmcnt is a 6-bit counter");
     static_assert(LP_MAX <= 2, "wait dispatch below handles 0, 1 or 2 La pieces per wave");
     constexpr int CLD = BN + 4;
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA pieces per wave");
+    static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows must split into 8-row DMA pieces");
     static_assert(TM % 16 == 0 && TN % 32 == 0, "wave tile: 16-row x 32-column units (column map pairs the n tiles)");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -115,14 +121,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     const char* gw[W_INS];
 #pragma unroll
     for (int i = 0; i < A_INS; ++i) {
-        const int r = (wid * A_INS + i) * 8 + (lane >> 3);
+        const int r = (wid + i * NW) * 8 + (lane >> 3);
         const int gc = (lane & 7) ^ ((r >> 1) & 7);
         const int m = min(m0 + r, p.M - 1);
         ga[i] = reinterpret_cast<const char*>(p.A + (size_t)m * p.lda + gc * 8);
     }
 #pragma unroll
     for (int i = 0; i < W_INS; ++i) {
-        const int r = (wid * W_INS + i) * 8 + (lane >> 3);
+        const int r = (wid + i * NW) * 8 + (lane >> 3);
         const int gc = (lane & 7) ^ glds_wswz(r);
         const int n = min(n0 + r, p.N - 1);
         gw[i] = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw + gc * 8);
@@ -149,13 +155,17 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         }
 #pragma unroll
         for (int i = 0; i < A_INS; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_void_t*)ga[i], (lds_void_t*)(base + (wid * A_INS + i) * 1024), 16, 0, 0);
-            ga[i] += BK * 2;
+            if (A_PIECES % NW == 0 || wid + i * NW < A_PIECES) {       // wave-uniform
+                __builtin_amdgcn_global_load_lds((glb_void_t*)ga[i], (lds_void_t*)(base + (wid + i * NW) * 1024), 16, 0, 0);
+                ga[i] += BK * 2;
+            }
         }
 #pragma unroll
         for (int i = 0; i < W_INS; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_void_t*)gw[i], (lds_void_t*)(base + A_BYTES + (wid * W_INS + i) * 1024), 16, 0, 0);
-            gw[i] += BK * 2;
+            if (W_PIECES % NW == 0 || wid + i * NW < W_PIECES) {
+                __builtin_amdgcn_global_load_lds((glb_void_t*)gw[i], (lds_void_t*)(base + A_BYTES + (wid + i * NW) * 1024), 16, 0, 0);
+                gw[i] += BK * 2;
+            }
         }
     };
 
@@ -252,6 +262,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
     };
 
     const int nk = p.K / BK;
+    // RAGGED: pieces this wave does NOT move in its last deal round (0, 1 or 2; wave-uniform)
+    const int short_by = (A_PIECES % NW != 0 && wid + (A_INS - 1) * NW >= A_PIECES ? 1 : 0) +
+                         (W_PIECES % NW != 0 && wid + (W_INS - 1) * NW >= W_PIECES ? 1 : 0);
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nk) issue(t);
@@ -262,7 +275,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
         if (rec) sb[0] = __builtin_readcyclecounter();
         // this wave's pieces of tile kt have landed once at most the NS-2 younger tiles are still outstanding
         // (loads retire in order; the LoRA fragment loads are older than every tile)
-        if (kt + NS - 2 < nk) {
+        if (RAGGED && kt + NS - 2 < nk) {
+            if (short_by == 0) wait_vmcnt<(NS - 2) * INS>();
+            else if (short_by == 1) wait_vmcnt<(NS - 2) * (INS > 1 ? INS - 1 : 0)>();
+            else wait_vmcnt<(NS - 2) * (INS > 2 ? INS - 2 : 0)>();
+        } else if (kt + NS - 2 < nk) {
             if (my_lp == 2) wait_vmcnt<(NS - 2) * (INS + 2)>();
             else if (my_lp == 1) wait_vmcnt<(NS - 2) * (INS + 1)>();
             else wait_vmcnt<(NS - 2) * INS>();
@@ -508,6 +525,8 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
             case 4: return glds_launch_cfg<256, 128, 4, 2, 0, 2>(p, st);
             case 6: return glds_launch_cfg<128, 128, 2, 2, 0, 2>(p, st);
             case 8: return glds_launch_cfg<128, 128, 2, 4, 0, 2>(p, st);
+            case 17: return glds_launch_cfg<128, 256, 4, 4, 0, 3>(p, st);
+            case 19: return glds_launch_cfg<96, 256, 3, 4, 0, 3>(p, st);
             case 13: return glds_launch_cfg<128, 128, 4, 2, 0, 3>(p, st);
             case 14: return glds_launch_cfg<128, 128, 4, 2, 0, 4>(p, st);
             case 15: {          // stamped build of the default 128x128 kernel (register epilogue)
@@ -536,6 +555,14 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     // reads + 16 MFMAs (256 of them matrix-core time).  A third / fourth stage (one block per CU) is slower (468 vs 602
     // TFLOP/s): what is missing is FLOP per L2 byte, i.e. a 256-wide tile (retired prototype: DESIGN.md section 9), not pipeline depth.  (Issuing the
     // fragment reads before the DMA pieces, so that the issue time covers the LDS latency, regressed to 365 TFLOP/s.)
+    // Less than one round of 128x128 blocks (N = 1024 at M = 5328: 336 blocks on 512 slots, 80 CUs hold two): a 256-wide
+    // tile with 3 stages at ONE block per CU -- 96x256 on 12 waves (224 blocks) or 128x256 on 16 -- same 32x64 wave tiles,
+    // 25 % less L2 -> LDS traffic per FLOP, two k-tiles in flight.  Measured cold (tools/bench_cfg.py), 128x128 -> 128x256 ->
+    // 96x256: 5328x1024x4096 631 -> 696 -> 709 TFLOP/s, x1024x3072 584 -> 638 -> 652, x1024x1024 485 -> 507 -> 501; on the
+    // multi-round shapes (N = 3072 / 4096) 128x256 is equal and 96x256 10-15 % slower, so they keep two 128x128 blocks per CU.
+    static const int wide_on = getenv("CVFT_GLDS_WIDE") ? atoi(getenv("CVFT_GLDS_WIDE")) : 1;
+    if (big && wide_on && nk >= 8 && t64 >= 1000 && p.N >= 256 && (long)((p.M + 95) / 96) * ((p.N + 255) / 256) <= 256)
+        return glds_launch_cfg<96, 256, 3, 4, 0, 3>(p, st);
     if (big && (nk >= 8 || big_env == 12) && t64 >= 1000) return glds_launch_cfg<128, 128, 4, 2, 0, 2>(p, st);
     if (big) {
         if (ns >= 3) return glds_launch_cfg<128, 64, 4, 2, 0, 3>(p, st);

@@ -45,6 +45,31 @@ def test_gemm_plain(dtype, M, N, K):
     assert rel(y, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N,K,r,label", [(4000, 1000, 512, 16, "96,256,3,4"), (5328, 1024, 2048, 0, "96,256,3,4"),
+                                           (4100, 1004, 512, 16, "96,256,3,4"), (2100, 1004, 256, 0, "64,64,2,2"),
+                                           (4100, 1004, 256, 16, "128,64,4,2"),
+                                           (4200, 2052, 512, 48, "128,128,4,2")])
+def test_gemm_tile_configs_and_epilogue_forms(M, N, K, r, label):
+    """bf16 LDS-DMA GEMM: the one-round 96x256 x 12-wave configuration (ragged DMA piece deal), and both forms of the register
+    epilogue under the W image's column map -- 16-byte (N % 8 == 0) and 8-byte (N % 4 == 0 only) -- with bias, activation,
+    pre-activation output, residual and a rank extension, partial edge tiles in both dimensions."""
+    HF = HFmod()
+    dtype = torch.bfloat16
+    x, w = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    b, res = rnd(N, seed=5), q(rnd(M, N, seed=6), dtype)
+    u = q(rnd(M, r, seed=3), dtype) if r else None
+    bl = q(rnd(N, r, seed=4) * 0.1, dtype) if r else None
+    pre = torch.empty(M, N, device=DEV, dtype=dtype)
+    y = HF.gemm(x.to(DEV, dtype), w.to(DEV, dtype), bias=b.to(DEV), U=None if u is None else u.to(DEV, dtype),
+                Bl=None if bl is None else bl.to(DEV, dtype), act="gelu_erf", preact=pre, residual=res.to(DEV, dtype))
+    assert label in HF.lib().cvft_gemm_last_kernel().decode(), HF.lib().cvft_gemm_last_kernel().decode()
+    z = x.double() @ w.double().t() + b.double()
+    if r:
+        z = z + u.double() @ bl.double().t()
+    assert rel(pre, z) < TOL[dtype]
+    assert rel(y, F.gelu(z) + res.double()) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("act", [None, "relu", "silu", "gelu_erf", "gelu_tanh", "mish"])
 def test_gemm_lora_epilogue(dtype, act):
