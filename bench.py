@@ -243,6 +243,18 @@ def main():
             tr.fit(module, loader)
         opt = tr.optimizer
         trainer_stats = dict(tr.graph_stats)
+        from cosyvoice_lora_finetune_framework_amd import train_joint as _tj
+        if _tj._TIMING:
+            torch.cuda.synchronize()
+            T = _tj._TIMING[-10:]
+            cp = sum(e[0].elapsed_time(e[1]) for e in T) / len(T)
+            gr = sum(e[1].elapsed_time(e[2]) for e in T) / len(T)
+            gap = sum(T[i][2].elapsed_time(T[i + 1][0]) for i in range(len(T) - 1)) / (len(T) - 1)
+            hc = sum(e[3][1] - e[3][0] for e in T) / len(T) * 1e3
+            hr = sum(e[3][2] - e[3][1] for e in T) / len(T) * 1e3
+            hg = sum(T[i + 1][3][0] - T[i][3][2] for i in range(len(T) - 1)) / (len(T) - 1) * 1e3
+            log(f"[bench] trainer host timeline: copies {hc:.2f} ms, replay call {hr:.2f} ms, replay return -> next step's copies {hg:.2f} ms")
+            log(f"[bench] trainer GPU timeline: static copies {cp:.3f} ms, graph {gr:.3f} ms, graph end -> next step's copies {gap:.3f} ms")
         el = torch.tensor([marks["t1"] - marks["t0"]], device=dev)
         if world > 1:
             torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
@@ -298,6 +310,17 @@ def main():
         final_loss = float(loss)
 
     log(f"[bench] timed region done: {elapsed / a.steps * 1e3:.2f} ms/step")
+    if os.environ.get("CVFT_BENCH_HOSTLAUNCH") and not a.via_trainer and graph is not None:
+        hs, tot = [], []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            graph.replay()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            hs.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
+        log(f"[bench] idle-GPU replay: host call {min(hs):.2f} ms, to completion {min(tot):.2f} ms")
     roof = None
     if not a.no_roofline:
         # event-instrumented eager step: every tap-GEMM launch bracketed by HIP events on the launch stream

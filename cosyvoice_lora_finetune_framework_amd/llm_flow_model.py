@@ -21,7 +21,13 @@ from .hipops import functional as HF
 from .modules import Numerics
 
 
-BATCH_SPLIT = int(os.environ.get("CVFT_BATCH_SPLIT", "1"))            # sub-batches per branch, each chain on its own stream (measured slower: 2 x 2 chains, and 2 LLM chains + 1 flow chain 36.3 vs 30.5 ms)
+# Sub-batches per branch, each an independent chain on its own stream.  Measured (B = 16, T = 500, captured step): the Flow
+# branch in two halves next to the whole-batch LLM branch -- three chains -- 28.2 -> 27.0 ms; the estimator's kernels
+# under-fill the chip even at M = 8 000 rows, and the second half fills what the first leaves.  More chains lose: LLM x 2 +
+# Flow x 2 33.4 ms, Flow x 4 40.4 ms, Flow x 3 27.0 ms with 4 hardware queues but 37.3 ms with 8 -- every fork / join edge of
+# the captured graph crosses hardware queues (~9 us each).  Results are unchanged (global loss denominators, see forward()).
+SPLIT = {'llm': int(os.environ.get("CVFT_LLM_SPLIT", "1")), 'flow': int(os.environ.get("CVFT_FLOW_SPLIT", "2"))}
+SPLIT_MIN_PART = int(os.environ.get("CVFT_SPLIT_MIN_PART", "4"))      # utterances per sub-batch below which a branch is not split
 BRANCH_STREAMS = os.environ.get("CVFT_BRANCH_STREAMS", "1") != "0"      # LLM branch on a second stream (joint mode): 35.9 -> 30.1 ms/step
 
 
@@ -49,8 +55,8 @@ class JointLLMFlowModel(nn.Module):
         """llm_flow_model.py:77-107.  `draws` (optional) injects the CFM random draws.
 
         Execution (results unchanged): the LLM and the Flow branch share nothing until the loss sum, and utterances share
-        nothing but the loss denominators -- so the step runs as 2 x BATCH_SPLIT independent chains on separate HIP
-        streams (LLM / Flow x sub-batches).  Most kernels of a chain under-fill the chip (the estimator's GEMMs are 252
+        nothing but the loss denominators -- so the step runs as SPLIT['llm'] + SPLIT['flow'] independent chains on separate HIP
+        streams (LLM / Flow x sub-batches, `SPLIT`).  Most kernels of a chain under-fill the chip (the estimator's GEMMs are 252
         blocks on 256 CUs) and are latency-bound; concurrent chains fill it.  autograd replays every chain's backward on
         the stream its forward ran on, so the overlap holds for the whole step, and inside a captured hipGraph it costs
         one fork and one join per chain and direction.  Sub-batch losses are recombined with their share of the global
@@ -60,12 +66,10 @@ class JointLLMFlowModel(nn.Module):
             HF.dropout_begin_step()       # new dropout masks per step (device-side seed: also across hipGraph replays)
         parts = batch.get('_parts')
         if parts is None:
-            B = batch['speech_token'].shape[0]
-            n = min(BATCH_SPLIT, B) if torch.cuda.is_available() else 1
-            parts = self._split_parts(batch, device, n) if n > 1 else [dict(batch, _w_llm=1.0, _w_flow=1.0)]
+            parts = self._make_parts(batch, batch, device, torch.cuda.is_available())
         do_llm = self.training_mode in ('joint', 'llm_only')
         do_flow = self.training_mode in ('joint', 'flow_only')
-        chains = [('llm', k) for k in range(len(parts))] * do_llm + [('flow', k) for k in range(len(parts))] * do_flow
+        chains = [('llm', k) for k in range(len(parts['llm']))] * do_llm + [('flow', k) for k in range(len(parts['flow']))] * do_flow
         use_streams = BRANCH_STREAMS and torch.cuda.is_available() and len(chains) > 1
         cur = torch.cuda.current_stream() if use_streams else None
         results = {}
@@ -77,7 +81,7 @@ class JointLLMFlowModel(nn.Module):
                 st = JointLLMFlowModel._streams[ci]
                 st.wait_stream(cur)
             with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-                part = parts[k]
+                part = parts[kind][k]
                 if kind == 'llm':
                     r = self._forward_llm(part, device)
                     results[(kind, k)] = (r['loss'] * part['_w_llm'], r['acc'] * part['_w_llm'] if 'acc' in r else None)
@@ -92,11 +96,11 @@ class JointLLMFlowModel(nn.Module):
                 cur.wait_stream(v[1])
                 results[key] = v[0]
         if do_llm:
-            losses['llm_loss'] = sum(results[('llm', k)][0] for k in range(len(parts))) * self.llm_loss_weight
+            losses['llm_loss'] = sum(results[('llm', k)][0] for k in range(len(parts['llm']))) * self.llm_loss_weight
             if results[('llm', 0)][1] is not None:
-                losses['llm_acc'] = sum(results[('llm', k)][1] for k in range(len(parts)))
+                losses['llm_acc'] = sum(results[('llm', k)][1] for k in range(len(parts['llm'])))
         if do_flow:
-            losses['flow_loss'] = sum(results[('flow', k)][0] for k in range(len(parts))) * self.flow_loss_weight
+            losses['flow_loss'] = sum(results[('flow', k)][0] for k in range(len(parts['flow']))) * self.flow_loss_weight
         if self.training_mode == 'joint':
             losses['loss'] = losses['llm_loss'] + losses['flow_loss']
         elif self.training_mode == 'llm_only':
@@ -105,16 +109,16 @@ class JointLLMFlowModel(nn.Module):
             losses['loss'] = losses['flow_loss']
         return losses
 
-    def _prepare_one(self, batch: dict, device, lm_pad: int = 1) -> dict:
+    def _prepare_one(self, batch: dict, device, lm_pad: int = 1, with_llm: bool = True) -> dict:
         out = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
         for k in ('speech_token_len', 'speech_feat_len', 'text_token_len'):
             if k in out:
                 out[k] = out[k].to(torch.int32)
-        if self.training_mode in ('joint', 'llm_only') and hasattr(self.llm, 'prepare_batch') and 'text_token' in batch:
+        if with_llm and self.training_mode in ('joint', 'llm_only') and hasattr(self.llm, 'prepare_batch') and 'text_token' in batch:
             out.update(self.llm.prepare_batch(batch, device, lm_pad))
         return out
 
-    def _split_parts(self, batch: dict, device, nparts: int):
+    def _split_parts(self, batch: dict, device, nparts: int, kind: str = 'llm', lm_pad: int = 1):
         """Host side: contiguous sub-batches + their share of the global loss denominators (frames / target tokens)."""
         B = batch['speech_token'].shape[0]
         bounds = [round(i * B / nparts) for i in range(nparts + 1)]
@@ -125,10 +129,11 @@ class JointLLMFlowModel(nn.Module):
             sl = slice(bounds[i], bounds[i + 1])
             sub = {k: (v[sl] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v)
                    for k, v in batch.items() if not k.startswith('_')}
-            part = self._prepare_one(sub, device)
+            part = self._prepare_one(sub, device, lm_pad, with_llm=(kind == 'llm'))      # index maps only where the LM runs
             part['_rows'] = sl
-            part['_w_flow'] = float(feat_len[sl].sum() / feat_len.sum())
-            part['_w_llm'] = float(tgt_len[sl].sum() / tgt_len.sum())
+            # device scalars, not Python floats: a captured step is replayed on other batches (other length mixes)
+            part['_w_flow'] = torch.tensor(float(feat_len[sl].sum() / feat_len.sum()), dtype=torch.float32).to(device)
+            part['_w_llm'] = torch.tensor(float(tgt_len[sl].sum() / tgt_len.sum()), dtype=torch.float32).to(device)
             parts.append(part)
         return parts
 
@@ -136,9 +141,17 @@ class JointLLMFlowModel(nn.Module):
         """Move a collated batch to `device` and attach the host-computed LLM index maps (and the sub-batch split), so
         that the training step itself performs no host<->device transfers (hipGraph-capturable)."""
         out = self._prepare_one(batch, device, lm_pad)
-        n = min(BATCH_SPLIT, batch['speech_token'].shape[0])
-        out['_parts'] = self._split_parts(batch, device, n) if n > 1 else [dict(out, _w_llm=1.0, _w_flow=1.0)]
+        out['_parts'] = self._make_parts(batch, out, device, True, lm_pad)
         return out
+
+    def _make_parts(self, batch: dict, whole: dict, device, split: bool, lm_pad: int = 1) -> dict:
+        """per branch: the list of sub-batches its chains run on (one entry aliasing `whole` when the branch is not split)"""
+        B = batch['speech_token'].shape[0]
+        parts = {}
+        for kind in ('llm', 'flow'):
+            n = SPLIT[kind] if split and B >= SPLIT[kind] * SPLIT_MIN_PART else 1
+            parts[kind] = self._split_parts(batch, device, n, kind, lm_pad) if n > 1 else [dict(whole, _w_llm=1.0, _w_flow=1.0)]
+        return parts
 
     def _forward_llm(self, batch: dict, device) -> Dict[str, Any]:
         return self.llm.forward_no_prompt(batch, device)

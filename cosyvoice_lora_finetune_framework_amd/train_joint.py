@@ -121,9 +121,111 @@ def _batch_denoms(batch, training_mode: str = 'joint') -> Dict[str, float]:
 
 
 TEXT_BUCKET = 16      # graph path: text tokens padded to a multiple of this (masked by text_token_len)
-LM_BUCKET = 32        # graph path: LM sequence length L rounded up to a multiple of this (masked by lm_len)
+LM_BUCKET = 16        # graph path: LM sequence length L rounded up to a multiple of this (masked by lm_len).  The padding rows are real
+                      # work for every LM kernel: at 32, L = 333 became 352 (+5.7 % on the LLM branch, ~1 ms/step vs the pre-staged step)
 # (mel frames T and speech tokens Lt are NOT bucketed: the length regulator interpolates Lt_max -> T_max of the padded
 #  batch, length_regulator.py:44-50, so padding them would change the result)
+
+
+class _Leaf:
+    """placeholder of tensor number `i` in a packed batch tree"""
+    __slots__ = ("i",)
+
+    def __init__(self, i: int):
+        self.i = i
+
+
+def _tree_map(obj, fn_tensor, fn_leaf=None, memo=None):
+    """rebuild a dict / list / tuple tree with tensors (or _Leaf placeholders) replaced; a tensor reachable twice (an
+    unsplit branch's `_parts` entry aliases the batch) is mapped once"""
+    memo = {} if memo is None else memo
+    if torch.is_tensor(obj):
+        if id(obj) not in memo:
+            memo[id(obj)] = fn_tensor(obj)
+        return memo[id(obj)]
+    if isinstance(obj, _Leaf):
+        return fn_leaf(obj)
+    if isinstance(obj, dict):
+        return {k: _tree_map(v, fn_tensor, fn_leaf, memo) for k, v in obj.items()}
+    if isinstance(obj, tuple):
+        return tuple(_tree_map(v, fn_tensor, fn_leaf, memo) for v in obj)
+    if isinstance(obj, list):
+        return [_tree_map(v, fn_tensor, fn_leaf, memo) for v in obj]
+    return obj
+
+
+class _PackedBatch:
+    """A prepared batch as ONE device byte slab plus a tree of typed views into it."""
+    __slots__ = ("tree", "slab", "spec", "meta", "key")
+
+    def bind(self, slab: torch.Tensor):
+        """the same tree over another slab of this layout (the captured step's static copy)"""
+        views = [slab[o:o + n].view(dt).view(shape) for (o, n, dt, shape) in self.meta]
+        return _tree_map(self.spec, None, lambda leaf: views[leaf.i])
+
+
+class _BatchPacker:
+    """Host side of the graph path's input staging.  A prepared batch is ~40 small tensors (tokens, lengths, mel frames,
+    LM index maps, the sub-batch copies of a split branch); moved one by one from pageable memory that was ~40 blit
+    launches on a compute queue per step plus as many device-to-device copies into the captured step's static buffers,
+    and with the step's three chains already on three hardware queues the extra queue traffic cost ~1 ms / step.  Here the
+    tensors are laid out in ONE pinned host slab (256-byte aligned), which goes to the device as a single DMA on the copy
+    stream; the static buffers of a captured step are views into one static slab, refreshed by one device copy."""
+    ALIGN = 256
+    ROUND = 1 << 16
+
+    def __init__(self):
+        self.pool = {}                    # rounded byte size -> [(pinned buffer, event of its last upload)]
+
+    def _pinned(self, nbytes: int):
+        size = -(-nbytes // self.ROUND) * self.ROUND
+        bufs = self.pool.setdefault(size, [])
+        for ent in bufs:
+            if ent[1] is None or ent[1].query():
+                return ent
+        ent = [torch.empty(size, dtype=torch.uint8).pin_memory(), None]
+        bufs.append(ent)
+        return ent
+
+    def pack(self, tree, dev, stream) -> _PackedBatch:
+        leaves, scalars = [], []
+
+        def note(t):
+            leaves.append(t.detach().contiguous())
+            return _Leaf(len(leaves) - 1)
+
+        def walk_scalars(o):             # ints / slices the captured step bakes in (LM length, sub-batch row ranges)
+            if isinstance(o, dict):
+                for k in sorted(o, key=str):
+                    walk_scalars(o[k])
+            elif isinstance(o, (tuple, list)):
+                for v in o:
+                    walk_scalars(v)
+            elif isinstance(o, (int, slice)) and not isinstance(o, bool):
+                scalars.append(repr(o))
+        pk = _PackedBatch()
+        pk.spec = _tree_map(tree, note)
+        walk_scalars(pk.spec)
+        off, meta = 0, []
+        for t in leaves:
+            n = t.numel() * t.element_size()
+            meta.append((off, n, t.dtype, tuple(t.shape)))
+            off += -(-max(n, 1) // self.ALIGN) * self.ALIGN
+        total = max(off, self.ALIGN)
+        ent = self._pinned(total)
+        host = ent[0]
+        for t, (o, n, dt, shape) in zip(leaves, meta):
+            if n:
+                host[o:o + n].view(dt).view(shape).copy_(t)
+        with torch.cuda.stream(stream):
+            pk.slab = torch.empty(total, dtype=torch.uint8, device=dev)
+            pk.slab.copy_(host[:total], non_blocking=True)
+            ent[1] = torch.cuda.Event()
+            ent[1].record()
+        pk.meta = meta
+        pk.key = (tuple((shape, str(dt)) for (_, _, dt, shape) in meta), tuple(scalars))
+        pk.tree = pk.bind(pk.slab)
+        return pk
 
 
 def _record_stream(obj, stream) -> None:
@@ -135,9 +237,8 @@ def _record_stream(obj, stream) -> None:
         for v in obj:
             _record_stream(v, stream)
     elif isinstance(obj, dict):
-        for k, v in obj.items():
-            if k != '_parts':
-                _record_stream(v, stream)
+        for v in obj.values():
+            _record_stream(v, stream)
 
 
 class _Prefetcher:
@@ -172,13 +273,17 @@ class _Prefetcher:
             yield item
 
 
+_TIMING = [] if os.environ.get('CVFT_TRAINER_TIMING') else None      # diagnostic: per-replay (events, host stamps), read by bench.py
+
+
 class _StepGraph:
     """One captured micro-step -- forward + backward into the flat LoRA-gradient buffer -- for one batch shape.  The
     batch lives in static device buffers that the trainer refreshes before every replay; the per-rank loss weights (DP)
     and the injected CFM draws are static inputs too."""
 
-    def __init__(self, module, prepared: dict, draws, w: torch.Tensor, accum: int, flat_g: torch.Tensor):
-        self.batch, self.draws, self.w = prepared, draws, w
+    def __init__(self, module, packed: _PackedBatch, draws, w: torch.Tensor, accum: int, flat_g: torch.Tensor):
+        self.slab = packed.slab.clone()              # static inputs: one slab, the batch tree is views into it
+        self.batch, self.draws, self.w = packed.bind(self.slab), draws, w
         model, dev = module.model, module.device
         keys = [k for k in ("llm", "flow") if (k == "llm" and module.training_mode in ('joint', 'llm_only')) or
                 (k == "flow" and module.training_mode in ('joint', 'flow_only'))]
@@ -205,23 +310,37 @@ class _StepGraph:
         flat_g.copy_(saved)                          # the warm-up run accumulated once; capture itself executes nothing
 
     @staticmethod
-    def _copy(dst, src):
+    def _copy(dst, src, seen=None):
+        """refresh static tensors one by one (the injected CFM draws; the batch itself is one slab copy)"""
+        seen = set() if seen is None else seen
         if torch.is_tensor(dst):
-            dst.copy_(src, non_blocking=True)
+            if id(dst) not in seen:
+                seen.add(id(dst))
+                dst.copy_(src, non_blocking=True)
         elif isinstance(dst, (tuple, list)):
             for a, b in zip(dst, src):
-                _StepGraph._copy(a, b)
+                _StepGraph._copy(a, b, seen)
         elif isinstance(dst, dict):
             for k in dst:
-                if k != '_parts':                    # (_parts aliases the same tensors when BATCH_SPLIT == 1)
-                    _StepGraph._copy(dst[k], src[k])
+                _StepGraph._copy(dst[k], src[k], seen)
 
-    def replay(self, prepared: dict, draws, w: torch.Tensor):
-        self._copy(self.batch, prepared)
+    def replay(self, packed: _PackedBatch, draws, w: torch.Tensor):
+        if _TIMING is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            h0 = time.perf_counter()
+        self.slab.copy_(packed.slab, non_blocking=True)
         if self.draws is not None:
             self._copy(self.draws, draws)
         self.w.copy_(w)
+        if _TIMING is not None:
+            ev[1].record()
+            h1 = time.perf_counter()
         self.graph.replay()
+        if _TIMING is not None:
+            ev[2].record()
+            ev.append((h0, h1, time.perf_counter()))
+            _TIMING.append(ev)
         return self.out
 
 
@@ -254,6 +373,7 @@ class Trainer:
         self.on_step_end = on_step_end     # optional hook(trainer) after every optimiser step (bench.py --via-trainer)
         self.graph_stats = {"replays": 0, "eager": 0, "captures": 0}
         self._copy_stream = None
+        self._packer = _BatchPacker()
         self._graphs: Dict[tuple, _StepGraph] = {}
         self._seen: Dict[tuple, int] = {}
         self.rank, _, self.world = (0, 0, 1) if not torch.distributed.is_initialized() else \
@@ -312,11 +432,12 @@ class Trainer:
             batch = dict(batch, text_token=torch.nn.functional.pad(tt, (0, TEXT_BUCKET - tt.shape[1] % TEXT_BUCKET)))
         # host -> device copies on a side stream: a pageable-memory copy blocks the host until every earlier operation
         # of ITS stream has finished -- on the compute stream that would be the whole previous step
+        # index maps / sub-batch split on the host, then ONE pinned slab -> ONE DMA on the copy stream (_BatchPacker)
+        packed = self._packer.pack(module.model.prepare_batch(batch, 'cpu', LM_BUCKET), dev, self._copy_stream)
+        ev = torch.cuda.Event()
         with torch.cuda.stream(self._copy_stream):
-            prepared = module.model.prepare_batch(batch, dev, LM_BUCKET)
-            ev = torch.cuda.Event()
             ev.record()
-        return batch, prepared, ev
+        return batch, packed, ev
 
     def _micro_step(self, module, opt, batch, draws, w, prepared=None, ready=None):
         """forward + backward of one local batch; returns the dict of detached loss scalars.  `w` = per-term loss weights
@@ -332,11 +453,11 @@ class Trainer:
                     ready = torch.cuda.Event()
                     ready.record()
             main.wait_event(ready)
-            _record_stream(prepared, main)
+            prepared.slab.record_stream(main)         # allocated on the copy stream, consumed on `main`
             _record_stream(draws, main)
-            maps = prepared.get('_lm_maps')
-            key = (tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(prepared.items()) if torch.is_tensor(v)),
-                   None if maps is None else maps[3], draws is not None and tuple(sorted(draws)))
+            # layout of the slab (every tensor's shape / dtype) + the Python scalars the step bakes in (LM length L,
+            # sub-batch row ranges) + whether CFM draws are injected
+            key = (prepared.key, draws is not None and tuple(sorted(draws)))
             g = self._graphs.get(key)
             if g is None:
                 self._seen[key] = self._seen.get(key, 0) + 1
@@ -346,7 +467,7 @@ class Trainer:
             if g is not None:
                 self.graph_stats["replays"] += 1
                 return g.replay(prepared, draws, w)
-            batch = prepared
+            batch = prepared.tree
         self.graph_stats["eager"] += 1
         losses = module.model(batch, dev, draws)
         total = sum(losses[f"{k}_loss"] * w[i] for i, k in enumerate(keys))

@@ -370,8 +370,9 @@ def test_sub_batch_chains_reproduce_global_batch_means(tiny_meta):
     batch = synth_batch([24, 17, 21], text_lens=[7, 5, 6], token_lens=[13, 9, 11], seed=11, text_vocab=100, speech_vocab=50)
     draws = cfm_draws(3, 24, seed=5)
     outs = []
-    for split in (1, 2):
-        J.BATCH_SPLIT = split
+    for split in ({'llm': 1, 'flow': 1}, {'llm': 2, 'flow': 2}, {'llm': 1, 'flow': 3}):
+        J.SPLIT.update(split)
+        min_part, J.SPLIT_MIN_PART = J.SPLIT_MIN_PART, 1
         try:
             for p in jm.parameters():
                 p.grad = None
@@ -380,11 +381,13 @@ def test_sub_batch_chains_reproduce_global_batch_means(tiny_meta):
             outs.append(([float(out[k]) for k in ('loss', 'llm_loss', 'flow_loss', 'llm_acc')],
                          {n: p.grad.clone() for n, p in jm.named_parameters() if p.grad is not None}))
         finally:
-            J.BATCH_SPLIT = 1
-    for a, b in zip(outs[0][0], outs[1][0]):
-        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (outs[0][0], outs[1][0])
-    assert set(outs[0][1]) == set(outs[1][1])
-    assert max(rel(outs[1][1][k], outs[0][1][k]) for k in outs[0][1]) < 1e-4
+            J.SPLIT.update({'llm': 1, 'flow': 2})
+            J.SPLIT_MIN_PART = min_part
+    for o in outs[1:]:
+        for a, b in zip(outs[0][0], o[0]):
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (outs[0][0], o[0])
+        assert set(outs[0][1]) == set(o[1])
+        assert max(rel(o[1][k], outs[0][1][k]) for k in outs[0][1]) < 1e-4
 
 
 def test_flow_prompt_path_loss_and_grads(tiny_meta):
