@@ -26,7 +26,9 @@ from .modules import Numerics
 # under-fill the chip even at M = 8 000 rows, and the second half fills what the first leaves.  More chains lose: LLM x 2 +
 # Flow x 2 33.4 ms, Flow x 4 40.4 ms, Flow x 3 27.0 ms with 4 hardware queues but 37.3 ms with 8 -- every fork / join edge of
 # the captured graph crosses hardware queues (~9 us each).  Results are unchanged (global loss denominators, see forward()).
-SPLIT = {'llm': int(os.environ.get("CVFT_LLM_SPLIT", "1")), 'flow': int(os.environ.get("CVFT_FLOW_SPLIT", "2"))}
+# Single-branch modes: flow_only x 2 18.6 -> 18.1 ms (x 3 18.6), llm_only x 2 16.0 -> 15.3 ms.
+SPLIT = {'llm': int(os.environ.get("CVFT_LLM_SPLIT", "1")), 'flow': int(os.environ.get("CVFT_FLOW_SPLIT", "2"))}      # joint / flow_only
+SPLIT_LLM_ONLY = int(os.environ.get("CVFT_LLM_SPLIT", "2"))                                                             # llm_only
 SPLIT_MIN_PART = int(os.environ.get("CVFT_SPLIT_MIN_PART", "4"))      # utterances per sub-batch below which a branch is not split
 BRANCH_STREAMS = os.environ.get("CVFT_BRANCH_STREAMS", "1") != "0"      # LLM branch on a second stream (joint mode): 35.9 -> 30.1 ms/step
 
@@ -149,7 +151,10 @@ class JointLLMFlowModel(nn.Module):
         B = batch['speech_token'].shape[0]
         parts = {}
         for kind in ('llm', 'flow'):
-            n = SPLIT[kind] if split and B >= SPLIT[kind] * SPLIT_MIN_PART else 1
+            runs = self.training_mode in ('joint', f'{kind}_only')          # a branch the mode does not run is never split
+            n = SPLIT_LLM_ONLY if (kind == 'llm' and self.training_mode == 'llm_only') else SPLIT[kind]
+            if not (split and runs) or B < n * SPLIT_MIN_PART:
+                n = 1
             parts[kind] = self._split_parts(batch, device, n, kind, lm_pad) if n > 1 else [dict(whole, _w_llm=1.0, _w_flow=1.0)]
         return parts
 
