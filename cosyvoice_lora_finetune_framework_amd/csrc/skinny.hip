@@ -113,17 +113,24 @@ int skinny_launch(const GP<bf16_t>& p, hipStream_t st) {
 // ------------------------------------------------------------------------------
 // SHARED: every rank tile uses the mask of site 0 (ONE adapter of rank 16*RB, e.g. r = 64 of BASELINE configs[4]): the mask
 // is derived once per fragment instead of once per rank tile, and drop(X) is written once (xd0).
-template <int RB, int MT, int KS, bool SHARED = false>
+// LN: X is the INPUT of a LayerNorm (encoder_layer.py:90-104, matcha transformer.py:255-316 pre-norm blocks) whose output
+// feeds this adapter: the block owns whole rows (its 8 waves split K), so the row statistics are two LDS reductions away --
+// the kernel normalises its fragments in registers (two-pass statistics like ln_fwd_kernel), writes Y = LN(X) for the main
+// GEMM plus mean / rstd for the LayerNorm backward, and carries on with the masked product on Y.  One launch instead of
+// LayerNorm + rank-side product, and LN(X) is not read back.  Needs the wave's whole K slice in one pass (K <= 256 * KS).
+struct LnArgs { const float* gamma; const float* beta; float eps; bf16_t* Y; float* mean; float* rstd; };
+template <int RB, int MT, int KS, bool SHARED = false, bool LN = false>
 __global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const bf16_t* __restrict__ X, int ldx,
                                                              const bf16_t* __restrict__ A, int lda, float alpha,
                                                              bf16_t* __restrict__ C, int ldc, float p,
                                                              const long long* __restrict__ seed, uint4 sites,
                                                              bf16_t* __restrict__ xd0, bf16_t* __restrict__ xd1,
-                                                             bf16_t* __restrict__ xd2) {
+                                                             bf16_t* __restrict__ xd2, LnArgs ln) {
     // xd0..2 (optional, one per rank tile / mask site): the dropped input drop_t(X) = keep_t * X / (1 - p) is also written
     // out, [M][K] each -- the backward pass needs it for dA_t = V_t^T drop_t(X) and would otherwise re-derive it in a pass
     // of its own (one launch per adapter per step)
     __shared__ __attribute__((aligned(16))) float red[4][MT][RB][16][17];
+    __shared__ float lnred[2][8][MT][16];
     bf16_t* const xd[3] = {xd0, xd1, xd2};
     const float inv_keep = 1.f / (1.f - p);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
@@ -148,7 +155,8 @@ __global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const
         xp[t] = X + (size_t)rows[t] * ldx + kg * 8;
     }
     const bf16_t* ap = A + (size_t)l15 * lda + kg * 8;
-    for (int k0 = kb; k0 < ke; k0 += 32 * KS) {
+    // LN: exactly one pass, taken by every wave (also one whose K slice is empty: it still meets the barriers)
+    for (int k0 = kb, pass = 0; LN ? pass < 1 : k0 < ke; k0 += 32 * KS, ++pass) {
         uint4 xv[KS][MT], av[KS][RB];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -157,6 +165,79 @@ __global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const
             for (int t = 0; t < MT; ++t) xv[s][t] = *reinterpret_cast<const uint4*>(xp[t] + k);
 #pragma unroll
             for (int j = 0; j < RB; ++j) av[s][j] = *reinterpret_cast<const uint4*>(ap + (size_t)j * 16 * lda + k);
+        }
+        if constexpr (LN) {
+            float4 gv[KS][2], bv[KS][2];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int k = min(k0 + 32 * s, K - 32) + kg * 8;
+                gv[s][0] = *reinterpret_cast<const float4*>(ln.gamma + k); gv[s][1] = *reinterpret_cast<const float4*>(ln.gamma + k + 4);
+                bv[s][0] = *reinterpret_cast<const float4*>(ln.beta + k); bv[s][1] = *reinterpret_cast<const float4*>(ln.beta + k + 4);
+            }
+            float mu[MT], rs[MT];
+            // pass 1: mean.  lane (kg, l15) holds 8 consecutive k of row l15 per k-step; the 4 kg lanes, then the 8 waves
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                float sm = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    if (k0 + 32 * s < ke) {
+                        const bf16x8 v = *reinterpret_cast<const bf16x8*>(&xv[s][t]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sm += (float)v[e];
+                    }
+                sm += __shfl_xor(sm, 16);
+                sm += __shfl_xor(sm, 32);
+                if (kg == 0) lnred[0][w][t][l15] = sm;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                float sm = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) sm += lnred[0][ww][t][l15];
+                mu[t] = sm / (float)K;
+            }
+            // pass 2: centred variance
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                float sq = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    if (k0 + 32 * s < ke) {
+                        const bf16x8 v = *reinterpret_cast<const bf16x8*>(&xv[s][t]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - mu[t]; sq += d * d; }
+                    }
+                sq += __shfl_xor(sq, 16);
+                sq += __shfl_xor(sq, 32);
+                if (kg == 0) lnred[1][w][t][l15] = sq;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                float sq = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) sq += lnred[1][ww][t][l15];
+                rs[t] = 1.0f / sqrtf(sq / (float)K + ln.eps);
+                if (w == 0 && kg == 0 && m0 + t * 16 + l15 < M) { ln.mean[rows[t]] = mu[t]; ln.rstd[rows[t]] = rs[t]; }
+            }
+            // normalise in place (what the main GEMM reads is exactly what the masked product sees) and publish Y
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int k = min(k0 + 32 * s, K - 32) + kg * 8;
+                const float g[8] = {gv[s][0].x, gv[s][0].y, gv[s][0].z, gv[s][0].w, gv[s][1].x, gv[s][1].y, gv[s][1].z, gv[s][1].w};
+                const float b[8] = {bv[s][0].x, bv[s][0].y, bv[s][0].z, bv[s][0].w, bv[s][1].x, bv[s][1].y, bv[s][1].z, bv[s][1].w};
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(&xv[s][t]);
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(((float)v[e] - mu[t]) * rs[t] * g[e] + b[e]);
+                    xv[s][t] = *reinterpret_cast<const uint4*>(&o);
+                    if (k0 + 32 * s < ke && m0 + t * 16 + l15 < M) *reinterpret_cast<bf16x8*>(ln.Y + (size_t)rows[t] * K + k) = o;
+                }
+            }
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -248,9 +329,10 @@ extern "C" int cvft_skinny_dropout(int M, int K, int R, const void* X, int ldx, 
     const int ksteps_per_wave = (K / 32 + 7) / 8;
     uint4 st = make_uint4(sites[0], nt > 1 ? sites[1] : 0u, nt > 2 ? sites[2] : 0u, nt > 3 ? sites[3] : 0u);
     const bool per_tile = !shared;
+    const LnArgs noln = {nullptr, nullptr, 0.f, nullptr, nullptr, nullptr};
 #define SKD_LAUNCH(RBv, KSv, SHv) hipLaunchKernelGGL((skinny_dropout_kernel<RBv, MT, KSv, SHv>), grid, dim3(512), 0, (hipStream_t)stream, M, K, \
                                                 (const bf16_t*)X, ldx, (const bf16_t*)A, lda, alpha, (bf16_t*)C, ldc, p, (const long long*)seed, st, \
-                                                (bf16_t*)(xd ? xd[0] : nullptr), (bf16_t*)(xd && per_tile ? xd[1] : nullptr), (bf16_t*)(xd && per_tile ? xd[2] : nullptr))
+                                                (bf16_t*)(xd ? xd[0] : nullptr), (bf16_t*)(xd && per_tile ? xd[1] : nullptr), (bf16_t*)(xd && per_tile ? xd[2] : nullptr), noln)
     const bool k2 = ksteps_per_wave >= 2;
     if (R == 16) { if (k2) SKD_LAUNCH(1, 2, false); else SKD_LAUNCH(1, 1, false); }
     else if (per_tile) { if (k2) SKD_LAUNCH(3, 2, false); else SKD_LAUNCH(3, 1, false); }
@@ -259,5 +341,35 @@ extern "C" int cvft_skinny_dropout(int M, int K, int R, const void* X, int ldx, 
     else { if (k2) SKD_LAUNCH(4, 2, true); else SKD_LAUNCH(4, 1, true); }
 #undef SKD_LAUNCH
     CVFT_LAUNCH_CHECK("cvft_skinny_dropout");
+    return 0;
+}
+
+// LayerNorm + the dropped rank-side product of its output in ONE launch (see skinny_dropout_kernel, LN):
+//   Y = LN(X) (bf16), mean / rstd [M] (fp32, for cvft_layernorm_bwd), U = alpha / (1 - p) * drop_t(Y) A_t^T, xd[t] = drop_t(Y)
+extern "C" int cvft_ln_skinny_dropout(int M, int K, int R, const void* X, const float* gamma, const float* beta, float eps, void* Y,
+                                      float* mean, float* rstd, const void* A, int lda, float alpha, void* U, int ldu, float p,
+                                      const int64_t* seed, const unsigned* sites, void* const* xd, void* stream) {
+    CVFT_CHECK_ARG(M > 0 && K >= 32 && K % 32 == 0 && K <= 1024 && (R == 16 || R == 48) && X && gamma && beta && Y && mean && rstd && A && U &&
+                   seed && sites && lda >= K && ldu >= R && p > 0.f && p < 1.f && lda % 8 == 0 &&
+                   (((uintptr_t)X | (uintptr_t)A | (uintptr_t)Y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
+                   "cvft_ln_skinny_dropout: bad args (bf16 contiguous rows, K %% 32 == 0, K <= 1024, R in {16, 48}, 16-byte aligned operands)");
+    const int nt = R / 16;
+    bool shared = true;
+    for (int t = 1; t < nt; ++t) shared = shared && sites[t] == sites[0];
+    CVFT_CHECK_ARG(nt == 1 || !shared, "cvft_ln_skinny_dropout: R = 48 is the stacked q|k|v form (three distinct mask sites)");
+    constexpr int MT = 2;
+    dim3 grid((M + 16 * MT - 1) / (16 * MT));
+    const int ksteps_per_wave = (K / 32 + 7) / 8;              // 1 .. 4: the wave's whole K slice stays in registers
+    uint4 st = make_uint4(sites[0], nt > 1 ? sites[1] : 0u, nt > 2 ? sites[2] : 0u, 0u);
+    const LnArgs ln = {gamma, beta, eps, (bf16_t*)Y, mean, rstd};
+#define LSK_LAUNCH(RBv, KSv) hipLaunchKernelGGL((skinny_dropout_kernel<RBv, MT, KSv, false, true>), grid, dim3(512), 0, (hipStream_t)stream, M, K, \
+                                           (const bf16_t*)X, K, (const bf16_t*)A, lda, alpha, (bf16_t*)U, ldu, p, (const long long*)seed, st,      \
+                                           (bf16_t*)(xd ? xd[0] : nullptr), (bf16_t*)(xd && nt > 1 ? xd[1] : nullptr),                          \
+                                           (bf16_t*)(xd && nt > 1 ? xd[2] : nullptr), ln)
+#define LSK_KS(RBv) do { if (ksteps_per_wave <= 1) LSK_LAUNCH(RBv, 1); else if (ksteps_per_wave == 2) LSK_LAUNCH(RBv, 2); else LSK_LAUNCH(RBv, 4); } while (0)
+    if (R == 16) LSK_KS(1); else LSK_KS(3);
+#undef LSK_KS
+#undef LSK_LAUNCH
+    CVFT_LAUNCH_CHECK("cvft_ln_skinny_dropout");
     return 0;
 }

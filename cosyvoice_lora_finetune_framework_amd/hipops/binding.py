@@ -94,6 +94,7 @@ SIGNATURES = {
     "cvft_dropout_add": [_i, _i64, _p, _p, _p, _f, _p, C.c_uint, _p],
     "cvft_act_dropout": [_i, _i64, _i, _p, _p, _p, _f, _p, C.c_uint, _p],
     "cvft_skinny_dropout": [_i, _i, _i, _p, _i, _p, _i, _f, _p, _i, _f, _p, _p, _p, _p],
+    "cvft_ln_skinny_dropout": [_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _i, _f, _p, _i, _f, _p, _p, _p, _p],
     "cvft_lora_side_dgrad": [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f, _p, _p, _p],
     "cvft_cfm_prepare": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p],
     "cvft_masked_mse_fwd": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p],

@@ -315,6 +315,57 @@ def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
 _DROPPED = {}       # mask site -> drop(x) written by the forward skinny kernel, consumed by that adapter's backward (dA = V^T drop(x))
 
 
+_PRE_U = {}        # LN output data_ptr -> (U, A data_ptr, alpha, p, sites): the rank-side product the LayerNorm launch already made
+
+
+def take_pre_u(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, nsites: int):
+    """(U, sites) that cvft_ln_skinny_dropout produced together with x = LN(.) for exactly this adapter, else None."""
+    ent = _PRE_U.pop(x.data_ptr(), None)
+    if ent is None:
+        return None
+    U, a_ptr, al, pp, sites, shape = ent
+    if a_ptr == A.data_ptr() and al == float(alpha) and pp == float(p) and len(sites) == nsites and shape == tuple(x.shape):
+        return U, sites
+    for st in sites:                      # not the adapter it was made for: forget it and its dropped copies
+        _DROPPED.pop(st, None)
+    return None
+
+
+def drop_pre_u(x: torch.Tensor) -> None:
+    """forget a hand-off nobody took (the adapter went down another path after all)"""
+    ent = _PRE_U.pop(x.data_ptr(), None)
+    if ent is not None:
+        for st in ent[4]:
+            _DROPPED.pop(st, None)
+
+
+def ln_skinny_dropout(x: torch.Tensor, gamma, beta, eps: float, A: torch.Tensor, alpha: float, p: float, nsites: int):
+    """(y, mean, rstd) = LayerNorm(x) and, from the same launch, U = alpha * drop_t(y) A_t^T with the dropped copies kept for
+    backward; U is parked in _PRE_U under y's address for the adapter Function that consumes y (take_pre_u)."""
+    M, K = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    U = torch.empty((M, A.shape[0]), dtype=x.dtype, device=x.device)
+    sites = [_next_drop_site() for _ in range(nsites)]
+    outs = [torch.empty_like(x) for _ in sites]
+    for st, t in zip(sites, outs):
+        _DROPPED[st] = t
+    xd = (C.c_void_p * 3)(*([t.data_ptr() for t in outs] + [None] * (3 - len(outs))))
+    check(lib().cvft_ln_skinny_dropout(M, K, A.shape[0], ptr(x), ptr(gamma), ptr(beta), float(eps), ptr(y), ptr(mean), ptr(rstd),
+                                       ptr(A), A.stride(0), float(alpha), ptr(U), U.stride(0), float(p), ptr(_DROPOUT["seed"]),
+                                       _sites_arr(sites), xd, stream()), "cvft_ln_skinny_dropout")
+    _PRE_U[y.data_ptr()] = (U, A.data_ptr(), float(alpha), float(p), sites, (M, K))
+    return y, mean, rstd
+
+
+def can_ln_skinny(x: torch.Tensor, A: torch.Tensor, gamma, beta) -> bool:
+    return (LN_SKINNY and x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and x.shape[1] % 32 == 0 and x.shape[1] <= 1024 and A.shape[0] in (16, 48) and A.stride(0) % 8 == 0
+            and A.data_ptr() % 16 == 0 and gamma.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0
+            and not gamma.requires_grad and not beta.requires_grad)
+
+
 def skinny_dropout(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, sites, keep_dropped: bool = False) -> torch.Tensor:
     """U[M, R] = alpha * drop_t(x) A_t^T per rank tile t (mask sites[t]); x bf16 contiguous [M, K], A [R, K].
     keep_dropped: the kernel also writes the dropped inputs (one per site) for the backward pass (dropped_input)."""
@@ -576,6 +627,7 @@ if _os.environ.get('CVFT_FP8', '0') == '1':
     FP8_ON = True
 STACKED_DROP_DEFER = _os.environ.get('CVFT_STACKED_DROP_DEFER', '0') != '0'
 KEEP_DROPPED = _os.environ.get('CVFT_KEEP_DROPPED', '1') != '0'   # forward writes drop(x) for the backward's dA (no re-derivation launch)
+LN_SKINNY = _os.environ.get('CVFT_LN_SKINNY', '1') != '0'    # LayerNorm launch also emits the dropped rank-side product of the adapter it feeds
 XDROP_ON = _os.environ.get('CVFT_XDROP', '1') != '0'        # lora_dropout dgrad: masked rank extension inside the GEMM launch
 SINK_PLAN_BLOCKS = int(_os.environ.get('CVFT_SINK_PLAN_BLOCKS', 512))
 SINK_DEFER = _os.environ.get('CVFT_SINK_DEFER', '1') != '0'
@@ -638,7 +690,12 @@ def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residu
         ops = (Ac, At, Bc, Bt)
         fused = drop is None and _can_fuse(x, Ac, Bc, pack.N, pack.K)
         if drop is not None:              # lora_dropout: the side path sees drop(x); mask applied inside the skinny kernel
-            U = skinny_dropout(x, Ac, scale, drop[0], [drop[1]], keep_dropped=True)
+            pre = take_pre_u(x, Ac, scale, drop[0], 1)        # made by the LayerNorm launch that produced x?
+            if pre is not None:
+                U = pre[0]
+                drop[1] = pre[1][0]                           # its mask site replaces the one the caller drew
+            else:
+                U = skinny_dropout(x, Ac, scale, drop[0], [drop[1]], keep_dropped=True)
         elif fused:
             U = torch.empty((x.shape[0], Ac.shape[0]), dtype=x.dtype, device=x.device)
         else:
@@ -750,7 +807,7 @@ class LinearFn(torch.autograd.Function):
         x = _c(x)
         need_grad = any(ctx.needs_input_grad[:3])
         ctx.padded = False
-        ctx.drop = (float(drop_p), _next_drop_site()) if (drop_p > 0 and A is not None) else None
+        ctx.drop = [float(drop_p), _next_drop_site()] if (drop_p > 0 and A is not None) else None
         if A is None and act is None and residual is None and pack.Npad != pack.N:
             Wf, bias, _ = pack.padded
             y = gemm(x, Wf, bias=bias)                                  # [M][Npad], pad columns exactly zero
@@ -837,9 +894,15 @@ class LinearQKVStackedFn(torch.autograd.Function):
     def forward(ctx, x, Aq, Bq, Ak, Bk, Av, Bv, wstack: QKVStack, ops, scale: float, drop_p: float = 0.0):
         x = _c(x)
         A, At, Bb, Bbt = ops
-        ctx.drop = (float(drop_p), [_next_drop_site() for _ in range(3)]) if drop_p > 0 else None
-        if ctx.drop is not None:          # lora_dropout: three mask sites (each LoRALinear owns its nn.Dropout)
-            U = skinny_dropout(x, A, scale, ctx.drop[0], ctx.drop[1], keep_dropped=True)
+        ctx.drop = None
+        if drop_p > 0:                    # lora_dropout: three mask sites (each LoRALinear owns its nn.Dropout)
+            pre = take_pre_u(x, A, scale, drop_p, 3)          # made by the LayerNorm launch that produced x?
+            if pre is not None:
+                U, sites = pre
+            else:
+                sites = [_next_drop_site() for _ in range(3)]
+                U = skinny_dropout(x, A, scale, float(drop_p), sites, keep_dropped=True)
+            ctx.drop = (float(drop_p), sites)
             Y = gemm(x, wstack.Wf, bias=wstack.bias, U=U, Bl=Bb)
         elif QKV_FUSE_SIDE and x.shape[1] % 64 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
             U = torch.empty((x.shape[0], A.shape[0]), dtype=x.dtype, device=x.device)     # [M, 3r], written by the launch
@@ -964,8 +1027,8 @@ class FeedForwardFn(torch.autograd.Function):
     def forward(ctx, x, A1, B1, A2, B2, residual, pack1, pack2, s1: float, s2: float, act: str, p1: float = 0.0, p2: float = 0.0):
         x = _c(x)
         need_grad = any(ctx.needs_input_grad[:5])
-        ctx.drops = ((float(p1), _next_drop_site()) if (p1 > 0 and A1 is not None) else None,
-                     (float(p2), _next_drop_site()) if (p2 > 0 and A2 is not None) else None)
+        ctx.drops = ([float(p1), _next_drop_site()] if (p1 > 0 and A1 is not None) else None,
+                     [float(p2), _next_drop_site()] if (p2 > 0 and A2 is not None) else None)
         h, U1, z, ops1 = _lin_fwd(x, A1, B1, pack1, s1, act, None, need_grad, ctx.drops[0])
         y, U2, _, ops2 = _lin_fwd(h, A2, B2, pack2, s2, None, residual, False, ctx.drops[1])
         ctx.cfg = (pack1, pack2, s1, s2, act, ops1, ops2, (A1, B1), (A2, B2))
@@ -1211,14 +1274,17 @@ class LayerNormForkFn(torch.autograd.Function):
     backward plus an autograd accumulation add."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float):
+    def forward(ctx, x, gamma, beta, eps: float, side=None):
         x = _c(x)
         rows, Cn = x.shape
-        y = torch.empty_like(x)
-        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        check(lib().cvft_layernorm_fwd(dt(x), rows, Cn, ptr(x), ptr(gamma), ptr(beta), eps, 0, 1.0,
-                                       ptr(y), ptr(mean), ptr(rstd), stream()), "cvft_layernorm_fwd")
+        if side is not None:                  # (A [R, K] compute dtype, alpha, p, nsites): the adapter that will read y
+            y, mean, rstd = ln_skinny_dropout(x, gamma, beta, eps, *side)
+        else:
+            y = torch.empty_like(x)
+            mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+            check(lib().cvft_layernorm_fwd(dt(x), rows, Cn, ptr(x), ptr(gamma), ptr(beta), eps, 0, 1.0,
+                                           ptr(y), ptr(mean), ptr(rstd), stream()), "cvft_layernorm_fwd")
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         return x.view_as(x), y
 
@@ -1226,18 +1292,20 @@ class LayerNormForkFn(torch.autograd.Function):
     def backward(ctx, dres, dy):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         if dy is None:
-            return dres, None, None, None
+            return dres, None, None, None, None
         dy = _c(dy)
         dres = None if dres is None else _c(dres)
         dx = torch.empty_like(x)
         check(lib().cvft_layernorm_bwd(dt(x), x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                        0, 1.0, ptr(dy), ptr(dres), ptr(dx), stream()), "cvft_layernorm_bwd")
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def layernorm_fork(x, gamma, beta, eps: float = 1e-5):
-    """-> (x_residual, LN(x)); use x_residual (not x) for the residual connection."""
-    return LayerNormForkFn.apply(x, gamma, beta, eps)
+def layernorm_fork(x, gamma, beta, eps: float = 1e-5, side=None):
+    """-> (x_residual, LN(x)); use x_residual (not x) for the residual connection.
+    side = (A [R, K], alpha, p, nsites): y feeds a LoRA adapter under lora_dropout -- its rank-side product comes out of
+    the same launch (ln_skinny_dropout) and waits in _PRE_U for that adapter's Function."""
+    return LayerNormForkFn.apply(x, gamma, beta, eps, side)
 
 
 class GroupNormMishFn(torch.autograd.Function):

@@ -83,7 +83,9 @@ def hip_linear(mod: nn.Module, x: torch.Tensor, dtype: Optional[torch.dtype] = N
         # reference lora.py:70: dropout on the side-path input only.  Fused form (mask inside the rank-side kernels,
         # counter-based) when the shapes allow, else nn.Dropout + separate side-path launches
         if type(drop) is nn.Dropout and HF._can_drop_fuse(x, A.shape[0]):
-            return HF.lora_linear(x, pack, A, Bm, scale, act, residual, drop_p=drop.p)
+            y = HF.lora_linear(x, pack, A, Bm, scale, act, residual, drop_p=drop.p)
+            HF.drop_pre_u(x)                                 # (a hand-off from the LayerNorm launch nobody took is dropped here)
+            return y
         return _lora_dropout_path(x, pack, A, Bm, scale, drop, act, residual)
     return HF.lora_linear(x, pack, A, Bm, scale, act, residual)
 
@@ -101,6 +103,7 @@ def hip_qkv(mq: nn.Module, mk: nn.Module, mv: nn.Module, x: torch.Tensor):
         out = None
         if drops[0] == drops[1] == drops[2] and all(type(p[6]) is nn.Dropout for p in parts):
             out = HF.lora_linear_qkv(x, packs, [(p[3], p[4]) for p in parts], [p[5] for p in parts], drop_p=drops[0])
+        HF.drop_pre_u(x)                                     # (a hand-off from the LayerNorm launch nobody took is dropped here)
         return out if out is not None else (hip_linear(mq, x), hip_linear(mk, x), hip_linear(mv, x))
     return HF.lora_linear_qkv(x, packs, [(p[3], p[4]) for p in parts], [p[5] for p in parts])
 
@@ -146,9 +149,35 @@ def hip_layernorm(ln: nn.LayerNorm, x, eps: Optional[float] = None, relu=False, 
     return HF.layernorm(x, _f32(ln.weight), _f32(ln.bias), ln.eps if eps is None else eps, relu, post_scale)
 
 
-def hip_layernorm_fork(ln: nn.LayerNorm, x, eps: Optional[float] = None):
-    """-> (x_residual, LN(x)) for pre-norm residual blocks: the two gradient branches of x meet in one kernel."""
-    return HF.layernorm_fork(x, _f32(ln.weight), _f32(ln.bias), ln.eps if eps is None else eps)
+def hip_layernorm_fork(ln: nn.LayerNorm, x, eps: Optional[float] = None, consumers=None):
+    """-> (x_residual, LN(x)) for pre-norm residual blocks: the two gradient branches of x meet in one kernel.
+    consumers: the LoRA module(s) LN(x) goes to next -- (linear_q, linear_k, linear_v) or (w_1,).  When they are about to take
+    the fused lora_dropout path (hip_qkv / hip_linear below), the LayerNorm launch also emits their rank-side product
+    U = s drop(LN(x)) A^T and the dropped copies (cvft_ln_skinny_dropout): one launch less per adapter and step."""
+    g, b, e = _f32(ln.weight), _f32(ln.bias), ln.eps if eps is None else eps
+    side = _ln_side(x, g, b, consumers) if consumers is not None else None
+    return HF.layernorm_fork(x, g, b, e, side)
+
+
+def _ln_side(x, g, b, mods):
+    """(A operand, scale, p, nsites) when `mods` will run HF.skinny_dropout on LN(x) with exactly these operands (the
+    conditions of hip_qkv's stacked path / hip_linear's fused-dropout path), else None."""
+    parts = [_lin_parts(m) for m in mods]
+    if any(p[3] is None or not _lora_dropout_on(m, p[6]) or type(p[6]) is not nn.Dropout for m, p in zip(mods, parts)):
+        return None
+    if len(mods) == 3:
+        if not (parts[0][6].p == parts[1][6].p == parts[2][6].p) or not HF._can_drop_fuse(x, 48):
+            return None
+        packs = [_cached(p[0], "lin", p[0].weight, x.dtype, lambda p=p: HF.LinearPack(p[1], p[2], x.dtype)) for p in parts]
+        st = HF._qkv_stacked_operands(x, packs, [(p[3], p[4]) for p in parts], [p[5] for p in parts])
+        if st is None:
+            return None
+        A, scale, nsites = st[1][0], parts[0][5], 3
+    else:
+        if not HF._can_drop_fuse(x, parts[0][3].shape[0]):
+            return None
+        A, scale, nsites = HF._lora_operands(parts[0][3], x.dtype)[0], parts[0][5], 1
+    return (A, scale, parts[0][6].p, nsites) if HF.can_ln_skinny(x, A, g, b) else None
 
 
 def to_len(lens: torch.Tensor, device) -> torch.Tensor:
@@ -282,7 +311,7 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, B, T, length, gelu: str, iso_len: int = 0):
         a = self.attn1
-        x, y = hip_layernorm_fork(self.norm1, x)
+        x, y = hip_layernorm_fork(self.norm1, x, consumers=(a.to_q, a.to_k, a.to_v))
         q, k, v = hip_qkv(a.to_q, a.to_k, a.to_v, y)
         o = HF.attn_bias(q, k, v, B, a.heads, T, length, a.scale, iso_len)
         x = hip_linear(a.to_out[0], o, residual=x)
@@ -531,9 +560,10 @@ class EncoderLayer(nn.Module):
     def forward(self, x, pos_emb, B, L, length, causal, eps):
         n_att, n_ff = (self.norm_mha, self.norm_ff) if self.conformer else (self.norm1, self.norm2)
         pd = self.dropout_rate if self.training else 0.0
-        x, y = hip_layernorm_fork(n_att, x, eps)
+        at, ff = self.self_attn, self.feed_forward
+        x, y = hip_layernorm_fork(n_att, x, eps, consumers=(at.linear_q, at.linear_k, at.linear_v))
         x = self.self_attn(y, x, pos_emb, B, L, length, causal, out_dropout=pd)
-        x, y = hip_layernorm_fork(n_ff, x, eps)
+        x, y = hip_layernorm_fork(n_ff, x, eps, consumers=(ff.w_1,) if self.training else None)
         return self.feed_forward(y, x, out_dropout=pd)
 
 

@@ -259,6 +259,15 @@ int cvft_act_dropout(int dtype, int64_t n, int act, const void* z, const void* d
  *   cvft_lora_side_dgrad: out[m,k] = dx[m,k] + sum_t keep_t(m,k)/(1-p) * sum_j V[m,16t+j] A[16t+j][k] */
 int cvft_skinny_dropout(int M, int K, int R, const void* X, int ldx, const void* A, int lda, float alpha, void* C, int ldc,
                         float p, const int64_t* seed, const unsigned* sites, void* const* xd, void* stream);
+/* LayerNorm + that product in ONE launch, for a pre-norm block whose normalised input feeds a LoRA adapter with lora_dropout
+ * (encoder_layer.py:90-104 norm -> linear_q|k|v / w_1; matcha transformer.py:255-316 norm1 -> to_q|k|v):
+ *   Y = LN(X) = (X - mean) * rstd * gamma + beta   (bf16, two-pass fp32 statistics; what the main GEMM then reads)
+ *   mean, rstd [M] fp32                              (saved for cvft_layernorm_bwd)
+ *   U = alpha / (1 - p) * drop_t(Y) A_t^T, xd[t] = drop_t(Y)   exactly as cvft_skinny_dropout(Y, ...)
+ * X, Y contiguous [M][K] bf16; K % 32 == 0, K <= 1024; R = 16 (one site) or 48 (stacked q|k|v, three sites). */
+int cvft_ln_skinny_dropout(int M, int K, int R, const void* X, const float* gamma, const float* beta, float eps, void* Y,
+                           float* mean, float* rstd, const void* A, int lda, float alpha, void* U, int ldu, float p,
+                           const int64_t* seed, const unsigned* sites, void* const* xd /*[3] or NULL*/, void* stream);
 int cvft_lora_side_dgrad(int M, int K, int R, const void* V, int ldv, const void* A, int lda, const void* dx, int ldi,
                          void* out, int ldo, float p, const int64_t* seed, const unsigned* sites, void* stream);
 /* CFM prepare (flow_matching.py:173-186 == flow_model.py:143-161), channel-last:

@@ -831,6 +831,39 @@ def test_qkv_stacked_lora_dropout_matches_torch():
     assert rel(x.grad.float(), xf.grad) < 3e-2
 
 
+@pytest.mark.parametrize("M,K,R,nsites", [(4000, 256, 48, 3), (5376, 1024, 48, 3), (5376, 1024, 16, 1), (1000, 512, 16, 1),
+                                          (333, 320, 16, 1), (77, 64, 48, 3)])
+def test_layernorm_with_rank_side_product(M, K, R, nsites):
+    """cvft_ln_skinny_dropout: LayerNorm and the dropped rank-side product of its output in one launch -- against the two
+    launches it replaces (cvft_layernorm_fwd, then cvft_skinny_dropout on the same y with the same mask sites).  Covers the
+    1 / 2 / 4 k-step instantiations, a K whose last waves have an empty slice (320), a partial last row block."""
+    HF = HFmod()
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * 2.0 + 0.5).to(DEV, torch.bfloat16)
+    gamma = (1.0 + 0.2 * torch.randn(K, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(K, generator=g)).to(DEV)
+    A = (torch.randn(R, K, generator=g) / math.sqrt(K)).to(DEV, torch.bfloat16)
+    alpha, pdrop, eps = 2.0, 0.15, 1e-5
+    HF.dropout_begin_step()
+    assert HF.can_ln_skinny(x, A, gamma, beta)
+    y, mean, rstd = HF.ln_skinny_dropout(x, gamma, beta, eps, A, alpha, pdrop, nsites)
+    U, sites = HF.take_pre_u(y, A, alpha, pdrop, nsites)
+    xd = [HF._DROPPED.pop(st) for st in sites]
+    # LayerNorm part: the stand-alone kernel (different reduction order: allow one bf16 ulp on y)
+    y_ref = HF.layernorm(x, gamma, beta, eps)
+    xf = x.float()
+    mu_ref = xf.mean(1)
+    rs_ref = 1.0 / torch.sqrt(xf.var(1, unbiased=False) + eps)
+    assert rel(mean, mu_ref) < 1e-5 and rel(rstd, rs_ref) < 1e-5
+    assert (y.float() - y_ref.float()).abs().max() <= 2.0 ** -7 * y_ref.float().abs().max()
+    assert (y != y_ref).float().mean() < 0.02
+    # rank-side part: bit-identical to the stand-alone kernel on the same y and mask sites
+    U_ref = HF.skinny_dropout(y, A, alpha, pdrop, list(sites), keep_dropped=True)
+    assert torch.equal(U, U_ref)
+    for st, t in zip(sites, xd):
+        assert torch.equal(t, HF._DROPPED.pop(st))
+
+
 @pytest.mark.parametrize("M,N,K,R", [(300, 128, 192, 16), (1000, 256, 1536, 48), (5328, 1024, 1024, 16), (2056, 520, 256, 64)])
 def test_gemm_masked_rank_extension(M, N, K, R):
     """cvft_gemm with xdrop (the lora_dropout dgrad inside the GEMM launch): C = A W^T + sum_t mask_t/(1-p) * (U_t Bl_t^T) with
