@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--dropout", type=int, default=1, help="1 (default) = train() mode with all of the reference's training dropouts (LoRA 0.15 / 0.05, encoder 0.1), as trainer.fit runs the step; 0 = eval() mode, dropout off, like the parity fixtures; 2 / 3 = LoRA / encoder dropouts only (diagnostic)")
     ap.add_argument("--fp8", type=int, default=0, help="1 = BASELINE configs[4] arithmetic: the frozen-W GEMMs of the LLM-sized linears in OCP e4m3 (per-token / per-channel scales); LoRA path, reductions and everything else stay bf16 / fp32")
     ap.add_argument("--via-trainer", type=int, default=1, help="1 (default) = time the steps inside train_joint.Trainer.fit (fresh host batch every step: index maps + H2D copies + the trainer's captured micro-step graph + all-reduce + clip + AdamW) ; 0 = replay one pre-staged batch (no trainer, no per-step host work)")
-    ap.add_argument("--ragged", type=int, default=0, help="--via-trainer: utterance lengths uniform in [0.6 T, T] (one utterance keeps T)")
+    ap.add_argument("--ragged", type=int, default=0, help="--via-trainer: 1 = utterance lengths uniform in [0.6 T, T], one utterance keeps T (one batch layout); 2 = none pinned: every batch has its own T_max / Lt_max and the trainer fits it to a captured layout (SHAPE_SLACK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -217,13 +217,13 @@ def main():
         # from the trainer's per-step hook (barrier + synchronize on both sides, like the direct mode below)
         from cosyvoice_lora_finetune_framework_amd.modules import Numerics
         from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, SyntheticLoader, Trainer
-        if a.warmup < 2:
-            log("[bench] --via-trainer captures a batch shape the second time it is seen: raising --warmup to 2")
-            a.warmup = 2
+        if a.warmup < 1:
+            log("[bench] --via-trainer captures the batch layout in its first step: raising --warmup to 1")
+            a.warmup = 1
         module = JointLightningModule(a.workload, learning_rate=2e-4, min_lr=1e-6, warmup_steps=10, weight_decay=0.01,
                                       model=jm, numerics=Numerics(dtype=dtype))
         torch.set_num_threads(min(host_cores(), 16))
-        loader = SyntheticLoader(a.warmup + a.steps, B, T, seed=1234, ragged=bool(a.ragged), rank=rank, cache=True)
+        loader = SyntheticLoader(a.warmup + a.steps, B, T, seed=1234, ragged=a.ragged, rank=rank, cache=True)
         marks = {}
 
         def hook(tr):
@@ -393,7 +393,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "frames": T, "lora_r": a.rank_lora,
                        "parallelism": f"dp{world}", "launch": ("Trainer.fit + " if a.via_trainer else "") + ("hipGraph" if graph is not None else "eager"),
                        "dropout": bool(a.dropout), "final_loss": final_loss,
-                       **({"trainer": trainer_stats, "ragged": bool(a.ragged)} if a.via_trainer else {})},
+                       **({"trainer": trainer_stats, "ragged": a.ragged} if a.via_trainer else {})},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -291,40 +291,48 @@ __device__ __forceinline__ void interp_src(int j, float scale, int Lin, int& i0,
     w0 = 1.f - w1;
 }
 template <typename T>
-__global__ void interp_fwd_kernel(int B, int Lin, int Lout, int C, const T* __restrict__ x, T* __restrict__ y) {
+__global__ void interp_fwd_kernel(int B, int Lin, int Lout, int C, const T* __restrict__ x, T* __restrict__ y,
+                                  const int* __restrict__ eff) {
+    // eff (cvft.h): the exact-shape batch's (Lin, Lout) when the tensors are padded to buckets -- they set the scale and
+    // the clamp; the tensor dims only the strides
     const size_t total = (size_t)B * Lout * C;
-    const float scale = (float)Lin / (float)Lout;
+    const int Li = eff ? min(eff[0], Lin) : Lin, Lo = eff ? min(eff[1], Lout) : Lout;
+    const float scale = (float)Li / (float)Lo;
     EW_LOOP(i, total) {
         int c = (int)(i % C);
         size_t bj = i / C;
         int j = (int)(bj % Lout), b = (int)(bj / Lout);
+        if (j >= Lo) { y[i] = from_f32<T>(0.f); continue; }
         int i0, i1;
         float w0, w1;
-        interp_src(j, scale, Lin, i0, i1, w0, w1);
+        interp_src(j, scale, Li, i0, i1, w0, w1);
         const T* xb = x + (size_t)b * Lin * C;
         y[i] = from_f32<T>(w0 * to_f32(xb[(size_t)i0 * C + c]) + w1 * to_f32(xb[(size_t)i1 * C + c]));
     }
 }
 template <typename T>
-__global__ void interp_bwd_kernel(int B, int Lin, int Lout, int C, const T* __restrict__ dy, T* __restrict__ dx) {
+__global__ void interp_bwd_kernel(int B, int Lin, int Lout, int C, const T* __restrict__ dy, T* __restrict__ dx,
+                                  const int* __restrict__ eff) {
     const size_t total = (size_t)B * Lin * C;
-    const float scale = (float)Lin / (float)Lout;
-    const float inv = (float)Lout / (float)Lin;
+    const int Li = eff ? min(eff[0], Lin) : Lin, Lo = eff ? min(eff[1], Lout) : Lout;
+    const float scale = (float)Li / (float)Lo;
+    const float inv = (float)Lo / (float)Li;
     EW_LOOP(i, total) {
         int c = (int)(i % C);
         size_t bi = i / C;
         int ii = (int)(bi % Lin), b = (int)(bi / Lin);
+        if (ii >= Li) { dx[i] = from_f32<T>(0.f); continue; }
         // candidate outputs: src in (ii-1, ii+1)  =>  j in ((ii-0.5)*inv-0.5, (ii+1.5)*inv-0.5); widen by one
         int jlo = (int)floorf(((float)ii - 0.5f) * inv - 0.5f) - 1;
         int jhi = (int)ceilf(((float)ii + 1.5f) * inv - 0.5f) + 1;
         if (jlo < 0) jlo = 0;
-        if (jhi > Lout - 1) jhi = Lout - 1;
+        if (jhi > Lo - 1) jhi = Lo - 1;
         const T* dyb = dy + (size_t)b * Lout * C;
         float s = 0.f;
         for (int j = jlo; j <= jhi; ++j) {
             int i0, i1;
             float w0, w1;
-            interp_src(j, scale, Lin, i0, i1, w0, w1);
+            interp_src(j, scale, Li, i0, i1, w0, w1);
             float g = to_f32(dyb[(size_t)j * C + c]);
             if (i0 == ii) s += w0 * g;
             if (i1 == ii) s += w1 * g;
@@ -332,25 +340,25 @@ __global__ void interp_bwd_kernel(int B, int Lin, int Lout, int C, const T* __re
         dx[i] = from_f32<T>(s);
     }
 }
-extern "C" int cvft_interp_linear_fwd(int dtype, int B, int Lin, int Lout, int C, const void* x, void* y, void* stream) {
+extern "C" int cvft_interp_linear_fwd(int dtype, int B, int Lin, int Lout, int C, const void* x, void* y, const int32_t* eff, void* stream) {
     CHECK_DTYPE("cvft_interp_linear_fwd", dtype);
     CVFT_CHECK_ARG(B > 0 && Lin > 0 && Lout > 0 && C > 0 && x && y, "cvft_interp_linear_fwd: bad args");
     size_t total = (size_t)B * Lout * C;
     if (dtype == CVFT_F32)
-        hipLaunchKernelGGL((interp_fwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const float*)x, (float*)y);
+        hipLaunchKernelGGL((interp_fwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const float*)x, (float*)y, eff);
     else
-        hipLaunchKernelGGL((interp_fwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const bf16_t*)x, (bf16_t*)y);
+        hipLaunchKernelGGL((interp_fwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const bf16_t*)x, (bf16_t*)y, eff);
     CVFT_LAUNCH_CHECK("cvft_interp_linear_fwd");
     return 0;
 }
-extern "C" int cvft_interp_linear_bwd(int dtype, int B, int Lin, int Lout, int C, const void* dy, void* dx, void* stream) {
+extern "C" int cvft_interp_linear_bwd(int dtype, int B, int Lin, int Lout, int C, const void* dy, void* dx, const int32_t* eff, void* stream) {
     CHECK_DTYPE("cvft_interp_linear_bwd", dtype);
     CVFT_CHECK_ARG(B > 0 && Lin > 0 && Lout > 0 && C > 0 && dy && dx, "cvft_interp_linear_bwd: bad args");
     size_t total = (size_t)B * Lin * C;
     if (dtype == CVFT_F32)
-        hipLaunchKernelGGL((interp_bwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const float*)dy, (float*)dx);
+        hipLaunchKernelGGL((interp_bwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const float*)dy, (float*)dx, eff);
     else
-        hipLaunchKernelGGL((interp_bwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const bf16_t*)dy, (bf16_t*)dx);
+        hipLaunchKernelGGL((interp_bwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, Lin, Lout, C, (const bf16_t*)dy, (bf16_t*)dx, eff);
     CVFT_LAUNCH_CHECK("cvft_interp_linear_bwd");
     return 0;
 }

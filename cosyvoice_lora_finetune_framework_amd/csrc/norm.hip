@@ -213,14 +213,16 @@ extern "C" int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, con
 // each frame's Cg-channel run is read with full-width loads.
 template <typename T, bool VECP>
 __global__ void __launch_bounds__(512) gn_stats_kernel(int T_, int C, int G, const T* __restrict__ x, float eps,
-                                                        float* __restrict__ mean, float* __restrict__ rstd) {
+                                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                                        const int* __restrict__ t_eff) {
     constexpr int VEC = VECP ? 16 / sizeof(T) : 1;
     __shared__ float sm[16];
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     const int Cg = C / G, CgV = Cg / VEC;
     const T* xb = x + (size_t)b * T_ * C + g * Cg;
-    const int nch = T_ * CgV;
-    const float n = (float)T_ * (float)Cg;
+    const int Te = t_eff ? min(*t_eff, T_) : T_;                   // frames the statistics run over (cvft.h: t_eff)
+    const int nch = Te * CgV;
+    const float n = (float)Te * (float)Cg;
     float s = 0.f;
     for (int e = threadIdx.x; e < nch; e += 512) {
         const T* p = xb + (size_t)(e / CgV) * C + (e % CgV) * VEC;
@@ -261,7 +263,7 @@ __global__ void __launch_bounds__(256) gn_apply_fwd_kernel(int B, int T_, int C,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const int* __restrict__ len,
                                                             const T* __restrict__ add, int apply_mish,
-                                                            T* __restrict__ y) {
+                                                            T* __restrict__ y, const int* __restrict__ t_eff) {
     // one 16-byte chunk (VEC channels of one frame, all in one group since Cg % VEC == 0) per thread and step
     constexpr int VEC = VECP ? 16 / sizeof(T) : 1;
     const size_t total = (size_t)B * T_ * C / VEC;
@@ -272,7 +274,8 @@ __global__ void __launch_bounds__(256) gn_apply_fwd_kernel(int B, int T_, int C,
         const int t = (int)(bt % T_), b = (int)(bt / T_);
         const int sg = b * G + c0 / Cg;
         const float mu = mean[sg], rs = rstd[sg];
-        const bool dead = len && t >= len[b];
+        const bool pad = t_eff && t >= *t_eff;                     // bucket padding: no such frame in the exact-shape batch
+        const bool dead = (len && t >= len[b]) || pad;
         const size_t i = ch * VEC;
         T xv[VEC], av[VEC], ov[VEC];
         if (VECP) {
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(256) gn_apply_fwd_kernel(int B, int T_, int C,
             const float z = (to_f32(xv[k]) - mu) * rs * gamma[c] + beta[c];
             float o = apply_mish ? act_apply(CVFT_ACT_MISH, z) : z;
             if (dead) o = 0.f;
-            if (add) o += to_f32(av[k]);
+            if (add && !pad) o += to_f32(av[k]);
             ov[k] = from_f32<T>(o);
         }
         if (VECP) *reinterpret_cast<uint4*>(y + i) = *reinterpret_cast<const uint4*>(ov);
@@ -307,16 +310,17 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(int T_, int C, int G,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const int* __restrict__ len,
                                                             int apply_mish, const T* __restrict__ dy,
-                                                            float* __restrict__ ws) {
+                                                            float* __restrict__ ws, const int* __restrict__ t_eff) {
     constexpr int VEC = VECP ? 16 / sizeof(T) : 1;
     __shared__ float sm[16];
     const int sg = blockIdx.x, b = sg / G, g = sg % G, sp = blockIdx.y;
     const int Cg = C / G, CgV = Cg / VEC;
     const size_t off = (size_t)b * T_ * C + g * Cg;
-    const float n = (float)T_ * (float)Cg;
+    const int Te = t_eff ? min(*t_eff, T_) : T_;
+    const float n = (float)Te * (float)Cg;
     const float mu = mean[sg], rs = rstd[sg];
-    const int lb = len ? min(len[b], T_) : T_;                     // frames t >= len contribute nothing
-    const int tc = (T_ + CVFT_GN_SPLIT - 1) / CVFT_GN_SPLIT;
+    const int lb = len ? min(len[b], Te) : Te;                     // frames t >= len contribute nothing
+    const int tc = (Te + CVFT_GN_SPLIT - 1) / CVFT_GN_SPLIT;       // (chunks of the exact frame count: same partial sums as the exact-shape launch)
     const int t0 = sp * tc, t1 = min(lb, t0 + tc);
     const int nch = t1 > t0 ? (t1 - t0) * CgV : 0;
     float s1 = 0.f, s2 = 0.f;
@@ -357,7 +361,8 @@ __global__ void __launch_bounds__(256) gn_apply_bwd_kernel(int B, int T_, int C,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const int* __restrict__ len,
                                                             int apply_mish, const T* __restrict__ dy,
-                                                            const float* __restrict__ ws, T* __restrict__ dx) {
+                                                            const float* __restrict__ ws, T* __restrict__ dx,
+                                                            const int* __restrict__ t_eff) {
     constexpr int VEC = VECP ? 16 / sizeof(T) : 1;
     const size_t total = (size_t)B * T_ * C / VEC;
     const int Cg = C / G, CV = C / VEC;
@@ -374,7 +379,8 @@ __global__ void __launch_bounds__(256) gn_apply_bwd_kernel(int B, int T_, int C,
             w1 += pr.x;
             w2 += pr.y;
         }
-        const bool live = !len || t < len[b];
+        const bool pad = t_eff && t >= *t_eff;
+        const bool live = (!len || t < len[b]) && !pad;
         const size_t i = ch * VEC;
         T xv[VEC], dv[VEC], ov[VEC];
         if (VECP) {
@@ -394,7 +400,7 @@ __global__ void __launch_bounds__(256) gn_apply_bwd_kernel(int B, int T_, int C,
                 if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c] + beta[c]);
                 dz *= gamma[c];
             }
-            ov[k] = from_f32<T>(rs * (dz - w1 - xh * w2));
+            ov[k] = from_f32<T>(pad ? 0.f : rs * (dz - w1 - xh * w2));
         }
         if (VECP) *reinterpret_cast<uint4*>(dx + i) = *reinterpret_cast<const uint4*>(ov);
         else dx[i] = ov[0];
@@ -408,7 +414,7 @@ static inline unsigned ew_grid(size_t total) {
 
 extern "C" int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, const void* x, const float* gamma,
                                        const float* beta, float eps, const int32_t* len, const void* add,
-                                       int apply_mish, void* y, float* mean, float* rstd, void* stream) {
+                                       int apply_mish, void* y, float* mean, float* rstd, const int32_t* t_eff, void* stream) {
     CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_groupnorm_mish_fwd: bad dtype");
     CVFT_CHECK_ARG(B > 0 && T > 0 && C > 0 && G > 0 && C % G == 0, "cvft_groupnorm_mish_fwd: bad dims B%d T%d C%d G%d", B, T, C, G);
     CVFT_CHECK_ARG(x && gamma && beta && y && mean && rstd, "cvft_groupnorm_mish_fwd: null operand");
@@ -418,19 +424,19 @@ extern "C" int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, co
     const bool vp = ((C / G) % vec == 0) && (C % vec == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const bool vpa = vp && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (!add || ((reinterpret_cast<uintptr_t>(add) & 15) == 0));
     if (dtype == CVFT_F32) {
-        if (vp) hipLaunchKernelGGL((gn_stats_kernel<float, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, eps, mean, rstd);
-        else hipLaunchKernelGGL((gn_stats_kernel<float, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, eps, mean, rstd);
+        if (vp) hipLaunchKernelGGL((gn_stats_kernel<float, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, eps, mean, rstd, t_eff);
+        else hipLaunchKernelGGL((gn_stats_kernel<float, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, eps, mean, rstd, t_eff);
         if (vpa) hipLaunchKernelGGL((gn_apply_fwd_kernel<float, true>), dim3(ew_grid(total / vec)), dim3(256), 0, st, B, T, C, G,
-                                    (const float*)x, gamma, beta, mean, rstd, len, (const float*)add, apply_mish, (float*)y);
+                                    (const float*)x, gamma, beta, mean, rstd, len, (const float*)add, apply_mish, (float*)y, t_eff);
         else hipLaunchKernelGGL((gn_apply_fwd_kernel<float, false>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
-                                (const float*)x, gamma, beta, mean, rstd, len, (const float*)add, apply_mish, (float*)y);
+                                (const float*)x, gamma, beta, mean, rstd, len, (const float*)add, apply_mish, (float*)y, t_eff);
     } else {
-        if (vp) hipLaunchKernelGGL((gn_stats_kernel<bf16_t, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, eps, mean, rstd);
-        else hipLaunchKernelGGL((gn_stats_kernel<bf16_t, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, eps, mean, rstd);
+        if (vp) hipLaunchKernelGGL((gn_stats_kernel<bf16_t, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, eps, mean, rstd, t_eff);
+        else hipLaunchKernelGGL((gn_stats_kernel<bf16_t, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, eps, mean, rstd, t_eff);
         if (vpa) hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16_t, true>), dim3(ew_grid(total / vec)), dim3(256), 0, st, B, T, C, G,
-                                    (const bf16_t*)x, gamma, beta, mean, rstd, len, (const bf16_t*)add, apply_mish, (bf16_t*)y);
+                                    (const bf16_t*)x, gamma, beta, mean, rstd, len, (const bf16_t*)add, apply_mish, (bf16_t*)y, t_eff);
         else hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16_t, false>), dim3(ew_grid(total)), dim3(256), 0, st, B, T, C, G,
-                                (const bf16_t*)x, gamma, beta, mean, rstd, len, (const bf16_t*)add, apply_mish, (bf16_t*)y);
+                                (const bf16_t*)x, gamma, beta, mean, rstd, len, (const bf16_t*)add, apply_mish, (bf16_t*)y, t_eff);
     }
     CVFT_LAUNCH_CHECK("cvft_groupnorm_mish_fwd");
     return 0;
@@ -438,7 +444,7 @@ extern "C" int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, co
 
 extern "C" int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, const void* x, const float* gamma,
                                        const float* beta, const float* mean, const float* rstd, const int32_t* len,
-                                       int apply_mish, const void* dy, void* dx, float* ws, void* stream) {
+                                       int apply_mish, const void* dy, void* dx, float* ws, const int32_t* t_eff, void* stream) {
     CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_groupnorm_mish_bwd: bad dtype");
     CVFT_CHECK_ARG(B > 0 && T > 0 && C > 0 && G > 0 && C % G == 0, "cvft_groupnorm_mish_bwd: bad dims");
     CVFT_CHECK_ARG(x && gamma && beta && mean && rstd && dy && dx && ws, "cvft_groupnorm_mish_bwd: null operand");
@@ -451,9 +457,9 @@ extern "C" int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, co
 #define GN_BWD(TT, VP)                                                                                                         \
     do {                                                                                                                       \
         hipLaunchKernelGGL((gn_bwd_stats_kernel<TT, VP>), sgrid, dim3(256), 0, st, T, C, G, (const TT*)x, gamma, beta, mean, rstd, len, \
-                           apply_mish, (const TT*)dy, ws);                                                                     \
+                           apply_mish, (const TT*)dy, ws, t_eff);                                                              \
         hipLaunchKernelGGL((gn_apply_bwd_kernel<TT, VP>), dim3(ew_grid(total / (VP ? vec : 1))), dim3(256), 0, st, B, T, C, G,  \
-                           (const TT*)x, gamma, beta, mean, rstd, len, apply_mish, (const TT*)dy, ws, (TT*)dx);                \
+                           (const TT*)x, gamma, beta, mean, rstd, len, apply_mish, (const TT*)dy, ws, (TT*)dx, t_eff);         \
     } while (0)
     if (dtype == CVFT_F32) { if (vp) GN_BWD(float, true); else GN_BWD(float, false); }
     else { if (vp) GN_BWD(bf16_t, true); else GN_BWD(bf16_t, false); }

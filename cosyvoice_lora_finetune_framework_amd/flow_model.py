@@ -40,7 +40,7 @@ class ConditionalCFM(nn.Module):
                 "cfg_rand": torch.rand(B, device=device)}
 
     def compute_loss_cl(self, feat, mu, spk, length, B: int, T: int, num: Numerics, draws=None,
-                        mel_mean: float = 0.0, mel_std: float = 1.0, cond=None, prompt_lens=None):
+                        mel_mean: float = 0.0, mel_std: float = 1.0, cond=None, prompt_lens=None, t_true=None):
         """Channel-last hot path.  feat [B,T,80] fp32 (raw log-mel if mel_mean/std given), mu [B*T,80],
         spk [B,80], length int32 [B] -> scalar loss (flow_matching.py:154-193).
         prompt_lens (list of B ints, flow_model.py:164-202): prompt-isolation attention in the estimator (split at the
@@ -61,7 +61,7 @@ class ConditionalCFM(nn.Module):
         else:
             self.estimator.prompt_isolation_len = 0
         try:
-            pred = self.estimator.forward_cl(xin, t, B, T, length, num.gelu)
+            pred = self.estimator.forward_cl(xin, t, B, T, length, num.gelu, t_true)
         finally:
             self.estimator.prompt_isolation_len = 0
         if prompt_lens is None:
@@ -186,8 +186,13 @@ class MaskedDiffWithXvec(nn.Module):
             tok = HF.embed_gather(token, self._embedding_table(dt), tok_len)
         h = self.encoder.forward_cl(tok, B, Lt, tok_len, num, causal=False)
         h = hip_linear(self.encoder_proj, h)
-        mu = self.length_regulator.forward_cl(h, B, Lt, T, feat_len)
-        loss, _ = self.decoder.compute_loss_cl(feat, mu, spk, feat_len, B, T, num, draws, self.mel_mean, self.mel_std)
+        # `_true_dims` (train_joint.Trainer, shape-bucketed batches): device int32 [Lt_max, T_max, ceil(T_max/2), ...] of the
+        # exact batch; absent = the tensors have their exact shapes
+        td = batch.get('_true_dims')
+        td = None if td is None else td.to(device)
+        mu = self.length_regulator.forward_cl(h, B, Lt, T, feat_len, None if td is None else td[0:2])
+        loss, _ = self.decoder.compute_loss_cl(feat, mu, spk, feat_len, B, T, num, draws, self.mel_mean, self.mel_std,
+                                               t_true=None if td is None else td[1:])
         return {'loss': loss}
 
     def prompt_plan(self, feat_len, cross_len=None):

@@ -77,8 +77,8 @@ SIGNATURES = {
     "cvft_lora_shadow": [_i, _p, _p, _p],
     "cvft_layernorm_fwd": [_i, _i, _i, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p],
     "cvft_layernorm_bwd": [_i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p],
-    "cvft_groupnorm_mish_fwd": [_i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p],
-    "cvft_groupnorm_mish_bwd": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
+    "cvft_groupnorm_mish_fwd": [_i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _p],
+    "cvft_groupnorm_mish_bwd": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p],
     "cvft_attn_bias_fwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _f, _i, _p, _i, _p, _p],
     "cvft_attn_bias_bwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _f, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p],
     "cvft_attn_relpos_fwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _f, _p, _i, _p, _f, _p, C.c_uint, _p],
@@ -99,8 +99,8 @@ SIGNATURES = {
     "cvft_cfm_prepare": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p],
     "cvft_masked_mse_fwd": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "cvft_masked_mse_bwd": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
-    "cvft_interp_linear_fwd": [_i, _i, _i, _i, _i, _p, _p, _p],
-    "cvft_interp_linear_bwd": [_i, _i, _i, _i, _i, _p, _p, _p],
+    "cvft_interp_linear_fwd": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "cvft_interp_linear_bwd": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
     "cvft_ce_fwd": [_i, _i, _i, _p, _i, _p, _p, _p, _p],
     "cvft_ce_bwd": [_i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p],
     "cvft_dwconv1d_fwd": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],

@@ -579,7 +579,13 @@ class LoraGradSink:
         need = nsplit * P.numel()
         ws = getattr(P, "_cvft_part", None)
         if ws is None or ws.numel() < need:
-            ws = torch.empty(need, dtype=torch.float32, device=P.device)
+            # A captured step holds the ADDRESS of the workspace it was captured with; a later batch layout with more
+            # row blocks needs a bigger one.  The old buffer is never freed (it stays that step's workspace): freeing it
+            # let later allocations land under the slab writes of the older captured step (GPU memory fault in the
+            # trainer's multi-layout path).  The new one gets headroom so that nearby layouts share it.
+            if ws is not None:
+                P.__dict__.setdefault("_cvft_part_retired", []).append(ws)
+            ws = torch.empty(need + need // 4, dtype=torch.float32, device=P.device)
             P._cvft_part = ws
         return ws
 
@@ -615,8 +621,7 @@ class LoraGradSink:
             dev = torch.device("cuda", torch.cuda.current_device())
             tbl = torch.tensor(self.tasks, dtype=torch.int64).to(dev)
             ent = (tbl, min(64, max(1, -(-max(t[2] * t[3] for t in self.tasks) // 1024))))
-            if len(LoraGradSink._cache) > 8:
-                LoraGradSink._cache.clear()
+            # (entries are never dropped: a captured step holds the address of its task table)
             LoraGradSink._cache[key] = ent
         check(lib().cvft_lora_grad_reduce(len(self.tasks), ptr(ent[0]), ent[1], stream()), "cvft_lora_grad_reduce")
         self.tasks = []
@@ -1310,7 +1315,7 @@ def layernorm_fork(x, gamma, beta, eps: float = 1e-5, side=None):
 
 class GroupNormMishFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, B: int, T: int, G: int, eps: float, length, add, mish: bool):
+    def forward(ctx, x, gamma, beta, B: int, T: int, G: int, eps: float, length, add, mish: bool, t_eff=None):
         x = _c(x)
         Cn = x.shape[1]
         assert x.shape[0] == B * T
@@ -1319,9 +1324,9 @@ class GroupNormMishFn(torch.autograd.Function):
         rstd = torch.empty(B * G, dtype=torch.float32, device=x.device)
         check(lib().cvft_groupnorm_mish_fwd(dt(x), B, T, Cn, G, ptr(x), ptr(gamma), ptr(beta), eps, ptr(length),
                                             ptr(None if add is None else _c(add)), int(mish), ptr(y), ptr(mean),
-                                            ptr(rstd), stream()), "cvft_groupnorm_mish_fwd")
+                                            ptr(rstd), ptr(t_eff), stream()), "cvft_groupnorm_mish_fwd")
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        ctx.dims, ctx.length, ctx.mish = (B, T, Cn, G), length, mish
+        ctx.dims, ctx.length, ctx.mish, ctx.t_eff = (B, T, Cn, G), length, mish, t_eff
         return y
 
     @staticmethod
@@ -1332,14 +1337,16 @@ class GroupNormMishFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         ws = torch.empty(B * G * 2 * cb.GN_SPLIT, dtype=torch.float32, device=x.device)
         check(lib().cvft_groupnorm_mish_bwd(dt(x), B, T, Cn, G, ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
-                                            ptr(ctx.length), int(ctx.mish), ptr(dy), ptr(dx), ptr(ws), stream()),
+                                            ptr(ctx.length), int(ctx.mish), ptr(dy), ptr(dx), ptr(ws), ptr(ctx.t_eff), stream()),
               "cvft_groupnorm_mish_bwd")
-        return dx, None, None, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None, None, None
 
 
-def groupnorm_mish(x, gamma, beta, B: int, T: int, G: int, eps: float = 1e-5, length=None, add=None, mish: bool = True):
-    """x [B*T, C] channel-last; y = mish(GN(x)) * (t < length[b]) + add[b]  (add carries no gradient)."""
-    return GroupNormMishFn.apply(x, gamma, beta, B, T, G, eps, length, add, mish)
+def groupnorm_mish(x, gamma, beta, B: int, T: int, G: int, eps: float = 1e-5, length=None, add=None, mish: bool = True,
+                   t_eff=None):
+    """x [B*T, C] channel-last; y = mish(GN(x)) * (t < length[b]) + add[b]  (add carries no gradient).
+    t_eff (device int32[1], optional): the exact batch's frame count when T is padded to a shape bucket (cvft.h)."""
+    return GroupNormMishFn.apply(x, gamma, beta, B, T, G, eps, length, add, mish, t_eff)
 
 
 # ---------------------------------------------------------------------------------
@@ -1465,12 +1472,12 @@ def gather_rows(src, idx: torch.Tensor, fill: float = 0.0):
 
 class InterpLinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, B: int, Lin: int, Lout: int):
+    def forward(ctx, x, B: int, Lin: int, Lout: int, eff=None):
         x = _c(x)
         Cn = x.shape[1]
         y = torch.empty((B * Lout, Cn), dtype=x.dtype, device=x.device)
-        check(lib().cvft_interp_linear_fwd(dt(x), B, Lin, Lout, Cn, ptr(x), ptr(y), stream()), "cvft_interp_linear_fwd")
-        ctx.dims = (B, Lin, Lout, Cn)
+        check(lib().cvft_interp_linear_fwd(dt(x), B, Lin, Lout, Cn, ptr(x), ptr(y), ptr(eff), stream()), "cvft_interp_linear_fwd")
+        ctx.dims, ctx.eff = (B, Lin, Lout, Cn), eff
         return y
 
     @staticmethod
@@ -1478,12 +1485,13 @@ class InterpLinearFn(torch.autograd.Function):
         B, Lin, Lout, Cn = ctx.dims
         dy = _c(dy)
         dx = torch.empty((B * Lin, Cn), dtype=dy.dtype, device=dy.device)
-        check(lib().cvft_interp_linear_bwd(dt(dy), B, Lin, Lout, Cn, ptr(dy), ptr(dx), stream()), "cvft_interp_linear_bwd")
-        return dx, None, None, None
+        check(lib().cvft_interp_linear_bwd(dt(dy), B, Lin, Lout, Cn, ptr(dy), ptr(dx), ptr(ctx.eff), stream()), "cvft_interp_linear_bwd")
+        return dx, None, None, None, None
 
 
-def interp_linear(x, B: int, Lin: int, Lout: int):
-    return InterpLinearFn.apply(x, B, Lin, Lout)
+def interp_linear(x, B: int, Lin: int, Lout: int, eff=None):
+    """eff (device int32[2], optional): the exact batch's (Lin, Lout) when the tensors are padded to shape buckets (cvft.h)."""
+    return InterpLinearFn.apply(x, B, Lin, Lout, eff)
 
 
 def l2norm_rows(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

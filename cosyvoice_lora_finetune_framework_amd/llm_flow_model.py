@@ -111,13 +111,13 @@ class JointLLMFlowModel(nn.Module):
             losses['loss'] = losses['flow_loss']
         return losses
 
-    def _prepare_one(self, batch: dict, device, lm_pad: int = 1, with_llm: bool = True) -> dict:
+    def _prepare_one(self, batch: dict, device, lm_pad: int = 1, with_llm: bool = True, lm_min: int = 0) -> dict:
         out = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
         for k in ('speech_token_len', 'speech_feat_len', 'text_token_len'):
             if k in out:
                 out[k] = out[k].to(torch.int32)
         if with_llm and self.training_mode in ('joint', 'llm_only') and hasattr(self.llm, 'prepare_batch') and 'text_token' in batch:
-            out.update(self.llm.prepare_batch(batch, device, lm_pad))
+            out.update(self.llm.prepare_batch(batch, device, lm_pad, lm_min))
         return out
 
     def _split_parts(self, batch: dict, device, nparts: int, kind: str = 'llm', lm_pad: int = 1):
@@ -131,6 +131,8 @@ class JointLLMFlowModel(nn.Module):
             sl = slice(bounds[i], bounds[i + 1])
             sub = {k: (v[sl] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v)
                    for k, v in batch.items() if not k.startswith('_')}
+            if '_true_dims' in batch:                   # exact batch maxima of a shape-bucketed batch: whole-batch values
+                sub['_true_dims'] = batch['_true_dims']
             part = self._prepare_one(sub, device, lm_pad, with_llm=(kind == 'llm'))      # index maps only where the LM runs
             part['_rows'] = sl
             # device scalars, not Python floats: a captured step is replayed on other batches (other length mixes)
@@ -139,10 +141,10 @@ class JointLLMFlowModel(nn.Module):
             parts.append(part)
         return parts
 
-    def prepare_batch(self, batch: dict, device, lm_pad: int = 1) -> dict:
+    def prepare_batch(self, batch: dict, device, lm_pad: int = 1, lm_min: int = 0) -> dict:
         """Move a collated batch to `device` and attach the host-computed LLM index maps (and the sub-batch split), so
         that the training step itself performs no host<->device transfers (hipGraph-capturable)."""
-        out = self._prepare_one(batch, device, lm_pad)
+        out = self._prepare_one(batch, device, lm_pad, lm_min=lm_min)
         out['_parts'] = self._make_parts(batch, out, device, True, lm_pad)
         return out
 

@@ -51,7 +51,7 @@ class TransformerLM(nn.Module):
         return w.detach() if w.dtype == dtype else _cached(emb, "tab", w, dtype, lambda: w.detach().to(dtype))
 
     @staticmethod
-    def build_index_maps(text_len, speech_len, speech_token, B: int, Lx: int, Lt: int, eos: int, pad_to: int = 1):
+    def build_index_maps(text_len, speech_len, speech_token, B: int, Lx: int, Lt: int, eos: int, pad_to: int = 1, L_min: int = 0):
         """Host-side (CPU tensors only) ragged layout of llm.py:88-95 + llm_flow_model.py:129-139.
         Source rows: [sos, task | spk(B) | text(B*Lx) | speech(B*Lt)].  Returns (idx [B*L] int32,
         target [B*L] int32, lm_len [B] int32, L).  pad_to > 1 rounds L up (rows past an utterance's length are the
@@ -60,7 +60,7 @@ class TransformerLM(nn.Module):
         tl = [int(v) for v in text_len.tolist()]
         sl = [int(v) for v in speech_len.tolist()]
         lens = [3 + a + b for a, b in zip(tl, sl)]
-        L = -(-max(lens) // pad_to) * pad_to
+        L = max(-(-max(lens) // pad_to) * pad_to, L_min)              # (L_min: the LM length of the captured step this batch joins)
         idx = torch.full((B, L), -1, dtype=torch.int32)
         tgt = torch.full((B, L), IGNORE_ID, dtype=torch.int32)
         st = speech_token.to(torch.int32)
@@ -108,13 +108,13 @@ class TransformerLM(nn.Module):
     def forward(self, batch: dict, device) -> Dict[str, Any]:
         return self.forward_no_prompt(batch, device)
 
-    def prepare_batch(self, batch: dict, device, lm_pad: int = 1) -> dict:
+    def prepare_batch(self, batch: dict, device, lm_pad: int = 1, lm_min: int = 0) -> dict:
         """Host-side preparation of one batch: index maps + H2D copies, done once per batch outside the
         (graph-capturable) step."""
         B, Lx = batch['text_token'].shape
         Lt = batch['speech_token'].shape[1]
         idx, tgt, lm_len, L = self.build_index_maps(batch['text_token_len'].cpu(), batch['speech_token_len'].cpu(),
-                                                    batch['speech_token'].cpu(), B, Lx, Lt, self.speech_token_size, lm_pad)
+                                                    batch['speech_token'].cpu(), B, Lx, Lt, self.speech_token_size, lm_pad, lm_min)
         return {'_lm_maps': (idx.to(device), tgt.to(device), lm_len.to(device), L)}
 
 

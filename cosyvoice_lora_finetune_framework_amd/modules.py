@@ -229,10 +229,10 @@ class Block1D(nn.Module):
         super().__init__()
         self.block = nn.Sequential(nn.Conv1d(dim, dim_out, 3, padding=1), nn.GroupNorm(groups, dim_out), nn.Mish())
 
-    def forward(self, x, B, T, length, add=None):
+    def forward(self, x, B, T, length, add=None, t_eff=None):
         conv, gn = self.block[0], self.block[1]
         h = HF.conv1d(x, conv_pack(conv, x.dtype), B, T, in_len=length)
-        return HF.groupnorm_mish(h, _f32(gn.weight), _f32(gn.bias), B, T, gn.num_groups, gn.eps, length, add, True)
+        return HF.groupnorm_mish(h, _f32(gn.weight), _f32(gn.bias), B, T, gn.num_groups, gn.eps, length, add, True, t_eff)
 
 
 class ResnetBlock1D(nn.Module):
@@ -245,11 +245,11 @@ class ResnetBlock1D(nn.Module):
         self.block2 = Block1D(dim_out, dim_out, groups=groups)
         self.res_conv = nn.Conv1d(dim, dim_out, 1)
 
-    def forward(self, x, B, T, length, temb_mish):
+    def forward(self, x, B, T, length, temb_mish, t_eff=None):
         with torch.no_grad():
             add = hip_linear(self.mlp[1], temb_mish)                       # [B, dim_out]; depends on t only
-        h = self.block1(x, B, T, length, add=add)
-        h = self.block2(h, B, T, length)
+        h = self.block1(x, B, T, length, add=add, t_eff=t_eff)
+        h = self.block2(h, B, T, length, t_eff=t_eff)
         # h + res_conv(x * mask): 1x1 conv == tap-GEMM with the input-length mask, residual fused
         return HF.conv1d(x, conv_pack(self.res_conv, x.dtype), B, T, in_len=length, residual=h)
 
@@ -368,9 +368,12 @@ class ConditionalDecoder(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    def forward_cl(self, xin, t, B: int, T: int, length, gelu: str = "gelu_erf"):
+    def forward_cl(self, xin, t, B: int, T: int, length, gelu: str = "gelu_erf", t_true=None):
         """xin [B*T, in_channels] (already [y|mu|spk|cond] packed), t [B] fp32, length int32 [B]
-        -> [B*T, out_channels] (masked)."""
+        -> [B*T, out_channels] (masked).
+        t_true (device int32 [levels], optional): T is padded to a shape bucket and t_true[l] holds the exact batch's frame
+        count at U-Net level l (T_max, ceil(T_max / 2), ...): the GroupNorms normalise over those frames only (cvft.h t_eff);
+        everything else on the path is masked by `length` already."""
         dtype = xin.dtype
         plen = self.prompt_isolation_len if self.prompt_isolation_enabled else 0
 
@@ -384,40 +387,41 @@ class ConditionalDecoder(nn.Module):
             temb = self.time_mlp(self.time_embeddings(t, dtype=dtype))
             temb_mish = HF.act_fwd(temb, "mish")
         x = xin
-        hiddens: List[Tuple[torch.Tensor, int, torch.Tensor]] = []
-        Tc, lc = T, length
+        hiddens: List[Tuple[torch.Tensor, int, torch.Tensor, int]] = []
+        Tc, lc, lv = T, length, 0
+        te = (lambda l: None) if t_true is None else (lambda l: t_true[l:l + 1])
         for resnet, tblocks, down in self.down_blocks:
-            x = resnet(x, B, Tc, lc, temb_mish)
+            x = resnet(x, B, Tc, lc, temb_mish, te(lv))
             for tb in tblocks:
                 x = tb(x, B, Tc, lc, gelu, iso(Tc))
-            hiddens.append((x, Tc, lc))
+            hiddens.append((x, Tc, lc, lv))
             if isinstance(down, Downsample1D):
                 pk = conv_pack(down.conv, dtype)
                 Tn = pk.out_len(Tc)
                 x = HF.conv1d(x, pk, B, Tc, Tn, in_len=lc)
-                Tc, lc = Tn, (lc + 1) // 2          # mask[:, :, ::2]
+                Tc, lc, lv = Tn, (lc + 1) // 2, lv + 1          # mask[:, :, ::2]
             else:
                 x = HF.conv1d(x, conv_pack(down, dtype), B, Tc, in_len=lc)
                 # reference appends mask_down[:, :, ::2] then drops it (masks = masks[:-1])
         for resnet, tblocks in self.mid_blocks:
-            x = resnet(x, B, Tc, lc, temb_mish)
+            x = resnet(x, B, Tc, lc, temb_mish, te(lv))
             for tb in tblocks:
                 x = tb(x, B, Tc, lc, gelu, iso(Tc))
         for resnet, tblocks, up in self.up_blocks:
-            skip, Ts, ls = hiddens.pop()
+            skip, Ts, ls, lvs = hiddens.pop()
             assert Ts == Tc, (Ts, Tc)
             x = torch.cat([x, skip], dim=1)
-            x = resnet(x, B, Ts, ls, temb_mish)
+            x = resnet(x, B, Ts, ls, temb_mish, te(lvs))
             for tb in tblocks:
                 x = tb(x, B, Ts, ls, gelu, iso(Ts))
             if isinstance(up, Upsample1D):
                 Tn = hiddens[-1][1]                 # cropped to the next skip's length
                 x = HF.conv1d(x, conv_pack(up.conv, dtype), B, Ts, Tn, in_len=ls)
-                Tc, lc = Tn, hiddens[-1][2]
+                Tc, lc, lv = Tn, hiddens[-1][2], hiddens[-1][3]
             else:
                 x = HF.conv1d(x, conv_pack(up, dtype), B, Ts, in_len=ls)
-                Tc, lc = Ts, ls
-        x = self.final_block(x, B, Tc, lc)
+                Tc, lc, lv = Ts, ls, lvs
+        x = self.final_block(x, B, Tc, lc, t_eff=te(lv))
         return HF.conv1d(x, conv_pack(self.final_proj, dtype), B, Tc, in_len=lc, out_len=lc)
 
     def forward(self, x, mask, mu, t, spks=None, cond=None, dtype: Optional[torch.dtype] = None, gelu="gelu_erf"):
@@ -459,8 +463,7 @@ class EspnetRelPositionalEncoding(nn.Module):
             pe = torch.zeros(2 * L - 1, d, dtype=torch.float32)
             pe[:, 0::2] = torch.sin(pos * div)
             pe[:, 1::2] = torch.cos(pos * div)
-            if len(self._cache) > 64:
-                self._cache.clear()
+            # (never evicted: a captured hipGraph holds the address of the table it was captured with; ~0.5 MB per length)
             self._cache[key] = pe.to(device=device, dtype=dtype).contiguous()
             self._cache[key]._cvft_const = True      # (a frozen linear_pos caches its projection of this table)
         return self._cache[key]
@@ -652,17 +655,20 @@ class InterpolateRegulator(nn.Module):
         out = self.inference_cl(x1[0], x2[0], int(mel_len1), int(mel_len2), input_frame_rate)
         return out.unsqueeze(0), mel_len1 + mel_len2
 
-    def forward_cl(self, x, B: int, Lin: int, T: int, ylen):
-        """x [B*Lin, C] -> [B*T, C] masked by ylen (int32 [B])."""
-        return self._stack_cl(HF.interp_linear(x, B, Lin, T), B, T, ylen)
+    def forward_cl(self, x, B: int, Lin: int, T: int, ylen, eff=None):
+        """x [B*Lin, C] -> [B*T, C] masked by ylen (int32 [B]).
+        eff (device int32 [2], optional): Lin / T are padded to shape buckets and eff = the exact batch's (Lt_max, T_max) --
+        the interpolation takes its scale and clamp from eff, the GroupNorms normalise over T_max frames, frames beyond
+        are zeros throughout (what the convolutions of the exact-shape batch see as their zero padding)."""
+        return self._stack_cl(HF.interp_linear(x, B, Lin, T, eff), B, T, ylen, None if eff is None else eff[1:2])
 
-    def _stack_cl(self, x, B: int, T: int, ylen):
+    def _stack_cl(self, x, B: int, T: int, ylen, t_eff=None):
         mods = list(self.model)
         i = 0
         while i + 2 < len(mods):
             conv, gn = mods[i], mods[i + 1]
             x = HF.conv1d(x, conv_pack(conv, x.dtype), B, T)
-            x = HF.groupnorm_mish(x, _f32(gn.weight), _f32(gn.bias), B, T, gn.num_groups, gn.eps, None, None, True)
+            x = HF.groupnorm_mish(x, _f32(gn.weight), _f32(gn.bias), B, T, gn.num_groups, gn.eps, None, None, True, t_eff)
             i += 3
         return HF.conv1d(x, conv_pack(mods[-1], x.dtype), B, T, out_len=ylen)
 

@@ -123,8 +123,14 @@ def _batch_denoms(batch, training_mode: str = 'joint') -> Dict[str, float]:
 TEXT_BUCKET = 16      # graph path: text tokens padded to a multiple of this (masked by text_token_len)
 LM_BUCKET = 16        # graph path: LM sequence length L rounded up to a multiple of this (masked by lm_len).  The padding rows are real
                       # work for every LM kernel: at 32, L = 333 became 352 (+5.7 % on the LLM branch, ~1 ms/step vs the pre-staged step)
-# (mel frames T and speech tokens Lt are NOT bucketed: the length regulator interpolates Lt_max -> T_max of the padded
-#  batch, length_regulator.py:44-50, so padding them would change the result)
+# Mel frames T and speech tokens Lt: the reference's results depend on the padded batch dims themselves (the length regulator
+# interpolates Lt_max -> T_max, length_regulator.py:44-50; the GroupNorms normalise over all T_max frames of the padded
+# batch, modules.py:60-73), so they are never rounded up blindly.  A batch MAY be padded up to the layout of a step that is
+# already captured when that costs at most SHAPE_SLACK: the exact maxima travel with the batch as device scalars
+# (`_true_dims`) and the interpolation / GroupNorm kernels work from those (cvft.h `eff` / `t_eff`) -- same results, and a
+# corpus whose batches rarely repeat a shape still runs on captured steps.
+SHAPE_SLACK = float(os.environ.get("CVFT_SHAPE_SLACK", "0.125"))
+TRUE_DIM_LEVELS = 4   # `_true_dims` = [Lt_max, T_max, ceil(T_max / 2), ceil(T_max / 4), ceil(T_max / 8)]
 
 
 class _Leaf:
@@ -156,7 +162,7 @@ def _tree_map(obj, fn_tensor, fn_leaf=None, memo=None):
 
 class _PackedBatch:
     """A prepared batch as ONE device byte slab plus a tree of typed views into it."""
-    __slots__ = ("tree", "slab", "spec", "meta", "key")
+    __slots__ = ("tree", "slab", "spec", "meta", "key", "dims")
 
     def bind(self, slab: torch.Tensor):
         """the same tree over another slab of this layout (the captured step's static copy)"""
@@ -175,7 +181,9 @@ class _BatchPacker:
     ROUND = 1 << 16
 
     def __init__(self):
+        import threading
         self.pool = {}                    # rounded byte size -> [(pinned buffer, event of its last upload)]
+        self.lock = threading.Lock()      # pack() runs on the prefetch thread and, for a late re-fit, on the main thread
 
     def _pinned(self, nbytes: int):
         size = -(-nbytes // self.ROUND) * self.ROUND
@@ -212,16 +220,17 @@ class _BatchPacker:
             meta.append((off, n, t.dtype, tuple(t.shape)))
             off += -(-max(n, 1) // self.ALIGN) * self.ALIGN
         total = max(off, self.ALIGN)
-        ent = self._pinned(total)
-        host = ent[0]
-        for t, (o, n, dt, shape) in zip(leaves, meta):
-            if n:
-                host[o:o + n].view(dt).view(shape).copy_(t)
-        with torch.cuda.stream(stream):
-            pk.slab = torch.empty(total, dtype=torch.uint8, device=dev)
-            pk.slab.copy_(host[:total], non_blocking=True)
-            ent[1] = torch.cuda.Event()
-            ent[1].record()
+        with self.lock:                   # a pinned buffer is taken until the event of its upload is on the stream
+            ent = self._pinned(total)
+            host = ent[0]
+            for t, (o, n, dt, shape) in zip(leaves, meta):
+                if n:
+                    host[o:o + n].view(dt).view(shape).copy_(t)
+            with torch.cuda.stream(stream):
+                pk.slab = torch.empty(total, dtype=torch.uint8, device=dev)
+                pk.slab.copy_(host[:total], non_blocking=True)
+                ent[1] = torch.cuda.Event()
+                ent[1].record()
         pk.meta = meta
         pk.key = (tuple((shape, str(dt)) for (_, _, dt, shape) in meta), tuple(scalars))
         pk.tree = pk.bind(pk.slab)
@@ -348,9 +357,11 @@ class Trainer:
     """The slice of pl.Trainer that train_joint.py:349-368 uses: max_epochs, accumulate_grad_batches,
     gradient_clip_val, callbacks, checkpoints (save_last + best), resume, step-level LR schedule.
 
-    On a GPU the micro-step (forward + backward) replays a captured hipGraph per batch shape (`use_graph`, default on;
-    CVFT_TRAINER_GRAPH=0 or use_graph=False launches eagerly): a shape is captured the second time it is seen, the
-    batch is copied into the graph's static buffers, all-reduce / clip / AdamW stay outside the graph."""
+    On a GPU the micro-step (forward + backward) replays a captured hipGraph per batch layout (`use_graph`, default on;
+    CVFT_TRAINER_GRAPH=0 or use_graph=False launches eagerly): a batch is padded up to the layout of an already captured
+    step when one covers it within SHAPE_SLACK (exact maxima travel as device scalars: same results), else its own layout
+    is captured (at most `max_graphs`, eager beyond); the batch reaches the graph's static slab by one DMA + one device
+    copy; all-reduce / clip / AdamW stay outside the graph."""
 
     def __init__(self, max_epochs: int = 100, accumulate_grad_batches: int = 1, gradient_clip_val: float = 1.0,
                  callbacks: Optional[list] = None, default_root_dir: str = OUTPUT_DIR, log_every_n_steps: int = 10,
@@ -375,7 +386,7 @@ class Trainer:
         self._copy_stream = None
         self._packer = _BatchPacker()
         self._graphs: Dict[tuple, _StepGraph] = {}
-        self._seen: Dict[tuple, int] = {}
+        self._layouts: List[tuple] = []    # (T, Lt, text, LM length, B) of every captured step, read by the prefetch thread
         self.rank, _, self.world = (0, 0, 1) if not torch.distributed.is_initialized() else \
             (torch.distributed.get_rank(), 0, torch.distributed.get_world_size())
 
@@ -427,17 +438,48 @@ class Trainer:
         if batch is None or not (self.use_graph and hasattr(module.model, 'prepare_batch')):
             return batch, None, None
         dev = module.device
-        if 'text_token' in batch and batch['text_token'].shape[1] % TEXT_BUCKET:
-            tt = batch['text_token']
-            batch = dict(batch, text_token=torch.nn.functional.pad(tt, (0, TEXT_BUCKET - tt.shape[1] % TEXT_BUCKET)))
-        # host -> device copies on a side stream: a pageable-memory copy blocks the host until every earlier operation
-        # of ITS stream has finished -- on the compute stream that would be the whole previous step
-        # index maps / sub-batch split on the host, then ONE pinned slab -> ONE DMA on the copy stream (_BatchPacker)
-        packed = self._packer.pack(module.model.prepare_batch(batch, 'cpu', LM_BUCKET), dev, self._copy_stream)
+        fitted, dims = self._fit_layout(batch)
+        # index maps / sub-batch split on the host, then ONE pinned slab -> ONE DMA on the copy stream (_BatchPacker): a
+        # host -> device copy on the compute stream would wait for the whole previous step
+        packed = self._packer.pack(module.model.prepare_batch(fitted, 'cpu', LM_BUCKET, dims[3]), dev, self._copy_stream)
+        packed.dims = dims
         ev = torch.cuda.Event()
         with torch.cuda.stream(self._copy_stream):
             ev.record()
-        return batch, packed, ev
+        return batch, packed, ev            # (draws_fn / loss denominators see the batch as the loader made it)
+
+    def _fit_layout(self, batch):
+        """Shape side of the graph path: text length to its bucket, and (T, Lt, text, LM length) up to the layout of an
+        already captured step when one covers the batch within SHAPE_SLACK.  Returns (padded batch with `_true_dims`,
+        (T', Lt', Lx', L', B))."""
+        feat, tok = batch['speech_feat'], batch['speech_token']
+        B, T, Lt = feat.shape[0], feat.shape[1], tok.shape[1]
+        has_text = 'text_token' in batch
+        Lx = -(-batch['text_token'].shape[1] // TEXT_BUCKET) * TEXT_BUCKET if has_text else 0
+        L = 0
+        if has_text:
+            L = int((batch['text_token_len'] + batch['speech_token_len']).max()) + 3          # llm_model.build_index_maps
+            L = -(-L // LM_BUCKET) * LM_BUCKET
+        best, cost = None, None
+        for (T2, Lt2, Lx2, L2, B2) in list(self._layouts):
+            if B2 != B or T2 < T or Lt2 < Lt or Lx2 < Lx or L2 < L:
+                continue
+            if T2 > T * (1 + SHAPE_SLACK) or Lt2 > Lt * (1 + SHAPE_SLACK) + 4 or L2 > L * (1 + SHAPE_SLACK) + LM_BUCKET:
+                continue
+            c = (T2 / T) * (max(L2, 1) / max(L, 1))
+            if cost is None or c < cost:
+                best, cost = (T2, Lt2, Lx2, L2, B2), c
+        T2, Lt2, Lx2, L2, _ = best if best is not None else (T, Lt, Lx, L, B)
+        out = dict(batch)
+        pad = torch.nn.functional.pad
+        if T2 > T:
+            out['speech_feat'] = pad(feat, (0, 0, 0, T2 - T))
+        if Lt2 > Lt:
+            out['speech_token'] = pad(tok, (0, Lt2 - Lt))
+        if has_text and Lx2 > batch['text_token'].shape[1]:
+            out['text_token'] = pad(batch['text_token'], (0, Lx2 - batch['text_token'].shape[1]))
+        out['_true_dims'] = torch.tensor([Lt] + [-(-T // (1 << l)) for l in range(TRUE_DIM_LEVELS)], dtype=torch.int32)
+        return out, (T2, Lt2, Lx2, L2, B)
 
     def _micro_step(self, module, opt, batch, draws, w, prepared=None, ready=None):
         """forward + backward of one local batch; returns the dict of detached loss scalars.  `w` = per-term loss weights
@@ -447,9 +489,15 @@ class Trainer:
                 (k == "flow" and module.training_mode in ('joint', 'flow_only'))]
         if prepared is not None:
             main = torch.cuda.current_stream()
+            if self._layouts and prepared.dims not in self._layouts and self._fit_layout(batch)[1] != prepared.dims:
+                # prepared (by the prefetch thread) before the step that covers it was captured: fit it again
+                _, prepared, ready = self._prepare(module, batch)
             if draws is not None:
+                T2 = prepared.dims[0]
                 with torch.cuda.stream(self._copy_stream):
                     draws = {k: v.to(dev) for k, v in draws.items()}
+                    if 'z' in draws and draws['z'].shape[-1] < T2:       # injected noise follows the padded frame count
+                        draws['z'] = torch.nn.functional.pad(draws['z'], (0, T2 - draws['z'].shape[-1]))
                     ready = torch.cuda.Event()
                     ready.record()
             main.wait_event(ready)
@@ -460,9 +508,12 @@ class Trainer:
             key = (prepared.key, draws is not None and tuple(sorted(draws)))
             g = self._graphs.get(key)
             if g is None:
-                self._seen[key] = self._seen.get(key, 0) + 1
-                if self._seen[key] >= 2 and len(self._graphs) < self.max_graphs:
+                # capture at first sight: a layout only gets here when no captured step covers it (_fit_layout)
+                if len(self._graphs) < self.max_graphs:
                     g = self._graphs[key] = _StepGraph(module, prepared, draws, w.clone(), self.accum, opt.flat_g)
+                    self._layouts.append(prepared.dims)
+                    if os.environ.get('CVFT_TRAINER_DEBUG'):
+                        print(f"[trainer] captured layout {prepared.dims} (exact {tuple(batch['speech_feat'].shape)}, {tuple(batch['speech_token'].shape)})", flush=True)
                     self.graph_stats["captures"] += 1
             if g is not None:
                 self.graph_stats["replays"] += 1
@@ -565,7 +616,7 @@ class SyntheticLoader:
     the epoch's batches once (a dataset already decoded in host memory, what DataLoader workers hand over): the CPU
     random-number generation of a 16 x 500 x 80 batch costs more than a whole GPU step."""
 
-    def __init__(self, n_batches: int, batch_size: int, T: int, seed: int = 1234, ragged: bool = False, rank: int = 0,
+    def __init__(self, n_batches: int, batch_size: int, T: int, seed: int = 1234, ragged=False, rank: int = 0,
                  cache: bool = False):
         self.n, self.bs, self.T, self.seed, self.ragged, self.rank = n_batches, batch_size, T, seed, ragged, rank
         self._cache = list(self._gen()) if cache else None
@@ -580,7 +631,8 @@ class SyntheticLoader:
             lens = [self.T] * self.bs
             if self.ragged:
                 lens = [int(self.T * (0.6 + 0.4 * float(torch.rand(1, generator=g)))) for _ in range(self.bs)]
-                lens[0] = self.T
+                if self.ragged != 2:          # (2: no utterance pinned to T -- every batch has its own T_max / Lt_max)
+                    lens[0] = self.T
             yield synth_batch(lens, seed=self.seed + 1000 * self.rank + i)
 
     def __iter__(self):

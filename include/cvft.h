@@ -178,10 +178,16 @@ int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, const float* g
 #define CVFT_GN_SPLIT 8   /* frame chunks of the backward statistics pass (partials in ws, summed in fixed order) */
 int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, const void* x, const float* gamma,
                             const float* beta, float eps, const int32_t* len, const void* add /*[B][C] dtype or NULL*/,
-                            int apply_mish, void* y, float* mean /*[B*G]*/, float* rstd /*[B*G]*/, void* stream);
+                            int apply_mish, void* y, float* mean /*[B*G]*/, float* rstd /*[B*G]*/,
+                            const int32_t* t_eff /*device int or NULL*/, void* stream);
 int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, const void* x, const float* gamma,
                             const float* beta, const float* mean, const float* rstd, const int32_t* len,
-                            int apply_mish, const void* dy, void* dx, float* ws /*[B*G*CVFT_GN_SPLIT*2] scratch*/, void* stream);
+                            int apply_mish, const void* dy, void* dx, float* ws /*[B*G*CVFT_GN_SPLIT*2] scratch*/,
+                            const int32_t* t_eff /*device int or NULL*/, void* stream);
+/* t_eff (both): the reference normalises over the PADDED batch's frames -- every t < T_max, utterance or padding
+ * (modules.py:60-73 on a [B, C, T_max] tensor).  When the trainer pads T_max up to a shape bucket so that one captured step
+ * serves many batches, *t_eff (<= T) carries the exact T_max: statistics and their backward run over t < *t_eff only, frames
+ * t >= *t_eff are written as zeros (forward output and dx).  NULL = T. */
 
 /* ---------------------------------------------------------------------------------
  * Fused attention, head_dim 64, additive key-padding bias -1e10 (NOT -inf):
@@ -285,9 +291,11 @@ int cvft_masked_mse_fwd(int dtype, int B, int T, int C, const void* pred, const 
 int cvft_masked_mse_bwd(int dtype, int B, int T, int C, const void* pred, const float* u, const int32_t* len,
                         const float* w, const float* gscale, void* dpred, void* stream);
 /* linear interpolation along time (F.interpolate mode='linear', align_corners=False), channel-last.
- * x [B][Lin][C] -> y [B][Lout][C]   (length_regulator.py:47) */
-int cvft_interp_linear_fwd(int dtype, int B, int Lin, int Lout, int C, const void* x, void* y, void* stream);
-int cvft_interp_linear_bwd(int dtype, int B, int Lin, int Lout, int C, const void* dy, void* dx, void* stream);
+ * x [B][Lin][C] -> y [B][Lout][C]   (length_regulator.py:47)
+ * eff (device int32[2] or NULL): the exact-shape batch's (Lin, Lout) when x / y are padded to shape buckets: the scale
+ * Lin/Lout and the source clamp come from eff, output frames >= eff[1] are zeros, input frames >= eff[0] get no gradient. */
+int cvft_interp_linear_fwd(int dtype, int B, int Lin, int Lout, int C, const void* x, void* y, const int32_t* eff, void* stream);
+int cvft_interp_linear_bwd(int dtype, int B, int Lin, int Lout, int C, const void* dy, void* dx, const int32_t* eff, void* stream);
 /* token-mean cross entropy with ignore index + argmax accuracy
  * (label_smoothing_loss.py:68-96 smoothing 0 ; common.py:78-97).
  * logits [n][V]; target [n] int32 (-1 ignore). out[0]+=sum nll, out[1]+=#valid, out[2]+=#correct.

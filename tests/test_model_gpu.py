@@ -390,6 +390,45 @@ def test_sub_batch_chains_reproduce_global_batch_means(tiny_meta):
         assert max(rel(o[1][k], outs[0][1][k]) for k in outs[0][1]) < 1e-4
 
 
+def test_shape_bucketed_batch_equals_exact_batch(tiny_meta):
+    """train_joint.Trainer._fit_layout: a batch padded up to the layout of another captured step (T, Lt, text, LM length all
+    larger, `_true_dims` = the exact maxima) gives the exact batch's losses and LoRA gradients -- the length regulator's
+    interpolation and every GroupNorm work from the device scalars, everything else is masked by the length vectors."""
+    from cosyvoice_lora_finetune_framework_amd import llm_flow_model as J
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    from cosyvoice_lora_finetune_framework_amd.train_joint import Trainer
+    num = Numerics(dtype=torch.float32)
+    flow = build_flow_product(tiny_meta["flow"], DEV, num)
+    llm = build_llm_product(tiny_meta["llm"], DEV, num)
+    jm = J.JointLLMFlowModel(llm, flow, 'joint', 2.0, 1.0).to(DEV).eval()
+    batch = synth_batch([23, 17, 21], text_lens=[7, 5, 6], token_lens=[13, 9, 11], seed=11, text_vocab=100, speech_vocab=50)
+    T = batch['speech_feat'].shape[1]
+    draws = cfm_draws(3, T, seed=5)
+    tr = Trainer(use_graph=False)
+    outs = []
+    for layout in (None, (T + 2, batch['speech_token'].shape[1] + 3, 32, 48, 3)):      # within SHAPE_SLACK of the batch
+        if layout is not None:
+            tr._layouts.append(layout)
+        fitted, dims = tr._fit_layout(batch)
+        if layout is not None:
+            assert dims == layout and fitted['speech_feat'].shape[1] == T + 2 and int(fitted['_true_dims'][1]) == T
+        prepared = jm.prepare_batch(fitted, DEV, 16, dims[3])
+        d = dict(draws)
+        if d['z'].shape[-1] < dims[0]:
+            d['z'] = torch.nn.functional.pad(d['z'], (0, dims[0] - d['z'].shape[-1]))
+        for p in jm.parameters():
+            p.grad = None
+        out = jm(prepared, DEV, d)
+        out['loss'].backward()
+        outs.append(([float(out[k]) for k in ('loss', 'llm_loss', 'flow_loss', 'llm_acc')],
+                     {n: p.grad.clone() for n, p in jm.named_parameters() if p.grad is not None}))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(a)), (outs[0][0], outs[1][0])
+    assert set(outs[0][1]) == set(outs[1][1])
+    assert max(rel(outs[1][1][k], outs[0][1][k]) for k in outs[0][1]) < 2e-5
+
+
 def test_flow_prompt_path_loss_and_grads(tiny_meta):
     """MaskedDiffWithXvec.forward with prompts and the anti-leakage strategies (flow_model.py:248-400,
     137-204) -- the product's forward() under the reference's `random` seed reproduces the reference's per-utterance

@@ -332,6 +332,49 @@ def test_interp_linear(dtype, Lin, Lout):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_shape_bucket_scalars_reproduce_exact_shapes(dtype):
+    """cvft.h `t_eff` / `eff`: GroupNorm+Mish and the linear interpolation on tensors PADDED to a shape bucket, with the exact
+    batch's frame counts passed as device scalars, give bit-for-bit what the exact-shape launch gives on the valid frames
+    (forward and input gradient) and zeros on the padding."""
+    HF = HFmod()
+    B, T, Tp, Cn, G = 3, 29, 36, 64, 8
+    lens = torch.tensor([29, 20, 7], dtype=torch.int32, device=DEV)
+    x = q(rnd(B, T, Cn, seed=1) + 0.2, dtype).to(DEV, dtype)
+    gy = q(rnd(B, T, Cn, seed=5), dtype).to(DEV, dtype)
+    g, b, add = (1 + 0.1 * rnd(Cn, seed=2)).to(DEV), (0.1 * rnd(Cn, seed=3)).to(DEV), q(rnd(B, Cn, seed=4), dtype).to(DEV, dtype)
+    junk = lambda *sh: (torch.randn(*sh, generator=torch.Generator().manual_seed(9)) * 3).to(DEV, dtype)
+
+    def padT(t, Tn, Tpn):          # [B, Tn, C] -> [B, Tpn, C], padding frames filled with junk (must not matter)
+        out = junk(B, Tpn, t.shape[2])
+        out[:, :Tn] = t
+        return out
+    te = torch.tensor([T], dtype=torch.int32, device=DEV)
+    for length in (lens, None):
+        xe = x.reshape(B * T, Cn).clone().requires_grad_(True)
+        ye = HF.groupnorm_mish(xe, g, b, B, T, G, 1e-5, length, add, True)
+        ye.backward(gy.reshape(B * T, Cn))
+        xp = padT(x, T, Tp).reshape(B * Tp, Cn).requires_grad_(True)
+        yp = HF.groupnorm_mish(xp, g, b, B, Tp, G, 1e-5, length, add, True, t_eff=te)
+        yp.backward(padT(gy, T, Tp).reshape(B * Tp, Cn))
+        yp3, gp3 = yp.reshape(B, Tp, Cn), xp.grad.reshape(B, Tp, Cn)
+        assert torch.equal(yp3[:, :T], ye.reshape(B, T, Cn)) and torch.equal(gp3[:, :T], xe.grad.reshape(B, T, Cn))
+        assert float(yp3[:, T:].abs().max()) == 0.0 and float(gp3[:, T:].abs().max()) == 0.0
+    # interpolation Lin -> Lout, both padded
+    Lin, Lout, Lip, Lop = 17, 29, 24, 36
+    h = q(rnd(B, Lin, Cn, seed=6), dtype).to(DEV, dtype)
+    gz = q(rnd(B, Lout, Cn, seed=7), dtype).to(DEV, dtype)
+    he = h.reshape(B * Lin, Cn).clone().requires_grad_(True)
+    ze = HF.interp_linear(he, B, Lin, Lout)
+    ze.backward(gz.reshape(B * Lout, Cn))
+    hp = padT(h, Lin, Lip).reshape(B * Lip, Cn).requires_grad_(True)
+    zp = HF.interp_linear(hp, B, Lip, Lop, eff=torch.tensor([Lin, Lout], dtype=torch.int32, device=DEV))
+    zp.backward(padT(gz, Lout, Lop).reshape(B * Lop, Cn))
+    zp3, gh3 = zp.reshape(B, Lop, Cn), hp.grad.reshape(B, Lip, Cn)
+    assert torch.equal(zp3[:, :Lout], ze.reshape(B, Lout, Cn)) and torch.equal(gh3[:, :Lin], he.grad.reshape(B, Lin, Cn))
+    assert float(zp3[:, Lout:].abs().max()) == 0.0 and float(gh3[:, Lin:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_cross_entropy(dtype):
     from oracle import ref_math as R
     HF = HFmod()

@@ -93,7 +93,8 @@ def test_trainer_graph_path_equals_eager_path(tiny_meta):
     from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
     from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, Trainer
     num = Numerics(dtype=torch.float32)
-    shapes = [(24, 5, 10), (24, 7, 10), (17, 5, 8), (24, 5, 10), (17, 6, 8), (24, 9, 10)]     # (T, Lx, Lt): repeats + bucket-mates
+    # (T, Lx, Lt): repeats, bucket-mates, and layouts that an earlier captured step covers within SHAPE_SLACK (23 -> 24, 16 -> 17)
+    shapes = [(24, 5, 10), (24, 7, 10), (17, 5, 8), (23, 5, 10), (16, 5, 8), (24, 9, 10)]
     hist, finals, stats = [], [], []
     for use_graph in (False, True):
         flow = build_flow_product(tiny_meta["flow"], DEV, num)
@@ -110,7 +111,7 @@ def test_trainer_graph_path_equals_eager_path(tiny_meta):
         hist.append(tr.history)
         finals.append({k: v.detach().clone() for k, v in jm.named_parameters() if v.requires_grad})
         stats.append(tr.graph_stats)
-    assert stats[0]["replays"] == 0 and stats[1]["replays"] >= 6 and stats[1]["captures"] >= 2, stats
+    assert stats[0]["replays"] == 0 and stats[1]["replays"] == 12 and stats[1]["captures"] == 2 and stats[1]["eager"] == 0, stats
     assert len(hist[0]) == len(hist[1]) == 6
     for a, b in zip(*hist):
         for k in ("loss", "llm_loss", "flow_loss", "lr", "grad_norm"):
