@@ -6,6 +6,7 @@
 // the eight partial tiles are summed through LDS.  M/32 blocks x 8 waves: 1000+ waves in flight.
 //
 // Replaces (reference): the x @ lora_A.T product of lora.py:71-73 (and its transpose in backward).
+#include <stdlib.h>
 #include "gemm_common.h"
 
 template <int RB, int MT, int KS>      // RB = R / 16 column tiles, MT = 16-row tiles per block, KS = k-steps in flight per wave
@@ -86,12 +87,16 @@ int skinny_launch(const GP<bf16_t>& p, hipStream_t st) {
                        p.out_stride == 1 && p.out_off == 0 && !p.out_len;
     if (!ident || p.fuse || p.R > 0 || p.bias || p.act || p.preact || p.dact_src || p.residual) return 1;
     if (p.N > 64 || p.N % 16 != 0 || p.K % 32 != 0 || p.K < 32 || !p.vecA || !p.vecW) return 1;
-    constexpr int MT = 2;
-    dim3 grid((p.M + 16 * MT - 1) / (16 * MT));
+    // rows per block: 32 (every A fragment used twice) unless that leaves half the chip without a block -- measured
+    // (tools/bench_side.py, cold): M = 4000, K = 1536, R = 48: 12.3 us at 32 rows (125 blocks), 10.0 at 16 (250), 16.6 at 64;
+    // from M = 5376 up 16 rows lose (20.2 -> 25.7 us at K = 3072: A is re-read from L2 once per block)
+    static const int mt_forced = getenv("CVFT_SKINNY_MT") ? atoi(getenv("CVFT_SKINNY_MT")) : 0;
+    const int mt_env = mt_forced ? mt_forced : (p.M <= 4096 ? 1 : 2);
     const int ksteps_per_wave = (p.K / 32 + 7) / 8;
-#define SK_LAUNCH(RBv, KSv) hipLaunchKernelGGL((skinny_kernel<RBv, MT, KSv>), grid, dim3(512), 0, st, p.M, p.K, p.A, p.lda, p.W, p.ldw, \
+#define SK_LAUNCH(RBv, MTv, KSv) hipLaunchKernelGGL((skinny_kernel<RBv, MTv, KSv>), dim3((p.M + 16 * MTv - 1) / (16 * MTv)), dim3(512), 0, st, p.M, p.K, p.A, p.lda, p.W, p.ldw, \
                                                p.alpha, p.C, p.ldc)
-#define SK_RB(RBv) do { if (ksteps_per_wave >= 4) SK_LAUNCH(RBv, 4); else if (ksteps_per_wave >= 2) SK_LAUNCH(RBv, 2); else SK_LAUNCH(RBv, 1); } while (0)
+#define SK_KS(RBv, MTv) do { if (ksteps_per_wave >= 4) SK_LAUNCH(RBv, MTv, 4); else if (ksteps_per_wave >= 2) SK_LAUNCH(RBv, MTv, 2); else SK_LAUNCH(RBv, MTv, 1); } while (0)
+#define SK_RB(RBv) do { if (mt_env == 1) SK_KS(RBv, 1); else if (mt_env == 4) SK_KS(RBv, 4); else SK_KS(RBv, 2); } while (0)
     switch (p.N / 16) {
         case 1: SK_RB(1); break;
         case 2: SK_RB(2); break;
@@ -99,6 +104,7 @@ int skinny_launch(const GP<bf16_t>& p, hipStream_t st) {
         default: SK_RB(4); break;
     }
 #undef SK_RB
+#undef SK_KS
 #undef SK_LAUNCH
     cvft_set_kernel_label("skinny_kernel<bf16,r%d>", p.N);
     CVFT_LAUNCH_CHECK("cvft_gemm");
@@ -357,17 +363,21 @@ extern "C" int cvft_ln_skinny_dropout(int M, int K, int R, const void* X, const 
     bool shared = true;
     for (int t = 1; t < nt; ++t) shared = shared && sites[t] == sites[0];
     CVFT_CHECK_ARG(nt == 1 || !shared, "cvft_ln_skinny_dropout: R = 48 is the stacked q|k|v form (three distinct mask sites)");
-    constexpr int MT = 2;
-    dim3 grid((M + 16 * MT - 1) / (16 * MT));
     const int ksteps_per_wave = (K / 32 + 7) / 8;              // 1 .. 4: the wave's whole K slice stays in registers
     uint4 st = make_uint4(sites[0], nt > 1 ? sites[1] : 0u, nt > 2 ? sites[2] : 0u, 0u);
     const LnArgs ln = {gamma, beta, eps, (bf16_t*)Y, mean, rstd};
-#define LSK_LAUNCH(RBv, KSv) hipLaunchKernelGGL((skinny_dropout_kernel<RBv, MT, KSv, false, true>), grid, dim3(512), 0, (hipStream_t)stream, M, K, \
+    // 16 rows per block while 32 would leave half the chip without a block (the estimator's half batches), like skinny_launch
+    static const int mt_forced = getenv("CVFT_SKINNY_MT") ? atoi(getenv("CVFT_SKINNY_MT")) : 0;
+    const int mt = mt_forced ? mt_forced : (M <= 4096 ? 1 : 2);
+#define LSK_LAUNCH(RBv, MTv, KSv) hipLaunchKernelGGL((skinny_dropout_kernel<RBv, MTv, KSv, false, true>), dim3((M + 16 * MTv - 1) / (16 * MTv)), dim3(512), 0, \
+                                           (hipStream_t)stream, M, K,                                                                           \
                                            (const bf16_t*)X, K, (const bf16_t*)A, lda, alpha, (bf16_t*)U, ldu, p, (const long long*)seed, st,      \
                                            (bf16_t*)(xd ? xd[0] : nullptr), (bf16_t*)(xd && nt > 1 ? xd[1] : nullptr),                          \
                                            (bf16_t*)(xd && nt > 1 ? xd[2] : nullptr), ln)
-#define LSK_KS(RBv) do { if (ksteps_per_wave <= 1) LSK_LAUNCH(RBv, 1); else if (ksteps_per_wave == 2) LSK_LAUNCH(RBv, 2); else LSK_LAUNCH(RBv, 4); } while (0)
-    if (R == 16) LSK_KS(1); else LSK_KS(3);
+#define LSK_KS(RBv, MTv) do { if (ksteps_per_wave <= 1) LSK_LAUNCH(RBv, MTv, 1); else if (ksteps_per_wave == 2) LSK_LAUNCH(RBv, MTv, 2); else LSK_LAUNCH(RBv, MTv, 4); } while (0)
+#define LSK_MT(RBv) do { if (mt == 1) LSK_KS(RBv, 1); else LSK_KS(RBv, 2); } while (0)
+    if (R == 16) LSK_MT(1); else LSK_MT(3);
+#undef LSK_MT
 #undef LSK_KS
 #undef LSK_LAUNCH
     CVFT_LAUNCH_CHECK("cvft_ln_skinny_dropout");
