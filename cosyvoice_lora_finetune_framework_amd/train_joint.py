@@ -461,10 +461,13 @@ class Trainer:
             L = int((batch['text_token_len'] + batch['speech_token_len']).max()) + 3          # llm_model.build_index_maps
             L = -(-L // LM_BUCKET) * LM_BUCKET
         best, cost = None, None
+        full = len(self._graphs) >= self.max_graphs          # no capture left: any covering step beats the eager path (2.5x)
         for (T2, Lt2, Lx2, L2, B2) in list(self._layouts):
             if B2 != B or T2 < T or Lt2 < Lt or Lx2 < Lx or L2 < L:
                 continue
-            if T2 > T * (1 + SHAPE_SLACK) or Lt2 > Lt * (1 + SHAPE_SLACK) + 4 or L2 > L * (1 + SHAPE_SLACK) + LM_BUCKET:
+            if not full and (T2 > T * (1 + SHAPE_SLACK) or Lt2 > Lt * (1 + SHAPE_SLACK) + 4 or L2 > L * (1 + SHAPE_SLACK) + LM_BUCKET):
+                continue
+            if full and T2 > 2 * T:
                 continue
             c = (T2 / T) * (max(L2, 1) / max(L, 1))
             if cost is None or c < cost:

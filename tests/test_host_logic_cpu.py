@@ -312,3 +312,39 @@ def test_trainer_denominators_have_a_fixed_key_set():
             assert set(_batch_denoms(b, mode)) == keys
     assert _batch_denoms(full, "joint") == {"flow": 17 * 80.0, "llm": 11.0}
     assert _batch_denoms(None, "joint") == {"flow": 0.0, "llm": 0.0} and _batch_denoms(no_text, "joint")["llm"] == 0.0
+
+
+def test_trainer_fits_batches_to_captured_layouts():
+    """Trainer._fit_layout (host side of the captured-step path): a batch joins the layout of an already captured step when
+    that covers it within SHAPE_SLACK -- cheapest covering layout, tensors padded, exact maxima in `_true_dims` -- else
+    keeps its own dims; once the graph budget is used up any covering layout within 2x is taken; and the LM index maps
+    honour the joined step's LM length."""
+    from cosyvoice_lora_finetune_framework_amd.llm_model import TransformerLM
+    from cosyvoice_lora_finetune_framework_amd.synthetic import synth_batch
+    from cosyvoice_lora_finetune_framework_amd.train_joint import LM_BUCKET, TEXT_BUCKET, Trainer
+    batch = synth_batch([100, 80], text_lens=[9, 7], token_lens=[58, 40], seed=3, text_vocab=100, speech_vocab=50)
+    T, Lt = batch['speech_feat'].shape[1], batch['speech_token'].shape[1]
+    Lx = -(-batch['text_token'].shape[1] // TEXT_BUCKET) * TEXT_BUCKET
+    L = -(-(9 + 58 + 3) // LM_BUCKET) * LM_BUCKET
+    tr = Trainer(use_graph=False, max_graphs=4)
+    fitted, dims = tr._fit_layout(batch)
+    assert dims == (T, Lt, Lx, L, 2) and fitted['speech_feat'].shape[1] == T and fitted['text_token'].shape[1] == Lx
+    assert fitted['_true_dims'].tolist() == [Lt, T, 50, 25, 13]
+    tr._layouts += [(T + 30, Lt + 20, Lx, L + 16, 2),          # covers, but T is 30 % over: outside the slack
+                    (T + 10, Lt + 6, Lx + 16, L + 16, 2),      # covers within the slack
+                    (T + 4, Lt + 2, Lx, L, 2),                 # covers, cheapest
+                    (T + 2, Lt - 1, Lx, L, 2),                 # does not cover Lt
+                    (T + 1, Lt, Lx, L, 3)]                     # another batch size
+    fitted, dims = tr._fit_layout(batch)
+    assert dims == (T + 4, Lt + 2, Lx, L, 2)
+    assert tuple(fitted['speech_feat'].shape) == (2, T + 4, 80) and fitted['speech_token'].shape[1] == Lt + 2
+    assert torch.equal(fitted['speech_feat'][:, :T], batch['speech_feat']) and float(fitted['speech_feat'][:, T:].abs().max()) == 0.0
+    assert fitted['_true_dims'].tolist() == [Lt, T, 50, 25, 13]
+    tr._layouts = [(T + 30, Lt + 20, Lx, L + 16, 2)]
+    assert tr._fit_layout(batch)[1] == (T, Lt, Lx, L, 2)       # only an out-of-slack layout: own dims, a new capture
+    tr._graphs = {i: None for i in range(4)}                   # budget used up: the covering layout is taken anyway
+    assert tr._fit_layout(batch)[1] == (T + 30, Lt + 20, Lx, L + 16, 2)
+    # LM index maps of a batch that joined a step with a longer LM sequence
+    idx, tgt, lm_len, L2 = TransformerLM.build_index_maps(batch['text_token_len'], batch['speech_token_len'], batch['speech_token'],
+                                                          2, Lx, Lt, 50, LM_BUCKET, L + 16)
+    assert L2 == L + 16 and idx.numel() == 2 * L2 and lm_len.tolist() == [70, 50] and int((idx.reshape(2, L2)[:, 70:] >= 0).sum()) == 0
