@@ -310,7 +310,7 @@ def main():
         elapsed = float(el)
         final_loss = float(loss)
 
-    log(f"[bench] timed region done: {elapsed / a.steps * 1e3:.2f} ms/step")
+    log(f"[bench] timed region done: {elapsed / a.steps * 1e3:.2f} ms/step; device memory reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB")
     if os.environ.get("CVFT_BENCH_HOSTLAUNCH") and not a.via_trainer and graph is not None:
         hs, tot = [], []
         for _ in range(5):

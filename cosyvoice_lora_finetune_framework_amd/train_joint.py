@@ -130,6 +130,7 @@ LM_BUCKET = 16        # graph path: LM sequence length L rounded up to a multipl
 # (`_true_dims`) and the interpolation / GroupNorm kernels work from those (cvft.h `eff` / `t_eff`) -- same results, and a
 # corpus whose batches rarely repeat a shape still runs on captured steps.
 SHAPE_SLACK = float(os.environ.get("CVFT_SHAPE_SLACK", "0.125"))
+T_ALIGN, LT_ALIGN = 4, 2
 TRUE_DIM_LEVELS = 4   # `_true_dims` = [Lt_max, T_max, ceil(T_max / 2), ceil(T_max / 4), ceil(T_max / 8)]
 
 
@@ -472,7 +473,8 @@ class Trainer:
             c = (T2 / T) * (max(L2, 1) / max(L, 1))
             if cost is None or c < cost:
                 best, cost = (T2, Lt2, Lx2, L2, B2), c
-        T2, Lt2, Lx2, L2, _ = best if best is not None else (T, Lt, Lx, L, B)
+        # nothing covers it: its own layout (frames to a multiple of 4, tokens of 2: near-equal maxima share one capture)
+        T2, Lt2, Lx2, L2, _ = best if best is not None else (-(-T // T_ALIGN) * T_ALIGN, -(-Lt // LT_ALIGN) * LT_ALIGN, Lx, L, B)
         out = dict(batch)
         pad = torch.nn.functional.pad
         if T2 > T:

@@ -408,10 +408,11 @@ def test_shape_bucketed_batch_equals_exact_batch(tiny_meta):
     tr = Trainer(use_graph=False)
     outs = []
     for layout in (None, (T + 2, batch['speech_token'].shape[1] + 3, 32, 48, 3)):      # within SHAPE_SLACK of the batch
-        if layout is not None:
+        if layout is None:                      # the batch as the loader made it: exact shapes, no `_true_dims`
+            fitted, dims = batch, (T, 0, 0, 0, 3)
+        else:
             tr._layouts.append(layout)
-        fitted, dims = tr._fit_layout(batch)
-        if layout is not None:
+            fitted, dims = tr._fit_layout(batch)
             assert dims == layout and fitted['speech_feat'].shape[1] == T + 2 and int(fitted['_true_dims'][1]) == T
         prepared = jm.prepare_batch(fitted, DEV, 16, dims[3])
         d = dict(draws)
