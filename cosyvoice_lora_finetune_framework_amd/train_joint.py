@@ -361,13 +361,14 @@ class Trainer:
     On a GPU the micro-step (forward + backward) replays a captured hipGraph per batch layout (`use_graph`, default on;
     CVFT_TRAINER_GRAPH=0 or use_graph=False launches eagerly): a batch is padded up to the layout of an already captured
     step when one covers it within SHAPE_SLACK (exact maxima travel as device scalars: same results), else its own layout
-    is captured (at most `max_graphs`, eager beyond); the batch reaches the graph's static slab by one DMA + one device
+    is captured (at most `max_graphs` -- a captured step keeps its activations: ~7.6 GiB at B = 16, T ~ 500, so 16 of them
+    are ~120 of the 288 GB -- eager beyond); the batch reaches the graph's static slab by one DMA + one device
     copy; all-reduce / clip / AdamW stay outside the graph."""
 
     def __init__(self, max_epochs: int = 100, accumulate_grad_batches: int = 1, gradient_clip_val: float = 1.0,
                  callbacks: Optional[list] = None, default_root_dir: str = OUTPUT_DIR, log_every_n_steps: int = 10,
                  draws_fn=None, save_checkpoints: bool = True, train_mode: bool = True, use_graph: Optional[bool] = None,
-                 max_graphs: int = 8, on_step_end=None):
+                 max_graphs: int = 16, on_step_end=None):
         self.max_epochs, self.accum, self.clip = max_epochs, max(1, accumulate_grad_batches), gradient_clip_val
         self.train_mode = train_mode       # pl.Trainer.fit puts the module tree in .train() (dropouts active); False keeps the caller's mode
         self.callbacks = callbacks or []
