@@ -37,7 +37,17 @@ struct GP {
     int direct_epi;               // LDS-DMA kernels: register epilogue allowed (set by gemm_glds_launch)
     int xcd_nsplit;               // LDS-DMA kernels: XCDs across N (1 = linear tile ranges; 2/4/8 = rectangles, see kernel)
     float xdrop_p; const long long* xdrop_seed; unsigned xdrop_sites[4];      // masked rank extension (cvft.h); 0 = off
+    float odrop_p; unsigned odrop_site;     // output dropout (cvft.h): C = residual + keep / (1 - p) * epi(.), seed = xdrop_seed; 0 = off
 };
+
+// keep / (1 - p) factors of the output-dropout mask for the 4-element group holding flat output element `idx` (idx % 4 == 0)
+__device__ __forceinline__ void gemm_odrop4(const float p, const long long* seed, const unsigned site, const unsigned long long idx, float* v) {
+    bool k4[4];
+    cvft_keep4(cvft_drop_key(seed, site), idx >> 2, cvft_drop_thr(p), k4);
+    const float inv = 1.f / (1.f - p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = k4[e] ? v[e] * inv : 0.f;
+}
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define CVFT_OOB 0x80000000u      // byte offset past every buffer (< 2 GiB each, host-checked): the load returns 0
@@ -91,6 +101,10 @@ __device__ __forceinline__ void gemm_epilogue_store(const GP<T>& p, const float*
                 for (int e = 0; e < VEC; ++e) ds[e] = to_f32(de[e]);
                 act_grad_mul_vec<VEC>(p.dact, v, ds);
             }
+            if (p.odrop_p > 0.f) {
+#pragma unroll
+                for (int e = 0; e < VEC; e += 4) gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, orow * (unsigned long long)p.N + nb + e, v + e);
+            }
             if (p.residual) {
                 uint4 rv = *reinterpret_cast<const uint4*>(&p.residual[orow * p.ldr + nb]);
                 const T* re = reinterpret_cast<const T*>(&rv);
@@ -109,6 +123,12 @@ __device__ __forceinline__ void gemm_epilogue_store(const GP<T>& p, const float*
                 if (p.preact) p.preact[orow * p.ldp + n] = from_f32<T>(x);
                 x = act_apply(p.act, x);
                 if (p.dact_src) x *= act_grad(p.dact, to_f32(p.dact_src[orow * p.ldd + n]));
+                if (p.odrop_p > 0.f) {
+                    const unsigned long long idx = orow * (unsigned long long)p.N + n;
+                    bool k4[4];
+                    cvft_keep4(cvft_drop_key(p.xdrop_seed, p.odrop_site), idx >> 2, cvft_drop_thr(p.odrop_p), k4);
+                    x = k4[idx & 3] ? x / (1.f - p.odrop_p) : 0.f;
+                }
                 if (p.residual) x += to_f32(p.residual[orow * p.ldr + n]);
                 if (!live) x = 0.f;
                 p.C[orow * p.ldc + n] = from_f32<T>(x);
@@ -147,6 +167,7 @@ __device__ __forceinline__ void gemm_epilogue_direct4(const GP<bf16_t>& p, const
         float ds[4] = {(float)d[0], (float)d[1], (float)d[2], (float)d[3]};
         act_grad_mul_vec<4>(p.dact, v, ds);
     }
+    if (p.odrop_p > 0.f) gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, orow * (unsigned long long)p.N + n, v);
     if (p.residual) {
         const bf16x4 r = *reinterpret_cast<const bf16x4*>(&p.residual[orow * p.ldr + n]);
 #pragma unroll
@@ -191,6 +212,10 @@ __device__ __forceinline__ void gemm_epilogue_direct8(const GP<bf16_t>& p, const
 #pragma unroll
         for (int e = 0; e < 8; ++e) ds[e] = (float)d[e];
         act_grad_mul_vec<8>(p.dact, v, ds);
+    }
+    if (p.odrop_p > 0.f) {
+        gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, orow * (unsigned long long)p.N + n, v);
+        gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, orow * (unsigned long long)p.N + n + 4, v + 4);
     }
     if (p.residual) {
         const bf16x8 r = *reinterpret_cast<const bf16x8*>(&p.residual[orow * p.ldr + n]);

@@ -52,6 +52,7 @@ class GemmArgs(C.Structure):
         ("C", C.c_void_p), ("ldc", C.c_int),
         ("La", C.c_void_p), ("ldla", C.c_int), ("lora_scale", C.c_float), ("Uout", C.c_void_p),
         ("xdrop_p", C.c_float), ("xdrop_seed", C.c_void_p), ("xdrop_sites", C.c_uint * 4),
+        ("odrop_p", C.c_float), ("odrop_site", C.c_uint),
     ]
 
 

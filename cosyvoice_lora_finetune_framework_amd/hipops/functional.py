@@ -57,8 +57,9 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
          geo: Optional[Geo] = None, nb: int = 1, in_len: Optional[torch.Tensor] = None,
          out_len: Optional[torch.Tensor] = None, out_rows: Optional[int] = None,
          La: Optional[torch.Tensor] = None, lora_scale: float = 1.0, Uout: Optional[torch.Tensor] = None,
-         xdrop=None) -> torch.Tensor:
+         xdrop=None, odrop=None) -> torch.Tensor:
     """C = epi(alpha * (taps(x) @ W^T + U @ Bl^T) + bias); W is [N][ntaps*K] (k contiguous).
+    odrop = (p, site): output dropout in the epilogue, C = residual + keep(site) / (1 - p) * epi(.) (cvft.h).
     xdrop = (p, sites): the U Bl^T term enters per 16-wide rank tile t as mask_t / (1 - p) * (U_t Bl_t^T), masks over the
     output elements (the lora_dropout dgrad; include/cvft.h)."""
     assert x.dim() == 2 and W.dim() == 2 and x.dtype == W.dtype
@@ -111,6 +112,9 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
         a.xdrop_p, a.xdrop_seed = float(xdrop[0]), ptr(_DROPOUT["seed"])
         for i, st in enumerate(xdrop[1]):
             a.xdrop_sites[i] = st
+    if odrop is not None:
+        assert out.stride(0) == N and N % 4 == 0
+        a.odrop_p, a.odrop_site, a.xdrop_seed = float(odrop[0]), int(odrop[1]), ptr(_DROPOUT["seed"])
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -139,7 +143,8 @@ def quant_fp8_rows(x: torch.Tensor):
 
 
 def gemm_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, bias=None, U=None, Bl=None, alpha: float = 1.0,
-             act: Optional[str] = None, preact=None, dact_src=None, dact: Optional[str] = None, residual=None, out=None) -> torch.Tensor:
+             act: Optional[str] = None, preact=None, dact_src=None, dact: Optional[str] = None, residual=None, out=None,
+             odrop=None) -> torch.Tensor:
     """C[M, N] bf16 = epi(alpha * (xs[m] ws[n] (xq wq^T) + U Bl^T) + bias) on e4m3 operands (quant_fp8_rows); LoRA term, bias,
     activation and residual as in gemm()."""
     M, K = xq.shape
@@ -164,6 +169,8 @@ def gemm_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Ten
     if residual is not None:
         a.residual, a.ldr = ptr(residual), residual.stride(0)
     a.C, a.ldc = ptr(out), out.stride(0)
+    if odrop is not None:
+        a.odrop_p, a.odrop_site, a.xdrop_seed = float(odrop[0]), int(odrop[1]), ptr(_DROPOUT["seed"])
     check(lib().cvft_gemm_fp8(C.byref(a), ptr(xq), xq.stride(0), ptr(xs), ptr(wq), wq.stride(0), ptr(ws), stream()), "cvft_gemm_fp8")
     return out
 
@@ -503,6 +510,8 @@ class LoraGradSink:
         self.streams = {}                 # streams that received slab launches (the LLM / Flow branches may run on two)
         self.keep = []                    # operands of side-stream / deferred launches stay alive until the join
         self.deferred = {}                # rank -> table rows of slab products postponed to flush()
+        self.uses = {}                    # id(parameter) -> [slab units handed out in this backward, their buffer]
+        self.task_of = {}                 # (grad, geometry) -> index of its latest reduce task (merged when slabs are contiguous)
         self.side = None
         if side_stream:
             if LoraGradSink._side is None:
@@ -574,34 +583,66 @@ class LoraGradSink:
             check(lib().cvft_lora_rank_partial_batch(r, len(rows), arr, stream()), "cvft_lora_rank_partial_batch")
         self.deferred = {}
 
-    @staticmethod
-    def workspace(P: torch.Tensor, nsplit: int) -> torch.Tensor:
-        need = nsplit * P.numel()
-        ws = getattr(P, "_cvft_part", None)
-        if ws is None or ws.numel() < need:
-            # A captured step holds the ADDRESS of the workspace it was captured with; a later batch layout with more
-            # row blocks needs a bigger one.  The old buffer is never freed (it stays that step's workspace): freeing it
-            # let later allocations land under the slab writes of the older captured step (GPU memory fault in the
-            # trainer's multi-layout path).  The new one gets headroom so that nearby layouts share it.
-            if ws is not None:
-                P.__dict__.setdefault("_cvft_part_retired", []).append(ws)
-            ws = torch.empty(need + need // 4, dtype=torch.float32, device=P.device)
-            P._cvft_part = ws
+    def workspace(self, P: torch.Tensor, nsplit: int) -> torch.Tensor:
+        """Slab workspace (nsplit x P.numel() floats) for the next product on parameter P inside this sink.  Several
+        products may hit the SAME parameter within one backward -- the sub-batch chains of a branch run the same adapters
+        concurrently on their own streams (llm_flow_model.SPLIT); shared weights -- so every product gets its own slab
+        range, laid out back to back in one per-parameter buffer: a chain never writes slabs another product owns, and
+        the products' reduce tasks merge into ONE task per gradient (add / add_block; two tasks on one gradient in the
+        same reduce launch would race on its read-modify-write)."""
+        unit = P.numel()
+        st = self.uses.get(id(P))
+        if st is None:
+            st = self.uses[id(P)] = [0, None]                 # units handed out in this backward, the buffer they come from
+        total = st[0] + nsplit
+        if st[1] is None:
+            hint = max(getattr(P, "_cvft_ws_units", 0), total)      # what an earlier backward needed in all
+            buf = getattr(P, "_cvft_part", None)
+            if buf is None or buf.numel() < hint * unit:
+                # A captured step holds the ADDRESS of the workspace it was captured with; a later batch layout with more
+                # row blocks needs a bigger one.  The old buffer is never freed (it stays that step's workspace): freeing
+                # it let later allocations land under the slab writes of the older captured step (GPU memory fault in the
+                # trainer's multi-layout path).  The new one gets headroom so that nearby layouts share it.
+                if buf is not None:
+                    P.__dict__.setdefault("_cvft_part_retired", []).append(buf)
+                buf = torch.empty(hint * unit + hint * unit // 4, dtype=torch.float32, device=P.device)
+                P._cvft_part = buf
+            st[1] = buf
+        if total * unit <= st[1].numel() and (unit % 4 == 0 or st[0] == 0):
+            ws = st[1][st[0] * unit: total * unit]
+        else:
+            # more products on this parameter than any earlier backward had (or slabs that would lose their 16-byte
+            # alignment): a buffer of its own now -- its reduce task goes into a later reduce launch (flush) -- and one
+            # contiguous range from the next backward on
+            ws = torch.empty(nsplit * unit, dtype=torch.float32, device=P.device)
+            P.__dict__.setdefault("_cvft_part_retired", []).append(ws)
+        st[0] = total
+        P._cvft_ws_units = max(getattr(P, "_cvft_ws_units", 0), total)
         return ws
 
     def _note_stream(self):
         st = torch.cuda.current_stream()
         self.streams[st.cuda_stream] = st
 
+    def _task(self, part_ptr: int, grad: torch.Tensor, rows: int, cols: int, pitch: int, stride: int, nsplit: int):
+        self._note_stream()
+        key = (grad.data_ptr(), rows, cols, pitch, stride)
+        i = self.task_of.get(key)
+        if i is not None:
+            t = self.tasks[i]
+            if t[0] + t[6] * stride * 4 == part_ptr:          # the slabs follow the earlier product's: one longer task
+                self.tasks[i] = t[:6] + (t[6] + nsplit, 0)
+                return
+        self.task_of[key] = len(self.tasks)
+        self.tasks.append((part_ptr, grad.data_ptr(), rows, cols, pitch, stride, nsplit, 0))
+
     def add(self, part: torch.Tensor, grad: torch.Tensor, numel: int, nsplit: int):
         """grad (contiguous, numel) += sum of nsplit contiguous slabs."""
-        self._note_stream()
-        self.tasks.append((part.data_ptr(), grad.data_ptr(), 1, numel, numel, numel, nsplit, 0))
+        self._task(part.data_ptr(), grad, 1, numel, numel, numel, nsplit)
 
     def add_block(self, part_ptr: int, grad: torch.Tensor, rows: int, cols: int, pitch: int, stride: int, nsplit: int):
         """grad [rows, cols] += sum over slabs of the [rows, cols] sub-block at part_ptr (row pitch / slab stride in floats)."""
-        self._note_stream()
-        self.tasks.append((part_ptr, grad.data_ptr(), rows, cols, pitch, stride, nsplit, 0))
+        self._task(part_ptr, grad, rows, cols, pitch, stride, nsplit)
 
     def flush(self):
         if not self.tasks:
@@ -619,12 +660,26 @@ class LoraGradSink:
         ent = LoraGradSink._cache.get(key)
         if ent is None:
             dev = torch.device("cuda", torch.cuda.current_device())
-            tbl = torch.tensor(self.tasks, dtype=torch.int64).to(dev)
-            ent = (tbl, min(64, max(1, -(-max(t[2] * t[3] for t in self.tasks) // 1024))))
-            # (entries are never dropped: a captured step holds the address of its task table)
+            # one reduce launch adds every task's slabs into its gradient with a plain read-modify-write: tasks that
+            # share a gradient (products whose slabs could not be merged) go into successive launches
+            waves, seen = [], []
+            for t in self.tasks:
+                w = next((i for i, g in enumerate(seen) if t[1] not in g), None)
+                if w is None:
+                    waves.append([])
+                    seen.append(set())
+                    w = len(waves) - 1
+                waves[w].append(t)
+                seen[w].add(t[1])
+            ent = [(torch.tensor(w, dtype=torch.int64).to(dev), len(w), min(64, max(1, -(-max(t[2] * t[3] for t in w) // 1024))))
+                   for w in waves]
+            # (entries are never dropped: a captured step holds the address of its task tables)
             LoraGradSink._cache[key] = ent
-        check(lib().cvft_lora_grad_reduce(len(self.tasks), ptr(ent[0]), ent[1], stream()), "cvft_lora_grad_reduce")
+        for tbl, n, gx in ent:
+            check(lib().cvft_lora_grad_reduce(n, ptr(tbl), gx, stream()), "cvft_lora_grad_reduce")
         self.tasks = []
+        self.task_of = {}
+        self.uses = {}
 
 
 import os as _os
@@ -683,7 +738,7 @@ def _widen_zero_padded(t: torch.Tensor, pitch: int) -> torch.Tensor:
     return w
 
 
-def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residual, keep_preact: bool, drop=None):
+def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residual, keep_preact: bool, drop=None, odrop=None):
     """One LoRA linear forward: y = act(x W^T + b + scale * (x A^T) B^T) (+ residual).
     Returns (y, U, z, ops): U = scale * x A^T [M, r] (saved for dB), z = pre-activation (when kept), ops = the
     compute-dtype (A, A^T, B, B^T) operands."""
@@ -709,9 +764,11 @@ def _lin_fwd(x, A, B, pack: LinearPack, scale: float, act: Optional[str], residu
         z = torch.empty((x.shape[0], pack.N), dtype=x.dtype, device=x.device)
     res = None if residual is None else _c(residual)
     if fused:
-        y = gemm(x, pack.Wf, bias=pack.bias, La=ops[0], lora_scale=scale, Uout=U, Bl=ops[2], act=act, preact=z, residual=res)
+        y = gemm(x, pack.Wf, bias=pack.bias, La=ops[0], lora_scale=scale, Uout=U, Bl=ops[2], act=act, preact=z, residual=res,
+                 odrop=odrop)
     else:
-        y = _mm(x, pack, 'f', pack.Wf, bias=pack.bias, U=U, Bl=None if ops is None else ops[2], act=act, preact=z, residual=res)
+        y = _mm(x, pack, 'f', pack.Wf, bias=pack.bias, U=U, Bl=None if ops is None else ops[2], act=act, preact=z, residual=res,
+                odrop=odrop)
     return y, U, z, ops
 
 
@@ -745,14 +802,14 @@ def _lora_param_grads(x, U, V, dz, A_ref, B_ref, ops):
                 defer = sink.will_defer(x, dz)
                 rpa, nsa = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, x.shape[1])
                 rpb_, nsb = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, dz.shape[1])
-                wsA, wsB = LoraGradSink.workspace(A, nsa), LoraGradSink.workspace(B, nsb)
+                wsA, wsB = sink.workspace(A, nsa), sink.workspace(B, nsb)
                 sink.rank_pair(defer, M, r, x.shape[1], x, V, wsA, rpa, dz.shape[1], dz, U, wsB, rpb_)
                 sink.add(wsA, gA, A.numel(), nsa)
                 sink.add(wsB, gB, B.numel(), nsb)
             else:
                 for Wd, Rk, P, g, tr in ((x, V, A, gA, False), (dz, U, B, gB, True)):
                     rpb, ns = LoraGradSink.plan(M, Wd.shape[1])
-                    ws = LoraGradSink.workspace(P, ns)
+                    ws = sink.workspace(P, ns)
                     check(lib().cvft_lora_rank_partial(dt(Wd), M, Wd.shape[1], r, ptr(Wd), Wd.stride(0), ptr(Rk),
                                                        Rk.stride(0), ptr(ws), int(tr), rpb, stream()), "cvft_lora_rank_partial")
                     sink.add(ws, g, P.numel(), ns)
@@ -808,19 +865,23 @@ class LinearFn(torch.autograd.Function):
     accumulated straight into the parameters' (flat) .grad buffers when those exist."""
 
     @staticmethod
-    def forward(ctx, x, A, B, residual, pack: LinearPack, scale: float, act: Optional[str], drop_p: float = 0.0):
+    def forward(ctx, x, A, B, residual, pack: LinearPack, scale: float, act: Optional[str], drop_p: float = 0.0,
+                out_drop_p: float = 0.0):
         x = _c(x)
         need_grad = any(ctx.needs_input_grad[:3])
         ctx.padded = False
         ctx.drop = [float(drop_p), _next_drop_site()] if (drop_p > 0 and A is not None) else None
-        if A is None and act is None and residual is None and pack.Npad != pack.N:
+        # y = residual + dropout(linear(x)) (encoder_layer.py:95 / 104) with the mask applied in the GEMM epilogue; backward
+        # re-derives it from the site (one cvft_dropout_add pass over dy)
+        ctx.odrop = (float(out_drop_p), _next_drop_site()) if out_drop_p > 0 else None
+        if A is None and act is None and residual is None and pack.Npad != pack.N and ctx.odrop is None:
             Wf, bias, _ = pack.padded
             y = gemm(x, Wf, bias=bias)                                  # [M][Npad], pad columns exactly zero
             _register_zero_padded(y)
             ctx.pack, ctx.padded = pack, True
             ctx.save_for_backward(x, None, None)
             return y[:, :pack.N]
-        y, U, z, ops = _lin_fwd(x, A, B, pack, scale, act, residual, need_grad, ctx.drop)
+        y, U, z, ops = _lin_fwd(x, A, B, pack, scale, act, residual, need_grad, ctx.drop, ctx.odrop)
         ctx.pack, ctx.scale, ctx.act = pack, scale, act
         ctx.ops, ctx.A_ref, ctx.B_ref = ops, A, B
         ctx.save_for_backward(x, U, z)
@@ -831,13 +892,15 @@ class LinearFn(torch.autograd.Function):
         x, U, z = ctx.saved_tensors
         if ctx.padded:
             dx = gemm(_widen_zero_padded(dy, ctx.pack.Npad), ctx.pack.padded[2]) if ctx.needs_input_grad[0] else None
-            return dx, None, None, None, None, None, None, None
-        dy = _c(dy) if ctx.act else _rowc(dy)
+            return dx, None, None, None, None, None, None, None, None
+        dy = _c(dy) if (ctx.act or ctx.odrop) else _rowc(dy)
+        dres = dy if ctx.needs_input_grad[3] else None
+        if ctx.odrop is not None:
+            dy = dropout_raw(dy, ctx.odrop[0], ctx.odrop[1])
         dz = act_bwd(z, dy, ctx.act) if ctx.act else dy
         dx, dA, dB = _lin_bwd(x, U, ctx.ops, ctx.A_ref, ctx.B_ref, ctx.pack, ctx.scale, dz, ctx.needs_input_grad[0],
                               ctx.needs_input_grad[1] or ctx.needs_input_grad[2], drop=ctx.drop)
-        dres = dy if ctx.needs_input_grad[3] else None
-        return dx, dA, dB, dres, None, None, None, None
+        return dx, dA, dB, dres, None, None, None, None, None
 
 
 class LinearQKVFn(torch.autograd.Function):
@@ -950,8 +1013,8 @@ class LinearQKVStackedFn(torch.autograd.Function):
             defer = r3 in (16, 32, 48, 64) and sink.will_defer(x, dY)
             rpa, nsa = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, K)
             rpb_, nsb = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, 3 * N)
-            wsA = LoraGradSink.workspace(ctx.refs[0][0], nsa * 3)       # slab [3r, K] per row block
-            wsB = LoraGradSink.workspace(ctx.refs[0][1], nsb * 9)       # slab [3N, 3r] per row block
+            wsA = sink.workspace(ctx.refs[0][0], nsa * 3)       # slab [3r, K] per row block
+            wsB = sink.workspace(ctx.refs[0][1], nsb * 9)       # slab [3N, 3r] per row block
             sink.rank_pair(defer, M, r3, K, x, V, wsA, rpa, 3 * N, dY, U, wsB, rpb_)
             for i, (gA, _) in enumerate(grads):
                 sink.add_block(wsA.data_ptr() + i * r * K * 4, gA, r, K, K, r3 * K, nsa)
@@ -991,8 +1054,8 @@ class LinearQKVStackedFn(torch.autograd.Function):
             defer = STACKED_DROP_DEFER and r == 16 and r3 == 48 and sink.will_defer(x, dY)
             rpa, nsa = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, K)
             rpb_, nsb = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, 3 * N)
-            wsB = LoraGradSink.workspace(ctx.refs[0][1], nsb * 9)
-            keep = [LoraGradSink.workspace(ctx.refs[i][0], nsa) for i in range(3)]
+            wsB = sink.workspace(ctx.refs[0][1], nsb * 9)
+            keep = [sink.workspace(ctx.refs[i][0], nsa) for i in range(3)]
             if defer:                       # the four slab products join the sink's end-of-backward batch launches
                 for i in range(3):
                     sink.defer_one(M, r, K, xds[i], V[:, i * r:(i + 1) * r], keep[i], 0, rpa, keep=(V,))
@@ -1093,10 +1156,14 @@ def lora_side(xd, A, B, base, scale: float):
 
 
 def lora_linear(x, pack: LinearPack, A=None, B=None, scale: float = 1.0, act: Optional[str] = None, residual=None,
-                drop_p: float = 0.0):
-    """drop_p > 0 (train mode, lora.py:70): the side path sees dropout(x); needs _can_drop_fuse(x, r)."""
-    return LinearFn.apply(x, A, B, residual, pack, scale, act, drop_p)
+                drop_p: float = 0.0, out_drop_p: float = 0.0):
+    """drop_p > 0 (train mode, lora.py:70): the side path sees dropout(x); needs _can_drop_fuse(x, r).
+    out_drop_p > 0: y = residual + dropout(act(linear(x))), mask in the GEMM epilogue (N % 4 == 0)."""
+    return LinearFn.apply(x, A, B, residual, pack, scale, act, drop_p, out_drop_p)
 
+
+# residual + dropout(linear(.)) with the mask in the GEMM epilogue instead of a cvft_dropout_add pass (CVFT_OUT_DROP_FUSE=0: A/B)
+OUT_DROP_FUSE = _os.environ.get("CVFT_OUT_DROP_FUSE", "1") != "0"
 
 _QKV_STACKS = {}
 QKV_STACKING = _os.environ.get("CVFT_QKV_STACK", "1") != "0"

@@ -71,23 +71,29 @@ def _lin_parts(mod: nn.Module):
 
 
 def hip_linear(mod: nn.Module, x: torch.Tensor, dtype: Optional[torch.dtype] = None, act: Optional[str] = None,
-               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+               residual: Optional[torch.Tensor] = None, out_drop: float = 0.0) -> torch.Tensor:
     """x [rows, in] -> [rows, out] through the fused LoRA tap-GEMM.  `mod` is an nn.Linear,
-    a 1x1 nn.Conv1d, or their LoRA wrappers."""
+    a 1x1 nn.Conv1d, or their LoRA wrappers.  out_drop > 0: residual + dropout(linear(x)) (encoder_layer.py:95 / 104) with
+    the mask applied in the GEMM epilogue (HF.OUT_DROP_FUSE, out features % 4 == 0), else a cvft_dropout_add pass."""
     dtype = x.dtype if dtype is None else dtype
     base, w, b, A, Bm, scale, drop = _lin_parts(mod)
     pack = _cached(base, "lin", base.weight, dtype, lambda: HF.LinearPack(w, b, dtype))
     if x.dtype != dtype:
         x = x.to(dtype)
+    od = out_drop if (out_drop > 0 and HF.OUT_DROP_FUSE and pack.N % 4 == 0) else 0.0
+    if od == 0.0 and out_drop > 0:
+        return HF.dropout_add(hip_linear(mod, x, dtype, act), out_drop, residual)
     if A is not None and _lora_dropout_on(mod, drop):
         # reference lora.py:70: dropout on the side-path input only.  Fused form (mask inside the rank-side kernels,
         # counter-based) when the shapes allow, else nn.Dropout + separate side-path launches
         if type(drop) is nn.Dropout and HF._can_drop_fuse(x, A.shape[0]):
-            y = HF.lora_linear(x, pack, A, Bm, scale, act, residual, drop_p=drop.p)
+            y = HF.lora_linear(x, pack, A, Bm, scale, act, residual, drop_p=drop.p, out_drop_p=od)
             HF.drop_pre_u(x)                                 # (a hand-off from the LayerNorm launch nobody took is dropped here)
             return y
+        if od > 0:
+            return HF.dropout_add(_lora_dropout_path(x, pack, A, Bm, scale, drop, act, None), od, residual)
         return _lora_dropout_path(x, pack, A, Bm, scale, drop, act, residual)
-    return HF.lora_linear(x, pack, A, Bm, scale, act, residual)
+    return HF.lora_linear(x, pack, A, Bm, scale, act, residual, out_drop_p=od)
 
 
 def _lora_dropout_on(mod: nn.Module, drop) -> bool:
@@ -519,9 +525,8 @@ class RelPositionMultiHeadedAttention(nn.Module):
             p = hip_linear(self.linear_pos, pos_emb)
         o = HF.attn_relpos(q, k, v, p, _f32(self.pos_bias_u), _f32(self.pos_bias_v), B, self.h, L, length, causal,
                            1.0 / math.sqrt(self.d_k), dropout_p=self.dropout_rate if self.training else 0.0)
-        if out_dropout > 0:       # x = residual + dropout(linear_out(.))  (encoder_layer.py:95 / 205)
-            return HF.dropout_add(hip_linear(self.linear_out, o), out_dropout, residual)
-        return hip_linear(self.linear_out, o, residual=residual)
+        # x = residual + dropout(linear_out(.))  (encoder_layer.py:95 / 205)
+        return hip_linear(self.linear_out, o, residual=residual, out_drop=out_dropout)
 
 
 class PositionwiseFeedForward(nn.Module):
@@ -539,7 +544,7 @@ class PositionwiseFeedForward(nn.Module):
                 h = HF.act_dropout(hip_linear(self.w_1, y), self.activation, self.dropout_rate)
             else:
                 h = hip_linear(self.w_1, y, act=self.activation)
-            return HF.dropout_add(hip_linear(self.w_2, h), out_dropout, residual)
+            return hip_linear(self.w_2, h, residual=residual, out_drop=out_dropout)
         return hip_ffn(self.w_1, self.w_2, y, self.activation, residual=residual)
 
 

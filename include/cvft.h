@@ -86,6 +86,11 @@ typedef struct {
      * bf16, LDS-DMA kernels with the register epilogue only (identity rows, K % 64 == 0, N % 4 == 0, R % 16 == 0, R <= 64);
      * any other launch is an error. */
     float xdrop_p; const int64_t* xdrop_seed; unsigned xdrop_sites[4];
+    /* output dropout (x = residual + dropout(linear(.)), encoder_layer.py:95 / 104): when odrop_p > 0 the epilogue result is
+     * multiplied by keep[m * N + n] / (1 - p) BEFORE the residual is added -- the counter-based mask of (xdrop_seed, odrop_site),
+     * the one cvft_dropout_add(site) applies to a contiguous [M, N] tensor (its backward).  Needs N % 4 == 0, ldc == N,
+     * identity row geometry and a seed; every GEMM kernel honours it. */
+    float odrop_p; unsigned odrop_site;
 } cvft_gemm_args;
 
 int cvft_gemm(const cvft_gemm_args* a, void* stream);

@@ -390,6 +390,50 @@ def test_sub_batch_chains_reproduce_global_batch_means(tiny_meta):
         assert max(rel(o[1][k], outs[0][1][k]) for k in outs[0][1]) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sub_batch_chains_with_gradient_sink(tiny_meta, dtype):
+    """The trainer's configuration of the same thing: rank-16 adapters, pre-allocated fp32 .grad buffers and an active
+    LoraGradSink (slab workspaces + one reduce) while the sub-batch chains of a branch run concurrently on the SAME
+    adapters -- every chain must own its slabs.  Gradients equal the one-chain step's."""
+    import copy
+    from cosyvoice_lora_finetune_framework_amd import llm_flow_model as J
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    meta = copy.deepcopy(tiny_meta)
+    for k in ("flow", "llm"):
+        meta[k]["lora"]["r"], meta[k]["lora"]["alpha"] = 16, 32
+    num = Numerics(dtype=dtype)
+    flow = build_flow_product(meta["flow"], DEV, num)
+    llm = build_llm_product(meta["llm"], DEV, num)
+    jm = J.JointLLMFlowModel(llm, flow, 'joint', 2.0, 1.0).to(DEV).eval()
+    batch = synth_batch([24, 17, 21, 19], text_lens=[7, 5, 6, 4], token_lens=[13, 9, 11, 10], seed=11, text_vocab=100, speech_vocab=50)
+    draws = cfm_draws(4, 24, seed=5)
+    params = [(n, p) for n, p in jm.named_parameters() if p.requires_grad]
+    outs = []
+    for split in ({'llm': 1, 'flow': 1}, {'llm': 2, 'flow': 2}, {'llm': 1, 'flow': 4}):
+        J.SPLIT.update(split)
+        min_part, J.SPLIT_MIN_PART = J.SPLIT_MIN_PART, 1
+        try:
+            # twice: the first backward of a split meets more products per adapter than the slab buffer was sized for
+            # (separate buffers, reduce tasks in successive launches), the second finds one contiguous range (merged tasks)
+            for rep in range(2):
+                for _, p in params:
+                    p.grad = torch.zeros_like(p, dtype=torch.float32)
+                out = jm(batch, DEV, draws)
+                with HF.LoraGradSink():
+                    out['loss'].backward()
+                torch.cuda.synchronize()
+                outs.append({n: p.grad.clone() for n, p in params})
+        finally:
+            J.SPLIT.update({'llm': 1, 'flow': 2})
+            J.SPLIT_MIN_PART = min_part
+    tol = 1e-4 if dtype == torch.float32 else 4e-2
+    for o in outs[1:]:
+        worst = max((rel(o[k], outs[0][k]), k) for k in outs[0] if float(outs[0][k].norm()) > 0)
+        assert worst[0] < tol, worst
+
+
 def test_shape_bucketed_batch_equals_exact_batch(tiny_meta):
     """train_joint.Trainer._fit_layout: a batch padded up to the layout of another captured step (T, Lt, text, LM length all
     larger, `_true_dims` = the exact maxima) gives the exact batch's losses and LoRA gradients -- the length regulator's

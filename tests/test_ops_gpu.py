@@ -655,6 +655,57 @@ def test_dropout_add_statistics_and_backward_mask(dtype):
     assert HF.dropout_add(x.detach(), 0.0) is not None
 
 
+@pytest.mark.parametrize("dtype,M,N,K,r", [(torch.float32, 300, 128, 48, 0), (torch.bfloat16, 2048, 1024, 1024, 16),
+                                         (torch.bfloat16, 5328, 1024, 4096, 16), (torch.bfloat16, 500, 260, 64, 0),
+                                         (torch.bfloat16, 640, 512, 2048, 16), (torch.float32, 77, 36, 20, 4)])
+def test_linear_output_dropout_in_gemm_epilogue(dtype, M, N, K, r):
+    """x = residual + dropout(linear_out(.)) (encoder_layer.py:95 / 104) with the mask applied in the GEMM epilogue
+    (cvft_gemm odrop_p / odrop_site) against the two-launch form (GEMM, then cvft_dropout_add) under the SAME seed and
+    site: identical keep pattern, values and all gradients equal to rounding; every epilogue form (LDS store, 8-byte and
+    16-byte register epilogue) is hit by one of the shapes."""
+    from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
+    from cosyvoice_lora_finetune_framework_amd.modules import hip_linear
+    HF = HFmod()
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(K, N)
+    mod = (LoRALinear(lin, r=r, lora_alpha=2 * r, lora_dropout=0.0) if r else lin).to(DEV)
+    if r:
+        torch.nn.init.normal_(mod.lora_B, std=0.05)
+    mod.train()
+    x = (torch.randn(M, K, device=DEV) * 0.5).to(dtype).requires_grad_(True)
+    res = torch.randn(M, N, device=DEV).to(dtype).requires_grad_(True)
+    g = torch.randn(M, N, device=DEV).to(dtype)
+    params = [q for q in mod.parameters() if q.requires_grad]
+    HF.dropout_begin_step()
+    p = 0.1
+
+    def run(fuse: bool):
+        HF.OUT_DROP_FUSE = fuse
+        HF._DROPOUT["site"] = 7
+        for t in [x, res] + params:
+            t.grad = None
+        y = hip_linear(mod, x, residual=res, out_drop=p)
+        y.backward(g)
+        return [y.detach().float(), x.grad.float().clone(), res.grad.float().clone()] + [q.grad.float().clone() for q in params if q.grad is not None]
+    try:
+        a = run(True)
+        b = run(False)
+    finally:
+        HF.OUT_DROP_FUSE = True
+    plain = hip_linear(mod.eval(), x.detach()).float()
+    kept_a = (a[0] - res.detach().float()).abs() > 1e-3 * plain.abs().clamp_min(1e-2)
+    kept_b = (b[0] - res.detach().float()).abs() > 1e-3 * plain.abs().clamp_min(1e-2)
+    big = plain.abs() > 0.05                       # (tiny outputs can round to the residual in bf16)
+    assert torch.equal(kept_a[big], kept_b[big])
+    rate = float(kept_a[big].float().mean())
+    assert abs(rate - (1 - p)) < 2e-2, rate
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for i, (u, w) in enumerate(zip(a, b)):
+        assert rel(u, w) < tol, (i, rel(u, w))
+    ref = res.detach().float() + torch.where(kept_b, plain / (1 - p), torch.zeros_like(plain))
+    assert rel(a[0], ref) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
 def test_encoder_train_mode_applies_dropout(tiny_meta=None):
     """RelPosEncoder in .train(): output differs from eval, differs between steps, p = 0 reproduces eval exactly."""
     HF = HFmod()
