@@ -500,6 +500,8 @@ class LoraGradSink:
     active = None
     _cache = {}
     _side = None
+    uses_hint = 1          # products expected per adapter and backward (JointLLMFlowModel: sub-batch chains of a branch)
+    scattered = False      # a product got a slab buffer of its own since this was last cleared (train_joint._StepGraph warm-up)
 
     def __init__(self, side_stream: Optional[bool] = None):
         if side_stream is None:
@@ -596,7 +598,8 @@ class LoraGradSink:
             st = self.uses[id(P)] = [0, None]                 # units handed out in this backward, the buffer they come from
         total = st[0] + nsplit
         if st[1] is None:
-            hint = max(getattr(P, "_cvft_ws_units", 0), total)      # what an earlier backward needed in all
+            # what an earlier backward needed in all, or this product's share times the chains about to run (uses_hint)
+            hint = max(getattr(P, "_cvft_ws_units", 0), total * max(1, LoraGradSink.uses_hint))
             buf = getattr(P, "_cvft_part", None)
             if buf is None or buf.numel() < hint * unit:
                 # A captured step holds the ADDRESS of the workspace it was captured with; a later batch layout with more
@@ -616,6 +619,7 @@ class LoraGradSink:
             # contiguous range from the next backward on
             ws = torch.empty(nsplit * unit, dtype=torch.float32, device=P.device)
             P.__dict__.setdefault("_cvft_part_retired", []).append(ws)
+            LoraGradSink.scattered = True
         st[0] = total
         P._cvft_ws_units = max(getattr(P, "_cvft_ws_units", 0), total)
         return ws
@@ -659,6 +663,9 @@ class LoraGradSink:
         key = tuple(self.tasks)
         ent = LoraGradSink._cache.get(key)
         if ent is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("LoraGradSink.flush: reduce task table not built before capture (run the step once more "
+                                   "eagerly: the warm-up's slab layout differed from this one)")
             dev = torch.device("cuda", torch.cuda.current_device())
             # one reduce launch adds every task's slabs into its gradient with a plain read-modify-write: tasks that
             # share a gradient (products whose slabs could not be merged) go into successive launches

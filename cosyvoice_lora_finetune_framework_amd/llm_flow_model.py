@@ -73,6 +73,7 @@ class JointLLMFlowModel(nn.Module):
         do_flow = self.training_mode in ('joint', 'flow_only')
         chains = [('llm', k) for k in range(len(parts['llm']))] * do_llm + [('flow', k) for k in range(len(parts['flow']))] * do_flow
         use_streams = BRANCH_STREAMS and torch.cuda.is_available() and len(chains) > 1
+        HF.LoraGradSink.uses_hint = max(len(v) for v in parts.values())      # chains that will run the same adapters
         cur = torch.cuda.current_stream() if use_streams else None
         results = {}
         for ci, (kind, k) in enumerate(reversed(chains)):          # the last chain (flow part 0 ... ) stays on the caller's stream

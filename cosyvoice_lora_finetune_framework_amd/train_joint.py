@@ -309,7 +309,10 @@ class _StepGraph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            LoraGradSink.scattered = False
             run()                                   # allocator / pack warm-up off the capture
+            if LoraGradSink.scattered:              # an adapter met more slab products than its buffer was sized for: the
+                run()                               # next backward lays them out contiguously -- the layout capture will see
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: the prefetch thread (allocations, host -> device copies on the copy stream) and, under DP, the

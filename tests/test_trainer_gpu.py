@@ -119,6 +119,53 @@ def test_trainer_graph_path_equals_eager_path(tiny_meta):
     assert max(rel(finals[1][k], finals[0][k]) for k in finals[0]) < 1e-5
 
 
+def test_trainer_sub_batch_chains_equal_one_chain(tiny_meta):
+    """The bench's configuration in small: batches of 8 (>= 2 x SPLIT_MIN_PART, so the Flow branch runs as two concurrent
+    half-batch chains on the same adapters), rank-16 adapters (matrix-core / slab LoRA-gradient path with the trainer's
+    LoraGradSink), captured micro-step graph, accumulation.  Per-step losses, gradient norms and the final LoRA tensors
+    equal the eager one-chain trainer's -- the reference's global-batch means (llm_flow_model.py:77-107)."""
+    import copy
+    from cosyvoice_lora_finetune_framework_amd import llm_flow_model as J
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, Trainer
+    meta = copy.deepcopy(tiny_meta)
+    for k in ("flow", "llm"):
+        meta[k]["lora"]["r"], meta[k]["lora"]["alpha"] = 16, 32
+    num = Numerics(dtype=torch.float32)
+    B = 8
+    hist, finals, stats = [], [], []
+    saved = dict(J.SPLIT)
+    try:
+        for use_graph, split in ((False, {'llm': 1, 'flow': 1}), (True, {'llm': 1, 'flow': 2}), (True, {'llm': 2, 'flow': 2})):
+            J.SPLIT.update(split)
+            flow = build_flow_product(meta["flow"], DEV, num)
+            llm = build_llm_product(meta["llm"], DEV, num)
+            jm = J.JointLLMFlowModel(llm, flow, 'joint', llm_loss_weight=2.0, flow_loss_weight=1.0)
+            module = JointLightningModule('joint', learning_rate=1e-3, min_lr=1e-5, warmup_steps=2, weight_decay=0.01, model=jm,
+                                          numerics=num)
+            batches = [synth_batch([24 - (i + j) % 7 for j in range(B)], text_lens=[7 - (i + j) % 3 for j in range(B)],
+                                   token_lens=[12 - (2 * i + j) % 4 for j in range(B)], seed=500 + i, text_vocab=100, speech_vocab=50)
+                       for i in range(4)]
+            tr = Trainer(max_epochs=2, accumulate_grad_batches=2, gradient_clip_val=1.0, train_mode=False, log_every_n_steps=1,
+                         save_checkpoints=False, use_graph=use_graph,
+                         draws_fn=lambda ep, bi, b: cfm_draws(B, b["speech_feat"].shape[1], 1000 * ep + bi))
+            tr.fit(module, batches)
+            hist.append(tr.history)
+            finals.append({k: v.detach().clone() for k, v in jm.named_parameters() if v.requires_grad})
+            stats.append(dict(tr.graph_stats))
+    finally:
+        J.SPLIT.update(saved)
+    assert stats[1]["replays"] == 8 and stats[1]["eager"] == 0 and stats[2]["replays"] == 8, stats
+    for h in hist[1:]:
+        assert len(h) == len(hist[0]) == 4
+        for a, b in zip(hist[0], h):
+            for k in ("loss", "llm_loss", "flow_loss", "lr", "grad_norm"):
+                assert abs(a[k] - b[k]) <= 2e-5 * abs(a[k]) + 1e-9, (k, a, b)
+    for f in finals[1:]:
+        assert max(rel(f[k], finals[0][k]) for k in finals[0]) < 2e-5
+
+
 @pytest.mark.parametrize("use_graph", [0, 1])
 def test_data_parallel_trainer_equals_global_batch(tmp_path, use_graph):
     """SURVEY 8e with the real stack: two fresh processes (gloo, both on this GPU, CVFT_SINGLE_DEVICE=1 set before any GPU
