@@ -781,6 +781,33 @@ __global__ void __launch_bounds__(256) lora_grad_reduce_kernel(const long long* 
     const long long rows = t[2], cols = t[3], pitch = t[4], stride = t[5];
     const int nsplit = (int)t[6];
     const long long numel = rows * cols;
+    // 16-byte form: four consecutive elements of one row per thread, four slabs in flight (fixed summation order)
+    const bool vec = (cols % 4 == 0) && (pitch % 4 == 0) && (stride % 4 == 0) &&
+                     (((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0);
+    if (vec) {
+        for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < numel; i += (long long)gridDim.x * 1024) {
+            const long long src = (pitch == cols) ? i : (i / cols) * pitch + (i % cols);
+            const float* sp = slab + src;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int k = 0;
+            for (; k + 4 <= nsplit; k += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(sp + (size_t)k * stride);
+                const float4 b = *reinterpret_cast<const float4*>(sp + (size_t)(k + 1) * stride);
+                const float4 c = *reinterpret_cast<const float4*>(sp + (size_t)(k + 2) * stride);
+                const float4 d = *reinterpret_cast<const float4*>(sp + (size_t)(k + 3) * stride);
+                s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+                s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+            }
+            for (; k < nsplit; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(sp + (size_t)k * stride);
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+            float4 g = *reinterpret_cast<float4*>(grad + i);
+            g.x += s.x; g.y += s.y; g.z += s.z; g.w += s.w;
+            *reinterpret_cast<float4*>(grad + i) = g;
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long long)gridDim.x * 256) {
         const long long src = (pitch == cols) ? i : (i / cols) * pitch + (i % cols);
         float s = 0.f;
