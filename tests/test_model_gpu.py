@@ -207,6 +207,22 @@ def _full_case(branch, tag):
     return c, ref
 
 
+def _trainer_style_backward(m, fwd, c, ref):
+    """The backward as train_joint.Trainer / bench.py run it: LoRA masters and gradients in FlatAdamW's flat fp32 buffers
+    (bf16 shadows, stacked q|k|v operands), backward inside a LoraGradSink (matrix-core slab products + ONE reduce
+    launch), train()-mode code paths with every dropout probability at 0 so that the reference gradients apply."""
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = FlatAdamW(params, lr=1e-4)
+    opt.zero_grad()
+    out = fwd()
+    with HF.LoraGradSink():
+        out["loss"].backward()
+    assert all(p.grad is not None and p.grad.dtype == torch.float32 for p in params)
+    _check_backward(lora_grads(m), c, ref, float(out["loss"]), "bf16")
+
+
 def _check_backward(grads, c, ref, loss, mode):
     tot = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
     rn = abs(tot - c["grads"]["total_norm"]) / c["grads"]["total_norm"]
@@ -223,7 +239,7 @@ def _check_backward(grads, c, ref, loss, mode):
 
 
 @pytest.mark.parametrize("tag", ["t500_r16", "t1000_r64"])
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16_trainer"])
 def test_full_size_flow_backward_matches_reference(tag, mode):
     """CosyVoice-300M flow, ragged B=2, BASELINE configs[1..3] shape (T=500, r=16) and configs[4] shape (T=1000, r=64):
     loss, total LoRA gradient norm and whole gradient tensors of six adapters (first / middle / last, A and B) against
@@ -238,13 +254,16 @@ def test_full_size_flow_backward_matches_reference(tag, mode):
     m = build_flow_product(meta, DEV, _numerics("vendored", dt))
     batch = synth_batch(c["feat_lens"], text_lens=c["text_lens"], seed=c["batch_seed"])
     draws = cfm_draws(len(c["feat_lens"]), max(c["feat_lens"]), c["draw_seed"])
+    if mode == "bf16_trainer":
+        _trainer_style_backward(m, lambda: m.forward_no_prompt(batch, DEV, draws), c, ref)
+        return
     out = m.forward_no_prompt(batch, DEV, draws)
     out["loss"].backward()
     _check_backward(lora_grads(m), c, ref, float(out["loss"]), mode)
 
 
 @pytest.mark.parametrize("tag", ["t500_r16", "t1000_r64"])
-@pytest.mark.parametrize("mode", ["fp32", "bf16", "fp8"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "fp8", "bf16_trainer"])
 def test_full_size_llm_backward_matches_reference(tag, mode):
     """Same for the LLM branch (L = 333 / 623); "fp8" = BASELINE configs[4] arithmetic (frozen-W GEMMs of the LLM-sized
     linears in OCP e4m3 with per-token / per-channel scales, everything else bf16)."""
@@ -258,6 +277,9 @@ def test_full_size_llm_backward_matches_reference(tag, mode):
     dt = torch.float32 if mode == "fp32" else torch.bfloat16
     m = build_llm_product(meta, DEV, _numerics("vendored", dt), full=True)
     batch = synth_batch(c["feat_lens"], text_lens=c["text_lens"], seed=c["batch_seed"])
+    if mode == "bf16_trainer":
+        _trainer_style_backward(m, lambda: m.forward_no_prompt(batch, DEV), c, ref)
+        return
     HF.FP8_ON = mode == "fp8"
     try:
         out = m.forward_no_prompt(batch, DEV)

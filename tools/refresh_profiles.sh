@@ -1,0 +1,24 @@
+#!/bin/bash
+# Regenerates, on the GPU box, everything profiles/ holds for the current build (run from the repo root):
+#   gpurun_out/final/{bench_n1.json, kernel_stats.csv, counters.json, pmc_traffic*.json, tests.log}
+# Copy the files into profiles/ afterwards (profiles/README.md names them).  rocprofv3 gets the program directly after `--`.
+set -e -o pipefail
+OUT=gpurun_out/final
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
+python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.log 2>&1
+tail -1 $OUT/bench_n1.log > $OUT/bench_n1.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof.log 2>&1
+cp "$(find $OUT/prof -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
+rm -rf $OUT/prof
+python tools/counters.py collect $OUT/counters > $OUT/counters.log 2>&1
+python tools/counters.py summarise $OUT/counters $OUT/counters.json > $OUT/counters.txt
+F=$(find $OUT/counters/fetch -name '*counter_collection.csv' | head -1)
+W=$(find $OUT/counters/write -name '*counter_collection.csv' | head -1)
+python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi64ELi64ELi2ELi2ELi0ELi4ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,64,64,2,2,ns4,regepi>' $OUT/pmc_traffic.json
+python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi128ELi128ELi4ELi2ELi0ELi2ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,128,128,4,2,ns2,regepi>' $OUT/pmc_traffic_128x128.json
+python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi96ELi256ELi3ELi4ELi0ELi3ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,96,256,3,4,ns3,regepi>' $OUT/pmc_traffic_96x256.json
+rm -rf $OUT/counters
+python bench.py --workload flow_only --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_flow_only_b8.json
+python bench.py --ragged 2 --steps 40 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_ragged2.json
+echo refreshed
