@@ -210,7 +210,7 @@ def _full_case(branch, tag):
 def _trainer_style_backward(m, fwd, c, ref):
     """The backward as train_joint.Trainer / bench.py run it: LoRA masters and gradients in FlatAdamW's flat fp32 buffers
     (bf16 shadows, stacked q|k|v operands), backward inside a LoraGradSink (matrix-core slab products + ONE reduce
-    launch), train()-mode code paths with every dropout probability at 0 so that the reference gradients apply."""
+    launch); eval() like the reference fixtures (dropout off)."""
     from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
     from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
     params = [p for p in m.parameters() if p.requires_grad]
