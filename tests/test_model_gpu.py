@@ -290,6 +290,62 @@ def test_full_size_llm_backward_matches_reference(tag, mode):
     _check_backward(lora_grads(m), c, ref, float(out["loss"]), mode)
 
 
+@pytest.mark.parametrize("branch,B", [("flow", 8), ("llm", 16)])
+def test_bench_batch_equals_accumulated_small_batches(branch, B):
+    """The bench's batch sizes on the bench's code path (CosyVoice-300M dims, bf16, FlatAdamW flat buffers, LoraGradSink,
+    sub-batch chains: Flow 2 x 4 utterances, LLM-only 2 x 8) against the SAME utterances run two at a time -- the batch size
+    the reference-pinned full-size tests use -- with gradient accumulation.  Uniform lengths, so every utterance's
+    contribution is independent of its batch mates (GroupNorm statistics are per utterance): loss and accumulated LoRA
+    gradients must agree to bf16 rounding.  Catches anything indexed by batch that B = 2 cannot (block maps over
+    batch x head, row-block plans, slab bookkeeping)."""
+    from cosyvoice_lora_finetune_framework_amd import llm_flow_model as J
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    fs = load_json("full_scalars.json")
+    L = fs[f"{branch}_lora"]
+    meta = dict(lora=dict(r=L["r"], alpha=L["alpha"], targets=L["targets"]), weight_seed=L["weight_seed"])
+    num = _numerics("vendored", torch.bfloat16)
+    if branch == "flow":
+        flow, llm, mode = build_flow_product(meta, DEV, num), torch.nn.Identity(), "flow_only"
+    else:
+        flow = build_flow_product(dict(meta, lora=dict(meta["lora"], targets=["to_q"])), DEV, num)     # (unused by llm_only)
+        flow.requires_grad_(False)
+        llm, mode = build_llm_product(meta, DEV, num, full=True), "llm_only"
+    jm = J.JointLLMFlowModel(llm, flow, mode, 2.0, 1.0).to(DEV).eval()
+    T = 500
+    batch = synth_batch([T] * B, seed=77)
+    draws = cfm_draws(B, T, 9)
+    params = [p for p in jm.parameters() if p.requires_grad]
+    opt = FlatAdamW(params, lr=1e-4)
+
+    def run(groups):
+        opt.zero_grad()
+        total = 0.0
+        for sl in groups:
+            sub = {k: v[sl] for k, v in batch.items()}
+            d = {k: v[sl] for k, v in draws.items()}
+            out = jm(sub, DEV, d if branch == "flow" else None)
+            w = (sl.stop - sl.start) / B
+            with HF.LoraGradSink():
+                (out["loss"] * w).backward()
+            total += float(out["loss"]) * w
+        torch.cuda.synchronize()
+        return total, opt.flat_g.clone()
+    big_loss, big = run([slice(0, B)])
+    small_loss, small = run([slice(i, i + 2) for i in range(0, B, 2)])
+    assert abs(big_loss - small_loss) / abs(small_loss) < 2e-3, (big_loss, small_loss)
+    assert float(small.norm()) > 0
+    assert rel(big, small) < 2e-2, rel(big, small)
+    off, worst = 0, (0.0, None)
+    for n_, p in [(n_, p) for n_, p in jm.named_parameters() if p.requires_grad]:
+        k = p.numel()
+        if float(small[off:off + k].norm()) > 1e-3 * float(small.norm()):
+            worst = max(worst, (rel(big[off:off + k], small[off:off + k]), n_))
+        off += k
+    assert worst[0] < 0.15, worst
+
+
 def test_conformer_convolution_module_matches_reference():
     """ConvolutionModule (pointwise -> GLU -> depthwise k=15 -> LayerNorm -> SiLU -> pointwise) vs the
     vendored cosyvoice/transformer/convolution.py output (ops.npz), both dtypes."""
