@@ -692,7 +692,9 @@ class LoraGradSink:
 import os as _os
 if _os.environ.get('CVFT_FP8', '0') == '1':
     FP8_ON = True
-STACKED_DROP_DEFER = _os.environ.get('CVFT_STACKED_DROP_DEFER', '0') != '0'
+# the stacked q|k|v adapters' four slab products join the sink's end-of-backward batch launches: 26.27 -> 25.91 ms/step with three
+# chains (same-box A/B; it lost 0.7 ms when the step was one chain)
+STACKED_DROP_DEFER = _os.environ.get('CVFT_STACKED_DROP_DEFER', '1') != '0'
 KEEP_DROPPED = _os.environ.get('CVFT_KEEP_DROPPED', '1') != '0'   # forward writes drop(x) for the backward's dA (no re-derivation launch)
 LN_SKINNY = _os.environ.get('CVFT_LN_SKINNY', '1') != '0'    # LayerNorm launch also emits the dropped rank-side product of the adapter it feeds
 XDROP_ON = _os.environ.get('CVFT_XDROP', '1') != '0'        # lora_dropout dgrad: masked rank extension inside the GEMM launch
@@ -1057,7 +1059,6 @@ class LinearQKVStackedFn(torch.autograd.Function):
         direct = all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for pair in grads for g in pair)
         xds = [dropped_input(x, p, st) for st in sites]                 # the three dropped inputs (written by the forward kernel)
         if sink is not None and direct and sink.side is None:
-            # (measured: postponing these four products to the sink's batch launches is slower here -- 31.8 vs 31.1 ms/step)
             defer = STACKED_DROP_DEFER and r == 16 and r3 == 48 and sink.will_defer(x, dY)
             rpa, nsa = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, K)
             rpb_, nsb = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, 3 * N)

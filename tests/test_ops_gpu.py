@@ -884,9 +884,11 @@ def test_lora_dropout_fused_path_matches_torch(act, r):
         assert rel(u, w) < 3e-2, (name, rel(u, w))
 
 
-def test_qkv_stacked_lora_dropout_matches_torch():
+@pytest.mark.parametrize("defer", [False, True])
+def test_qkv_stacked_lora_dropout_matches_torch(defer):
     """Stacked q|k|v under lora_dropout: three mask sites in one cvft_skinny_dropout launch, one side-dgrad launch,
-    dA of the three adapters from three re-derived dropped inputs in one multi-problem slab launch."""
+    dA of the three adapters from three re-derived dropped inputs in one multi-problem slab launch -- in line, or
+    (defer, the default) postponed to the sink's end-of-backward batch launches."""
     from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
     from cosyvoice_lora_finetune_framework_amd.modules import hip_qkv
     from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
@@ -903,11 +905,16 @@ def test_qkv_stacked_lora_dropout_matches_torch():
     g = [torch.randn(M, N, device=DEV).to(torch.bfloat16) for _ in range(3)]
     opt.zero_grad()
     HF.dropout_begin_step()
-    with HF.LoraGradSink():
-        q_, k_, v_ = hip_qkv(mods[0], mods[1], mods[2], x)
-        assert "Stacked" in type(q_.grad_fn).__name__
-        fused = torch.cat(g, 1)
-        torch.autograd.backward([q_, k_, v_], [fused[:, :N], fused[:, N:2 * N], fused[:, 2 * N:]])
+    saved, HF.STACKED_DROP_DEFER = HF.STACKED_DROP_DEFER, defer
+    try:
+        with HF.LoraGradSink() as sink:
+            q_, k_, v_ = hip_qkv(mods[0], mods[1], mods[2], x)
+            assert "Stacked" in type(q_.grad_fn).__name__
+            fused = torch.cat(g, 1)
+            torch.autograd.backward([q_, k_, v_], [fused[:, :N], fused[:, N:2 * N], fused[:, 2 * N:]])
+            assert bool(sink.deferred) == defer
+    finally:
+        HF.STACKED_DROP_DEFER = saved
     seed, last = int(HF._DROPOUT["seed"].item()), HF._DROPOUT["site"]
     xf = x.detach().float().requires_grad_(True)
     outs = []
