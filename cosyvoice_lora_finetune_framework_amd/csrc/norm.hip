@@ -6,6 +6,7 @@
 // subsampling.py:69-113/338-383, matcha transformer.py:255-316; Block1D /
 // ResnetBlock1D GroupNorm(8)+Mish (modules.py:60-94) and InterpolateRegulator's
 // GroupNorm(1)+Mish (length_regulator.py:34-41).
+#include <stdlib.h>
 #include "common.h"
 
 // One wavefront per row.  VP (C % VEC == 0, C <= 64*VEC*NCH, aligned): the row is read ONCE with 16-byte loads
@@ -407,6 +408,158 @@ __global__ void __launch_bounds__(256) gn_apply_bwd_kernel(int B, int T_, int C,
     }
 }
 
+// ------------------------------------------------------------------ GroupNorm, one launch each way
+// The group's (T x Cg) slab of one utterance is small (T = 500, Cg = 32: 32 KB in bf16): ONE block per (b, g) keeps it in
+// registers (up to GN_NCH 16-byte chunks per thread), forms the two-pass statistics and applies them -- x is read once
+// instead of three times and the statistics launch disappears from the estimator's dependent chain (74 launches per
+// Flow chain and step, forward + backward).  Chunk e = tid + 512 k walks the slab frame-major, so a bucket-padded launch
+// (t_eff < T) gives every thread the same valid chunks as the exact-shape launch: bit-identical on the valid frames.
+constexpr int GN_NCH = 8;
+
+template <typename T>
+__global__ void __launch_bounds__(512) gn_fused_fwd_kernel(int T_, int C, int G, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, const int* __restrict__ len, const T* __restrict__ add,
+                                                            int apply_mish, T* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, const int* __restrict__ t_eff) {
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ float sm[16];
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int Cg = C / G, CgV = Cg / VEC;
+    const size_t off = (size_t)b * T_ * C + g * Cg;
+    const int Te = t_eff ? min(*t_eff, T_) : T_;
+    const int nst = Te * CgV, nall = T_ * CgV;
+    const float n = (float)Te * (float)Cg;
+    uint4 xr[GN_NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < GN_NCH; ++k) {
+        const int e = threadIdx.x + k * 512;
+        xr[k] = make_uint4(0, 0, 0, 0);
+        if (e < nall) xr[k] = *reinterpret_cast<const uint4*>(x + off + (size_t)(e / CgV) * C + (e % CgV) * VEC);
+        if (e < nst) {
+            const T* ve = reinterpret_cast<const T*>(&xr[k]);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) s += to_f32(ve[q]);
+        }
+    }
+    const float mu = block_sum(s, sm) / n;
+    float v2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < GN_NCH; ++k) {
+        const int e = threadIdx.x + k * 512;
+        if (e < nst) {
+            const T* ve = reinterpret_cast<const T*>(&xr[k]);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) { const float d = to_f32(ve[q]) - mu; v2 += d * d; }
+        }
+    }
+    const float rs = 1.0f / sqrtf(block_sum(v2, sm) / n + eps);
+    if (threadIdx.x == 0) {
+        mean[blockIdx.x] = mu;
+        rstd[blockIdx.x] = rs;
+    }
+    const int lb = len ? len[b] : T_;
+#pragma unroll
+    for (int k = 0; k < GN_NCH; ++k) {
+        const int e = threadIdx.x + k * 512;
+        if (e >= nall) continue;
+        const int t = e / CgV, cc = (e % CgV) * VEC, c0 = g * Cg + cc;
+        const bool pad = t_eff && t >= Te;
+        const bool dead = t >= lb || pad;
+        const T* ve = reinterpret_cast<const T*>(&xr[k]);
+        T av[VEC], ov[VEC];
+        if (add) *reinterpret_cast<uint4*>(av) = *reinterpret_cast<const uint4*>(add + (size_t)b * C + c0);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const float z = (to_f32(ve[q]) - mu) * rs * gamma[c0 + q] + beta[c0 + q];
+            float o = apply_mish ? act_apply(CVFT_ACT_MISH, z) : z;
+            if (dead) o = 0.f;
+            if (add && !pad) o += to_f32(av[q]);
+            ov[q] = from_f32<T>(o);
+        }
+        *reinterpret_cast<uint4*>(y + off + (size_t)t * C + cc) = *reinterpret_cast<const uint4*>(ov);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512) gn_fused_bwd_kernel(int T_, int C, int G, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const int* __restrict__ len, int apply_mish,
+                                                            const T* __restrict__ dy, T* __restrict__ dx,
+                                                            const int* __restrict__ t_eff) {
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ float sm[16];
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int Cg = C / G, CgV = Cg / VEC;
+    const size_t off = (size_t)b * T_ * C + g * Cg;
+    const int Te = t_eff ? min(*t_eff, T_) : T_;
+    const int nall = T_ * CgV;
+    const float n = (float)Te * (float)Cg;
+    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+    const int lb = len ? min(len[b], Te) : Te;                     // frames t >= len (or in the bucket padding) contribute nothing
+    const int nlive = lb * CgV;
+    uint4 xr[GN_NCH], dr[GN_NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < GN_NCH; ++k) {
+        const int e = threadIdx.x + k * 512;
+        xr[k] = make_uint4(0, 0, 0, 0);
+        dr[k] = make_uint4(0, 0, 0, 0);
+        if (e < nall) {
+            const size_t i = off + (size_t)(e / CgV) * C + (e % CgV) * VEC;
+            xr[k] = *reinterpret_cast<const uint4*>(x + i);
+            dr[k] = *reinterpret_cast<const uint4*>(dy + i);
+        }
+        if (e < nlive) {
+            const int c0 = g * Cg + (e % CgV) * VEC;
+            const T* ve = reinterpret_cast<const T*>(&xr[k]);
+            const T* de = reinterpret_cast<const T*>(&dr[k]);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const float xh = (to_f32(ve[q]) - mu) * rs;
+                float dz = to_f32(de[q]);
+                if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c0 + q] + beta[c0 + q]);
+                dz *= gamma[c0 + q];
+                s1 += dz;
+                s2 += dz * xh;
+            }
+        }
+    }
+    const float w1 = block_sum(s1, sm) / n;
+    const float w2 = block_sum(s2, sm) / n;
+#pragma unroll
+    for (int k = 0; k < GN_NCH; ++k) {
+        const int e = threadIdx.x + k * 512;
+        if (e >= nall) continue;
+        const int t = e / CgV, cc = (e % CgV) * VEC, c0 = g * Cg + cc;
+        const bool pad = t_eff && t >= Te;
+        const bool live = t < lb;
+        const T* ve = reinterpret_cast<const T*>(&xr[k]);
+        const T* de = reinterpret_cast<const T*>(&dr[k]);
+        T ov[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const float xh = (to_f32(ve[q]) - mu) * rs;
+            float dz = 0.f;
+            if (live) {
+                dz = to_f32(de[q]);
+                if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c0 + q] + beta[c0 + q]);
+                dz *= gamma[c0 + q];
+            }
+            ov[q] = from_f32<T>(pad ? 0.f : rs * (dz - w1 - xh * w2));
+        }
+        *reinterpret_cast<uint4*>(dx + off + (size_t)t * C + cc) = *reinterpret_cast<const uint4*>(ov);
+    }
+}
+
+// one block per (b, g) holds the slab: vector path, at most 512 * GN_NCH chunks (CVFT_GN_FUSED=0: the two-launch kernels)
+static bool gn_fused_ok(int T, int Cg, int vec, bool vec_ok) {
+    static const int on = getenv("CVFT_GN_FUSED") ? atoi(getenv("CVFT_GN_FUSED")) : 1;
+    return on && vec_ok && (long)T * (Cg / vec) <= 512L * GN_NCH;
+}
+
 static inline unsigned ew_grid(size_t total) {
     size_t g = (total + 255) / 256;
     return (unsigned)(g > 4096 ? 4096 : (g == 0 ? 1 : g));
@@ -423,6 +576,14 @@ extern "C" int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, co
     const int vec = dtype == CVFT_F32 ? 4 : 8;
     const bool vp = ((C / G) % vec == 0) && (C % vec == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const bool vpa = vp && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (!add || ((reinterpret_cast<uintptr_t>(add) & 15) == 0));
+    if (gn_fused_ok(T, C / G, vec, vpa)) {
+        if (dtype == CVFT_F32) hipLaunchKernelGGL((gn_fused_fwd_kernel<float>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, gamma, beta, eps,
+                                                  len, (const float*)add, apply_mish, (float*)y, mean, rstd, t_eff);
+        else hipLaunchKernelGGL((gn_fused_fwd_kernel<bf16_t>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, gamma, beta, eps,
+                                len, (const bf16_t*)add, apply_mish, (bf16_t*)y, mean, rstd, t_eff);
+        CVFT_LAUNCH_CHECK("cvft_groupnorm_mish_fwd");
+        return 0;
+    }
     if (dtype == CVFT_F32) {
         if (vp) hipLaunchKernelGGL((gn_stats_kernel<float, true>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, eps, mean, rstd, t_eff);
         else hipLaunchKernelGGL((gn_stats_kernel<float, false>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, eps, mean, rstd, t_eff);
@@ -453,6 +614,14 @@ extern "C" int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, co
     const int vec = dtype == CVFT_F32 ? 4 : 8;
     const bool vp = ((C / G) % vec == 0) && (C % vec == 0) &&
                     (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+    if (gn_fused_ok(T, C / G, vec, vp)) {
+        if (dtype == CVFT_F32) hipLaunchKernelGGL((gn_fused_bwd_kernel<float>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, gamma, beta, mean,
+                                                  rstd, len, apply_mish, (const float*)dy, (float*)dx, t_eff);
+        else hipLaunchKernelGGL((gn_fused_bwd_kernel<bf16_t>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, gamma, beta, mean,
+                                rstd, len, apply_mish, (const bf16_t*)dy, (bf16_t*)dx, t_eff);
+        CVFT_LAUNCH_CHECK("cvft_groupnorm_mish_bwd");
+        return 0;
+    }
     const dim3 sgrid(B * G, CVFT_GN_SPLIT);
 #define GN_BWD(TT, VP)                                                                                                         \
     do {                                                                                                                       \
