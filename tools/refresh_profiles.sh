@@ -20,5 +20,5 @@ python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi128ELi128ELi4ELi2ELi0ELi2E
 python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi96ELi256ELi3ELi4ELi0ELi3ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,96,256,3,4,ns3,regepi>' $OUT/pmc_traffic_96x256.json
 rm -rf $OUT/counters
 python bench.py --workload flow_only --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_flow_only_b8.json
-python bench.py --ragged 2 --steps 40 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_ragged2.json
+python bench.py --ragged 2 --steps 120 --warmup 30 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_ragged2.json
 echo refreshed
