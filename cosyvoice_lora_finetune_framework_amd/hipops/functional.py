@@ -831,25 +831,38 @@ def _lora_param_grads(x, U, V, dz, A_ref, B_ref, ops):
 
 
 def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_dx: bool, need_dAB: bool,
-             dx_residual=None, dact_src=None, dact: Optional[str] = None, drop=None):
+             dx_residual=None, dact_src=None, dact: Optional[str] = None, drop=None, odrop=None):
     """Backward of one LoRA linear given dz = gradient at its pre-activation output.
-    dx = (dz W + (scale * dz B) A) [* act'(dact_src)] [+ dx_residual]  -- the last two ride in the dgrad epilogue
-    (fused producer-activation backward, fused gradient accumulation);  dA / dB go to the parameters' flat .grad
-    buffers (through the active LoraGradSink when there is one) or are returned."""
+    dx = (dz W + (scale * dz B) A) [* act'(dact_src)] [* keep(odrop) / (1 - p)] [+ dx_residual]  -- the bracketed links ride in
+    the dgrad epilogue (fused producer-activation backward, the producer's dropout mask, fused gradient accumulation);
+    dA / dB go to the parameters' flat .grad buffers (through the active LoraGradSink when there is one) or are returned."""
     dx = dA = dB = V = None
     has_lora = ops is not None
+
+    def producer_chain(dh):
+        """act'(z) and the producer's dropout mask as passes of their own (launches whose epilogue could not take them)"""
+        if dact_src is None:
+            return dh if odrop is None else dropout_raw(dh, odrop[0], odrop[1])
+        if odrop is None:
+            return act_bwd(dact_src, dh, dact)
+        out = torch.empty_like(dact_src)
+        check(lib().cvft_act_dropout(dt(dact_src), dact_src.numel(), ACT[dact], ptr(dact_src), ptr(_c(dh)), ptr(out), float(odrop[0]),
+                                     ptr(_DROPOUT["seed"]), int(odrop[1]), stream()), "cvft_act_dropout")
+        return out
     if has_lora and drop is not None:
-        # lora_dropout: dx = dz W + mask/(1-p) * (V A); the masked term is added by the side-dgrad kernel, the adapter
-        # gradients see drop(x), re-materialised from the mask site
-        assert dact_src is None, "producer-activation fusion is not combined with lora_dropout"
+        # lora_dropout: dx = dz W + mask/(1-p) * (V A); the masked term is added inside the GEMM launch (xdrop: it joins the
+        # accumulators BEFORE the epilogue, so act'(z) / the producer's mask still ride there) or by the side-dgrad kernel
+        # (then the producer chain runs as a pass of its own); the adapter gradients see drop(x), re-materialised from the site
         Ac, At, Bc, Bt = ops
         V = gemm(dz, Bt, alpha=scale)
         if need_dx:
             if _can_xdrop(dz, pack.Wb, V, At, dx_residual):
-                dx = gemm(dz, pack.Wb, U=V, Bl=At, residual=dx_residual, xdrop=(drop[0], [drop[1]] * (V.shape[1] // 16)))
+                dx = gemm(dz, pack.Wb, U=V, Bl=At, residual=dx_residual, xdrop=(drop[0], [drop[1]] * (V.shape[1] // 16)),
+                          dact_src=dact_src, dact=dact, odrop=odrop)
             else:
+                assert dx_residual is None or (dact_src is None and odrop is None)
                 dx = gemm(dz, pack.Wb, residual=dx_residual)
-                dx = side_dgrad(V, Ac, dx, drop[0], [drop[1]])
+                dx = producer_chain(side_dgrad(V, Ac, dx, drop[0], [drop[1]]))
         if need_dAB:
             dA, dB = _lora_param_grads(dropped_input(x, drop[0], drop[1]), U, V, dz, A_ref, B_ref, ops)
         return dx, dA, dB
@@ -858,11 +871,13 @@ def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_d
         if need_dx and _can_fuse(dz, Bt, At, pack.K, pack.N):
             # dgrad with the side path fused: V = s * dz B is produced by the same launch
             V = torch.empty((dz.shape[0], Bt.shape[0]), dtype=dz.dtype, device=dz.device)
-            dx = gemm(dz, pack.Wb, La=Bt, lora_scale=scale, Uout=V, Bl=At, dact_src=dact_src, dact=dact, residual=dx_residual)
+            dx = gemm(dz, pack.Wb, La=Bt, lora_scale=scale, Uout=V, Bl=At, dact_src=dact_src, dact=dact, residual=dx_residual,
+                      odrop=odrop)
         elif need_dx or need_dAB:
             V = gemm(dz, Bt, alpha=scale)                         # [M, r] = s * dz B
     if need_dx and dx is None:
-        dx = _mm(dz, pack, 'b', pack.Wb, U=V, Bl=None if V is None else ops[1], dact_src=dact_src, dact=dact, residual=dx_residual)
+        dx = _mm(dz, pack, 'b', pack.Wb, U=V, Bl=None if V is None else ops[1], dact_src=dact_src, dact=dact, residual=dx_residual,
+                 odrop=odrop)
     if has_lora and need_dAB:
         dA, dB = _lora_param_grads(x, U, V, dz, A_ref, B_ref, ops)
     return dx, dA, dB
@@ -1096,17 +1111,25 @@ class LinearQKVStackedFn(torch.autograd.Function):
 
 
 class FeedForwardFn(torch.autograd.Function):
-    """y = W2 act(W1 x + b1) + b2 (+ residual), both linears with optional LoRA.  Backward applies act'(z) in the
-    epilogue of W2's dgrad launch (no separate activation-backward pass over the [M, hidden] tensor)."""
+    """y = W2 drop_in(act(W1 x + b1)) + b2, then residual + drop_out(y): both linears with optional LoRA (and lora_dropout), the
+    encoder's inner and residual-branch dropouts (positionwise_feed_forward.py:54, encoder_layer.py:104 / 234) optional.
+    Forward: the activation, the inner mask and the pre-activation save ride in W1's epilogue, the outer mask and the residual
+    in W2's.  Backward applies act'(z) and the inner mask in the epilogue of W2's dgrad launch -- no separate pass over the
+    [M, hidden] tensor either way (at the LLM's 5 328 x 4 096 that was 130 MB of traffic per layer and step)."""
 
     @staticmethod
-    def forward(ctx, x, A1, B1, A2, B2, residual, pack1, pack2, s1: float, s2: float, act: str, p1: float = 0.0, p2: float = 0.0):
+    def forward(ctx, x, A1, B1, A2, B2, residual, pack1, pack2, s1: float, s2: float, act: str, p1: float = 0.0, p2: float = 0.0,
+                p_in: float = 0.0, p_out: float = 0.0):
         x = _c(x)
         need_grad = any(ctx.needs_input_grad[:5])
-        ctx.drops = ([float(p1), _next_drop_site()] if (p1 > 0 and A1 is not None) else None,
-                     [float(p2), _next_drop_site()] if (p2 > 0 and A2 is not None) else None)
-        h, U1, z, ops1 = _lin_fwd(x, A1, B1, pack1, s1, act, None, need_grad, ctx.drops[0])
-        y, U2, _, ops2 = _lin_fwd(h, A2, B2, pack2, s2, None, residual, False, ctx.drops[1])
+        # mask sites in the order the unfused path draws them: W1's adapter, inner, W2's adapter, outer
+        d1 = [float(p1), _next_drop_site()] if (p1 > 0 and A1 is not None) else None
+        od_in = (float(p_in), _next_drop_site()) if p_in > 0 else None
+        d2 = [float(p2), _next_drop_site()] if (p2 > 0 and A2 is not None) else None
+        od_out = (float(p_out), _next_drop_site()) if p_out > 0 else None
+        ctx.drops = (d1, d2, od_in, od_out)
+        h, U1, z, ops1 = _lin_fwd(x, A1, B1, pack1, s1, act, None, need_grad, d1, od_in)
+        y, U2, _, ops2 = _lin_fwd(h, A2, B2, pack2, s2, None, residual, False, d2, od_out)
         ctx.cfg = (pack1, pack2, s1, s2, act, ops1, ops2, (A1, B1), (A2, B2))
         ctx.save_for_backward(x, U1, z, h if A2 is not None else None, U2)      # (h: dA2 = V2^T h, or drop(h) re-derived)
         return y
@@ -1115,21 +1138,20 @@ class FeedForwardFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, U1, z, h, U2 = ctx.saved_tensors
         pack1, pack2, s1, s2, act, ops1, ops2, (A1, B1), (A2, B2) = ctx.cfg
-        dy = _rowc(dy)
+        d1, d2, od_in, od_out = ctx.drops
+        dy = _c(dy) if od_out is not None else _rowc(dy)
+        dres = dy if ctx.needs_input_grad[5] else None
+        if od_out is not None:
+            dy = dropout_raw(dy, od_out[0], od_out[1])
         need1 = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         need2 = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         need_dx = ctx.needs_input_grad[0]
-        d1, d2 = ctx.drops
-        if d2 is None:
-            dz, dA2, dB2 = _lin_bwd(h, U2, ops2, A2, B2, pack2, s2, dy, need_dx or need1, need2, dact_src=z, dact=act)
-        else:       # lora_dropout on W2: its masked side term must join before act'(z) multiplies -> separate activation backward
-            dh, dA2, dB2 = _lin_bwd(h, U2, ops2, A2, B2, pack2, s2, dy, need_dx or need1, need2, drop=d2)
-            dz = act_bwd(z, dh, act) if dh is not None else None
+        dz, dA2, dB2 = _lin_bwd(h, U2, ops2, A2, B2, pack2, s2, dy, need_dx or need1, need2, dact_src=z, dact=act, drop=d2,
+                                odrop=od_in)
         dx = dA1 = dB1 = None
         if dz is not None:
             dx, dA1, dB1 = _lin_bwd(x, U1, ops1, A1, B1, pack1, s1, dz, need_dx, need1, drop=d1)
-        dres = dy if ctx.needs_input_grad[5] else None
-        return dx, dA1, dB1, dA2, dB2, dres, None, None, None, None, None, None, None
+        return dx, dA1, dB1, dA2, dB2, dres, None, None, None, None, None, None, None, None, None
 
 
 class LoraSideFn(torch.autograd.Function):
@@ -1172,6 +1194,8 @@ def lora_linear(x, pack: LinearPack, A=None, B=None, scale: float = 1.0, act: Op
 
 # residual + dropout(linear(.)) with the mask in the GEMM epilogue instead of a cvft_dropout_add pass (CVFT_OUT_DROP_FUSE=0: A/B)
 OUT_DROP_FUSE = _os.environ.get("CVFT_OUT_DROP_FUSE", "1") != "0"
+# train-mode feed-forward as ONE Function (activation + inner mask in W1's epilogue, act' + inner mask in W2's dgrad epilogue)
+FFN_TRAIN_FUSE = _os.environ.get("CVFT_FFN_TRAIN_FUSE", "1") != "0"
 
 _QKV_STACKS = {}
 QKV_STACKING = _os.environ.get("CVFT_QKV_STACK", "1") != "0"
@@ -1222,8 +1246,9 @@ def lora_linear_qkv(x, packs, loras, scales, drop_p: float = 0.0):
 
 
 def lora_feed_forward(x, pack1, pack2, lora1=(None, None), lora2=(None, None), s1: float = 1.0, s2: float = 1.0,
-                      act: str = "relu", residual=None, p1: float = 0.0, p2: float = 0.0):
-    return FeedForwardFn.apply(x, lora1[0], lora1[1], lora2[0], lora2[1], residual, pack1, pack2, s1, s2, act, p1, p2)
+                      act: str = "relu", residual=None, p1: float = 0.0, p2: float = 0.0, p_in: float = 0.0, p_out: float = 0.0):
+    """p1 / p2: lora_dropout of the two adapters; p_in / p_out: the encoder's inner and residual-branch dropouts."""
+    return FeedForwardFn.apply(x, lora1[0], lora1[1], lora2[0], lora2[1], residual, pack1, pack2, s1, s2, act, p1, p2, p_in, p_out)
 
 
 # ---------------------------------------------------------------------------------

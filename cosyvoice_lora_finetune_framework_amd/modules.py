@@ -114,9 +114,15 @@ def hip_qkv(mq: nn.Module, mk: nn.Module, mv: nn.Module, x: torch.Tensor):
     return HF.lora_linear_qkv(x, packs, [(p[3], p[4]) for p in parts], [p[5] for p in parts])
 
 
-def hip_ffn(m1: nn.Module, m2: nn.Module, x: torch.Tensor, act: str, residual: Optional[torch.Tensor] = None):
-    """W2 act(W1 x) (+ residual) with the activation backward fused into W2's dgrad (HF.FeedForwardFn)."""
+def hip_ffn(m1: nn.Module, m2: nn.Module, x: torch.Tensor, act: str, residual: Optional[torch.Tensor] = None,
+            inner_drop: float = 0.0, out_drop: float = 0.0):
+    """residual + drop_out(W2 drop_in(act(W1 x))) with the activation backward (and the inner mask) fused into W2's dgrad
+    (HF.FeedForwardFn); inner_drop / out_drop: the encoder's training dropouts (masks in the GEMM epilogues)."""
     p1, p2 = _lin_parts(m1), _lin_parts(m2)
+    if (inner_drop > 0 or out_drop > 0) and not (HF.FFN_TRAIN_FUSE and HF.OUT_DROP_FUSE and p1[1].shape[0] % 4 == 0 and p2[1].shape[0] % 4 == 0):
+        h = hip_linear(m1, x)
+        h = HF.act_dropout(h, act, inner_drop) if inner_drop > 0 else HF.ActFn.apply(h, act)
+        return hip_linear(m2, h, residual=residual, out_drop=out_drop)
     d1 = p1[6].p if (p1[3] is not None and _lora_dropout_on(m1, p1[6])) else 0.0
     d2 = p2[6].p if (p2[3] is not None and _lora_dropout_on(m2, p2[6])) else 0.0
     if d1 > 0 or d2 > 0:
@@ -124,10 +130,16 @@ def hip_ffn(m1: nn.Module, m2: nn.Module, x: torch.Tensor, act: str, residual: O
             (d1 == 0 or (type(p1[6]) is nn.Dropout and p1[3].shape[0] == 16 and p1[1].shape[1] % 32 == 0)) and \
             (d2 == 0 or (type(p2[6]) is nn.Dropout and p2[3].shape[0] == 16 and p2[1].shape[1] % 32 == 0))
         if not ok:
-            return hip_linear(m2, hip_linear(m1, x, act=act), residual=residual)
+            h = hip_linear(m1, x, act=None if inner_drop > 0 else act)
+            if inner_drop > 0:
+                h = HF.act_dropout(h, act, inner_drop)
+            return hip_linear(m2, h, residual=residual, out_drop=out_drop)
     k1 = _cached(p1[0], "lin", p1[0].weight, x.dtype, lambda: HF.LinearPack(p1[1], p1[2], x.dtype))
     k2 = _cached(p2[0], "lin", p2[0].weight, x.dtype, lambda: HF.LinearPack(p2[1], p2[2], x.dtype))
-    return HF.lora_feed_forward(x, k1, k2, (p1[3], p1[4]), (p2[3], p2[4]), p1[5], p2[5], act, residual, p1=d1, p2=d2)
+    y = HF.lora_feed_forward(x, k1, k2, (p1[3], p1[4]), (p2[3], p2[4]), p1[5], p2[5], act, residual, p1=d1, p2=d2,
+                             p_in=inner_drop, p_out=out_drop)
+    HF.drop_pre_u(x)                                         # (a hand-off from the LayerNorm launch nobody took is dropped here)
+    return y
 
 
 def _lora_dropout_path(x, pack, A, Bm, scale, drop, act, residual):
@@ -538,14 +550,9 @@ class PositionwiseFeedForward(nn.Module):
         self.w_2 = nn.Linear(hidden_units, idim)
 
     def forward(self, y, residual, out_dropout: float = 0.0):
-        if self.training and (self.dropout_rate > 0 or out_dropout > 0):
-            # w_2(dropout(act(w_1 x)))  (positionwise_feed_forward.py:54), then residual + dropout(.) (encoder_layer.py:104 / 234)
-            if self.dropout_rate > 0:         # activation and inner dropout in one pass (and one pass backward)
-                h = HF.act_dropout(hip_linear(self.w_1, y), self.activation, self.dropout_rate)
-            else:
-                h = hip_linear(self.w_1, y, act=self.activation)
-            return hip_linear(self.w_2, h, residual=residual, out_drop=out_dropout)
-        return hip_ffn(self.w_1, self.w_2, y, self.activation, residual=residual)
+        # w_2(dropout(act(w_1 x)))  (positionwise_feed_forward.py:54), then residual + dropout(.) (encoder_layer.py:104 / 234)
+        return hip_ffn(self.w_1, self.w_2, y, self.activation, residual=residual,
+                       inner_drop=self.dropout_rate if self.training else 0.0, out_drop=out_dropout if self.training else 0.0)
 
 
 class EncoderLayer(nn.Module):

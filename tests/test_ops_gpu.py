@@ -706,6 +706,58 @@ def test_linear_output_dropout_in_gemm_epilogue(dtype, M, N, K, r):
     assert rel(a[0], ref) < (1e-4 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("act", ["relu", "silu"])
+@pytest.mark.parametrize("lora,lora_p", [(True, 0.15), (True, 0.0), (False, 0.0)])
+def test_feed_forward_train_mode_fused_matches_unfused(act, lora, lora_p):
+    """PositionwiseFeedForward in train mode (positionwise_feed_forward.py:54, encoder_layer.py:104): the one-Function
+    form (activation + inner mask in W1's epilogue, outer mask + residual in W2's, act' + inner mask in the epilogue of W2's
+    dgrad -- with the masked rank extension of W2's lora_dropout in the same launch) against the launch-per-stage form
+    (linear, cvft_act_dropout, linear + epilogue mask) under the SAME seed and mask sites: outputs and every gradient agree
+    to bf16 rounding."""
+    from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
+    from cosyvoice_lora_finetune_framework_amd.modules import PositionwiseFeedForward
+    from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
+    HF = HFmod()
+    torch.manual_seed(21)
+    d, hid, M = 256, 1024, 1500
+    ff = PositionwiseFeedForward(d, hid, 0.1, act)
+    if lora:
+        ff.w_1 = LoRALinear(ff.w_1, r=16, lora_alpha=32, lora_dropout=lora_p)
+        ff.w_2 = LoRALinear(ff.w_2, r=16, lora_alpha=32, lora_dropout=lora_p)
+        torch.nn.init.normal_(ff.w_1.lora_B, std=0.05)
+        torch.nn.init.normal_(ff.w_2.lora_B, std=0.05)
+    ff = ff.to(DEV).train()
+    params = [q for q in ff.parameters() if q.requires_grad] if lora else []
+    opt = FlatAdamW(params, lr=1e-3) if lora else None
+    x = (torch.randn(M, d, device=DEV) * 0.7).to(torch.bfloat16).requires_grad_(True)
+    res = torch.randn(M, d, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    g = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    HF.dropout_begin_step()
+
+    def run(fused: bool):
+        HF.FFN_TRAIN_FUSE = fused
+        HF._DROPOUT["site"] = 40
+        x.grad = res.grad = None
+        if opt is not None:
+            opt.zero_grad()
+        with HF.LoraGradSink():
+            y = ff(x, res, out_dropout=0.1)
+            assert ("FeedForward" in type(y.grad_fn).__name__) == fused
+            y.backward(g)
+        torch.cuda.synchronize()
+        return [y.detach().float(), x.grad.float().clone(), res.grad.float().clone()] + [q.grad.float().clone() for q in params]
+    try:
+        a = run(True)
+        b = run(False)
+    finally:
+        HF.FFN_TRAIN_FUSE = True
+    for i, (u, w) in enumerate(zip(a, b)):
+        assert rel(u, w) < 2e-2, (i, rel(u, w))
+    # and the masks really are on: eval mode differs
+    ff.eval()
+    assert rel(ff(x.detach(), res.detach()), a[0]) > 5e-2
+
+
 def test_encoder_train_mode_applies_dropout(tiny_meta=None):
     """RelPosEncoder in .train(): output differs from eval, differs between steps, p = 0 reproduces eval exactly."""
     HF = HFmod()
