@@ -24,6 +24,10 @@ def main():
     from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
     from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, Trainer
     meta = load_json("tiny_meta.json")
+    big = os.environ.get("CVFT_DPTEST_BIG") == "1"       # the driver's N > 1 configuration in small: rank-16 adapters (slab
+    if big:                                               # products + LoraGradSink), shards of 8 (two Flow chains per rank)
+        for k in ("flow", "llm"):
+            meta[k]["lora"]["r"], meta[k]["lora"]["alpha"] = 16, 32
     num = Numerics(dtype=torch.float32)
     jm = JointLLMFlowModel(build_llm_product(meta["llm"], "cuda", num), build_flow_product(meta["flow"], "cuda", num), 'joint',
                            llm_loss_weight=2.0, flow_loss_weight=1.0)
@@ -34,6 +38,8 @@ def main():
     # a shard padded to other maxima would not reproduce the global-batch run
     G = [([24, 24, 17, 20], [7, 7, 5, 6], [13, 13, 9, 11]), ([22, 22, 15, 19], [6, 6, 4, 5], [12, 12, 8, 10]),
          ([24, 24, 21, 13], [7, 7, 3, 6], [13, 13, 11, 7]), ([20, 20, 18, 11], [5, 5, 5, 2], [11, 11, 10, 6])]
+    if big:          # 16 utterances per global batch: every pattern of G four times, the two maxima first (ranks 0 and 1 get one each)
+        G = [(fl[:2] + (fl[2:] * 7), tl[:2] + (tl[2:] * 7), kl[:2] + (kl[2:] * 7)) for fl, tl, kl in G]
     batches, draws = [], []
     for i, (fl, tl, kl) in enumerate(G):
         full = synth_batch(fl, text_lens=tl, token_lens=kl, seed=500 + i, text_vocab=100, speech_vocab=50)

@@ -166,13 +166,15 @@ def test_trainer_sub_batch_chains_equal_one_chain(tiny_meta):
         assert max(rel(f[k], finals[0][k]) for k in finals[0]) < 2e-5
 
 
-@pytest.mark.parametrize("use_graph", [0, 1])
-def test_data_parallel_trainer_equals_global_batch(tmp_path, use_graph):
+@pytest.mark.parametrize("use_graph,big", [(0, 0), (1, 0), (1, 1)])
+def test_data_parallel_trainer_equals_global_batch(tmp_path, use_graph, big):
     """SURVEY 8e with the real stack: two fresh processes (gloo, both on this GPU, CVFT_SINGLE_DEVICE=1 set before any GPU
     call) run JointLLMFlowModel + FlatAdamW + Trainer.fit with accumulation on their shards of ragged global batches.
     The all-reduced gradient norm of every optimiser step and the LoRA tensors after 4 steps equal the single-process
     global-batch run (reference semantics: global-batch means, cosyvoice/flow/flow_matching.py:192,
-    label_smoothing_loss.py:91-96; no_sync on accumulation micro-steps, cosyvoice/utils/executor.py:64-65)."""
+    label_smoothing_loss.py:91-96; no_sync on accumulation micro-steps, cosyvoice/utils/executor.py:64-65).
+    big = the driver's N > 1 configuration in small: rank-16 adapters (matrix-core slab products through the LoraGradSink),
+    16 utterances per global batch, so every rank's shard of 8 runs its Flow branch as two concurrent chains."""
     import os
     import socket
     import subprocess
@@ -184,7 +186,8 @@ def test_data_parallel_trainer_equals_global_batch(tmp_path, use_graph):
 
     def launch(rank, world, out):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), CVFT_DIST_BACKEND="gloo", CVFT_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), CVFT_DIST_BACKEND="gloo", CVFT_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   CVFT_DPTEST_BIG=str(big))
         return subprocess.Popen([sys.executable, os.path.join(here, "dp_worker.py"), str(out), str(use_graph)], env=env,
                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
 
