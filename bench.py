@@ -247,13 +247,13 @@ def main():
         from cosyvoice_lora_finetune_framework_amd import train_joint as _tj
         if _tj._TIMING:
             torch.cuda.synchronize()
-            T = _tj._TIMING[-10:]
-            cp = sum(e[0].elapsed_time(e[1]) for e in T) / len(T)
-            gr = sum(e[1].elapsed_time(e[2]) for e in T) / len(T)
-            gap = sum(T[i][2].elapsed_time(T[i + 1][0]) for i in range(len(T) - 1)) / (len(T) - 1)
-            hc = sum(e[3][1] - e[3][0] for e in T) / len(T) * 1e3
-            hr = sum(e[3][2] - e[3][1] for e in T) / len(T) * 1e3
-            hg = sum(T[i + 1][3][0] - T[i][3][2] for i in range(len(T) - 1)) / (len(T) - 1) * 1e3
+            TL = _tj._TIMING[-10:]
+            cp = sum(e[0].elapsed_time(e[1]) for e in TL) / len(TL)
+            gr = sum(e[1].elapsed_time(e[2]) for e in TL) / len(TL)
+            gap = sum(TL[i][2].elapsed_time(TL[i + 1][0]) for i in range(len(TL) - 1)) / (len(TL) - 1)
+            hc = sum(e[3][1] - e[3][0] for e in TL) / len(TL) * 1e3
+            hr = sum(e[3][2] - e[3][1] for e in TL) / len(TL) * 1e3
+            hg = sum(TL[i + 1][3][0] - TL[i][3][2] for i in range(len(TL) - 1)) / (len(TL) - 1) * 1e3
             log(f"[bench] trainer host timeline: copies {hc:.2f} ms, replay call {hr:.2f} ms, replay return -> next step's copies {hg:.2f} ms")
             log(f"[bench] trainer GPU timeline: static copies {cp:.3f} ms, graph {gr:.3f} ms, graph end -> next step's copies {gap:.3f} ms")
         el = torch.tensor([marks["t1"] - marks["t0"]], device=dev)
@@ -323,7 +323,7 @@ def main():
             hs.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
         log(f"[bench] idle-GPU replay: host call {min(hs):.2f} ms, to completion {min(tot):.2f} ms")
     roof = None
-    if not a.no_roofline:
+    if rank == 0 and not a.no_roofline:              # (the instrumented step has no collective in it: rank 0 alone runs it)
         # event-instrumented eager step: every tap-GEMM launch bracketed by HIP events on the launch stream
         # An event pair costs time of its own (two timestamp packets on the queue): the empty bracket is measured here and
         # taken off every record, else the 8-us launches of this step read 50 % long against the rocprofv3 kernel trace.
@@ -397,7 +397,14 @@ def main():
             if mf:                                                                   # and the largest matrix-core-bound one
                 roof["largest_mfma_bound"] = line(*max(mf, key=lambda kv: kv[1]["ms"]))
             roof["all_gemm_kernels"] = {k: {"ms": v["ms"], "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12,
-                                            "gbps": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "n": v["n"]} for k, v in groups.items()}
+                                            "gbps": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "n": v["n"]}
+                                        for k, v in groups.items() if not k.startswith("attn_")}
+            # the fused attention launches of the same instrumented step (FLOPs of the visible query-key pairs only;
+            # a rel-pos backward bracket holds its two launches, dQ and dK/dV)
+            roof["attention_kernels"] = {k: {"ms": v["ms"], "tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12,
+                                             "frac_of_mfma_peak": v["flop"] / (v["ms"] * 1e-3) / 1e12 / mfma_peak,
+                                             "avg_us": v["ms"] * 1e3 / v["n"], "n": v["n"]}
+                                         for k, v in groups.items() if k.startswith("attn_")}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -424,6 +431,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
+        dp.barrier()                                  # the other ranks wait for rank 0's roofline leg, then all leave together
         torch.distributed.destroy_process_group()
 
 

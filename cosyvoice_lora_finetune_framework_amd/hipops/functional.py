@@ -22,6 +22,27 @@ from .binding import ACT, GemmArgs, check, dt, lib, ptr, stream
 PROFILE = None   # bench.py sets this to a list: every tap-GEMM launch is then bracketed by HIP events
 
 
+class _Bracket:
+    """bench.py's roofline leg (PROFILE is a list): HIP events around one attention launch on its launch stream, with the
+    launch's algorithmic work -- FLOPs of the visible (query, key) pairs only, operands and results once."""
+
+    def __init__(self, kernel: str, flop: float, nbytes: float):
+        self.rec = {"kernel": kernel, "flop": flop, "bytes": nbytes} if PROFILE is not None else None
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec["start"] = torch.cuda.Event(enable_timing=True)
+            self.rec["start"].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None and exc[0] is None:
+            self.rec["end"] = torch.cuda.Event(enable_timing=True)
+            self.rec["end"].record()
+            PROFILE.append(self.rec)
+        return False
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -1459,8 +1480,9 @@ class AttnBiasFn(torch.autograd.Function):
         assert q.stride(0) == k.stride(0) == v.stride(0)
         o = torch.empty((B * T, H * 64), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
-        check(lib().cvft_attn_bias_fwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, int(iso_len), ptr(o),
-                                       o.stride(0), ptr(lse), stream()), "cvft_attn_bias_fwd")
+        with _Bracket("attn_bias_fwd", 4.0 * B * H * T * T * 64, 4.0 * B * T * H * 64 * q.element_size()):     # QK^T, PV
+            check(lib().cvft_attn_bias_fwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, int(iso_len), ptr(o),
+                                           o.stride(0), ptr(lse), stream()), "cvft_attn_bias_fwd")
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.args = (B, H, T, klen, scale, int(iso_len))
         return o
@@ -1473,9 +1495,10 @@ class AttnBiasFn(torch.autograd.Function):
         dqkv = torch.empty((B * T, 3 * H * 64), dtype=q.dtype, device=q.device)
         dq, dk, dv = dqkv[:, :H * 64], dqkv[:, H * 64:2 * H * 64], dqkv[:, 2 * H * 64:]
         delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
-        check(lib().cvft_attn_bias_bwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, iso_len, ptr(o),
-                                       ptr(do), o.stride(0), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-                                       dqkv.stride(0), stream()), "cvft_attn_bias_bwd")
+        with _Bracket("attn_bias_bwd", 10.0 * B * H * T * T * 64, 8.0 * B * T * H * 64 * q.element_size()):    # S, dP, dV, dK, dQ
+            check(lib().cvft_attn_bias_bwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, iso_len, ptr(o),
+                                           ptr(do), o.stride(0), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                           dqkv.stride(0), stream()), "cvft_attn_bias_bwd")
         return dq, dk, dv, None, None, None, None, None, None
 
 
@@ -1493,9 +1516,11 @@ class AttnRelPosFn(torch.autograd.Function):
         seed = _DROPOUT["seed"] if drop_p > 0 else None
         o = torch.empty((B * L, H * 64), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
-        check(lib().cvft_attn_relpos_fwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
-                                         ptr(bias_u), ptr(bias_v), ptr(length), int(causal), scale, ptr(o), o.stride(0),
-                                         ptr(lse), float(drop_p), ptr(seed), drop_site, stream()), "cvft_attn_relpos_fwd")
+        vis = 0.5 if causal else 1.0                      # share of the (query, key) square a causal launch has to compute
+        with _Bracket("attn_relpos_fwd", 6.0 * vis * B * H * L * L * 64, 4.0 * B * L * H * 64 * q.element_size()):   # QK^T, band, PV
+            check(lib().cvft_attn_relpos_fwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
+                                             ptr(bias_u), ptr(bias_v), ptr(length), int(causal), scale, ptr(o), o.stride(0),
+                                             ptr(lse), float(drop_p), ptr(seed), drop_site, stream()), "cvft_attn_relpos_fwd")
         ctx.save_for_backward(q, k, v, p, bias_u, bias_v, o, lse)
         ctx.args = (B, H, L, length, causal, scale)
         ctx.drop = (float(drop_p), seed, drop_site)
@@ -1512,11 +1537,13 @@ class AttnRelPosFn(torch.autograd.Function):
         dqkv = torch.empty((B * L, 3 * H * 64), dtype=q.dtype, device=q.device)
         dq, dk, dv = dqkv[:, :H * 64], dqkv[:, H * 64:2 * H * 64], dqkv[:, 2 * H * 64:]
         delta = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
-        check(lib().cvft_attn_relpos_bwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
-                                         ptr(bu), ptr(bv), ptr(length), int(causal), scale, ptr(o), ptr(do), o.stride(0),
-                                         ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), ptr(dpos),
-                                         ctx.drop[0], ptr(ctx.drop[1]), ctx.drop[2], stream()),
-              "cvft_attn_relpos_bwd")
+        vis = 0.5 if causal else 1.0
+        with _Bracket("attn_relpos_bwd", 14.0 * vis * B * H * L * L * 64, 8.0 * B * L * H * 64 * q.element_size()):  # S, band, dP, dV, dK, dQ (k and p terms)
+            check(lib().cvft_attn_relpos_bwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
+                                             ptr(bu), ptr(bv), ptr(length), int(causal), scale, ptr(o), ptr(do), o.stride(0),
+                                             ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), ptr(dpos),
+                                             ctx.drop[0], ptr(ctx.drop[1]), ctx.drop[2], stream()),
+                  "cvft_attn_relpos_bwd")
         dp_out = None if dpos is None else dpos.to(p.dtype)
         return dq, dk, dv, dp_out, None, None, None, None, None, None, None, None, None, None
 

@@ -263,8 +263,12 @@ class _Prefetcher:
         self.q = queue.Queue(maxsize=depth)
         self._end = object()
 
+        dev_index = torch.cuda.current_device() if torch.cuda.is_available() else None
+
         def work():
             try:
+                if dev_index is not None:       # a new thread starts on device 0: bind it to this rank's GPU (one process per GPU)
+                    torch.cuda.set_device(dev_index)
                 for item in iterable:
                     self.q.put(fn(item))
                 self.q.put(self._end)
