@@ -181,14 +181,14 @@ template <typename T>
 __global__ void cfm_prepare_kernel(int B, int T_, const float* __restrict__ feat, const float* __restrict__ z,
                                    const float* __restrict__ t_raw, const float* __restrict__ keep,
                                    const T* __restrict__ mu, const T* __restrict__ spk, const T* __restrict__ cond,
-                                   float mel_mean, float mel_std, float sigma_min, T* __restrict__ xin,
+                                   float mel_mean, float mel_std, float sigma_min, int cosine, T* __restrict__ xin,
                                    float* __restrict__ u, float* __restrict__ tout) {
     const size_t total = (size_t)B * T_ * 80;
     EW_LOOP(i, total) {
         int c = (int)(i % 80);
         size_t bt = i / 80;
         int b = (int)(bt / T_);
-        const float t = 1.f - cosf(t_raw[b] * 0.5f * 3.14159265358979323846f);
+        const float t = cosine ? 1.f - cosf(t_raw[b] * 0.5f * 3.14159265358979323846f) : t_raw[b];     // t_scheduler (flow_matching.py:176)
         const float x1 = (feat[i] - mel_mean) / mel_std;
         const float zz = z[i];
         const float y = (1.f - (1.f - sigma_min) * t) * zz + t * x1;
@@ -204,16 +204,16 @@ __global__ void cfm_prepare_kernel(int B, int T_, const float* __restrict__ feat
 }
 extern "C" int cvft_cfm_prepare(int dtype, int B, int T, const float* feat, const float* z, const float* t_raw,
                                 const float* cfg_keep, const void* mu, const void* spk, const void* cond, float mel_mean,
-                                float mel_std, float sigma_min, void* xin, float* u, float* t, void* stream) {
+                                float mel_std, float sigma_min, int t_cosine, void* xin, float* u, float* t, void* stream) {
     CHECK_DTYPE("cvft_cfm_prepare", dtype);
     CVFT_CHECK_ARG(B > 0 && T > 0 && feat && z && t_raw && cfg_keep && mu && spk && xin && u && t, "cvft_cfm_prepare: bad args");
     size_t total = (size_t)B * T * 80;
     if (dtype == CVFT_F32)
         hipLaunchKernelGGL((cfm_prepare_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, feat, z,
-                           t_raw, cfg_keep, (const float*)mu, (const float*)spk, (const float*)cond, mel_mean, mel_std, sigma_min, (float*)xin, u, t);
+                           t_raw, cfg_keep, (const float*)mu, (const float*)spk, (const float*)cond, mel_mean, mel_std, sigma_min, t_cosine, (float*)xin, u, t);
     else
         hipLaunchKernelGGL((cfm_prepare_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, B, T, feat, z,
-                           t_raw, cfg_keep, (const bf16_t*)mu, (const bf16_t*)spk, (const bf16_t*)cond, mel_mean, mel_std, sigma_min, (bf16_t*)xin, u, t);
+                           t_raw, cfg_keep, (const bf16_t*)mu, (const bf16_t*)spk, (const bf16_t*)cond, mel_mean, mel_std, sigma_min, t_cosine, (bf16_t*)xin, u, t);
     CVFT_LAUNCH_CHECK("cvft_cfm_prepare");
     return 0;
 }

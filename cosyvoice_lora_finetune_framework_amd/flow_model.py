@@ -26,8 +26,6 @@ class ConditionalCFM(nn.Module):
                  t_scheduler: str = 'cosine', training_cfg_rate: float = 0.2, inference_cfg_rate: float = 0.7,
                  estimator: Optional[nn.Module] = None):
         super().__init__()
-        if t_scheduler != 'cosine':
-            raise NotImplementedError("only the cosine t-scheduler of CosyVoice-300M is built")
         self.in_channels, self.n_spks, self.spk_emb_dim = in_channels, n_spks, spk_emb_dim
         self.sigma_min, self.t_scheduler = sigma_min, t_scheduler
         self.training_cfg_rate, self.inference_cfg_rate = training_cfg_rate, inference_cfg_rate
@@ -54,7 +52,7 @@ class ConditionalCFM(nn.Module):
         keep = (draws["cfg_rand"].to(dev) > self.training_cfg_rate).to(torch.float32) if self.training_cfg_rate > 0 \
             else torch.ones(B, device=dev)
         xin, u, t = HF.cfm_prepare(mu, spk, feat.to(dev, torch.float32).contiguous(), z.contiguous(), t_raw, keep, B, T,
-                                   mel_mean, mel_std, self.sigma_min, cond)
+                                   mel_mean, mel_std, self.sigma_min, cond, self.t_scheduler == 'cosine')
         if prompt_lens is not None and len(prompt_lens) > 0:
             self.estimator.prompt_isolation_len = int(max(prompt_lens))
             self.estimator.prompt_isolation_enabled = True
@@ -97,7 +95,8 @@ class ConditionalCFM(nn.Module):
         mu_cache = torch.concat([mu[:, :, :prompt_len], mu[:, :, -34:]], dim=2) if prompt_len > 0 else mu[:, :, -34:]
         new_cache = torch.stack([z_cache, mu_cache], dim=-1)
         t_span = torch.linspace(0, 1, n_timesteps + 1, device=mu.device, dtype=mu.dtype)
-        t_span = 1 - torch.cos(t_span * 0.5 * 3.14159265359)
+        if self.t_scheduler == 'cosine':                 # (flow_matching.py:67; any other value: the linear span)
+            t_span = 1 - torch.cos(t_span * 0.5 * 3.14159265359)
         return self.solve_euler(z, t_span, mu, mask, spks, cond, num), new_cache
 
     @torch.no_grad()

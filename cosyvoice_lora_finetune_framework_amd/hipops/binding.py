@@ -97,13 +97,13 @@ SIGNATURES = {
     "cvft_skinny_dropout": [_i, _i, _i, _p, _i, _p, _i, _f, _p, _i, _f, _p, _p, _p, _p],
     "cvft_ln_skinny_dropout": [_i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _i, _f, _p, _i, _f, _p, _p, _p, _p],
     "cvft_lora_side_dgrad": [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _f, _p, _p, _p],
-    "cvft_cfm_prepare": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p],
+    "cvft_cfm_prepare": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _i, _p, _p, _p, _p],
     "cvft_masked_mse_fwd": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "cvft_masked_mse_bwd": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "cvft_interp_linear_fwd": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
     "cvft_interp_linear_bwd": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
-    "cvft_ce_fwd": [_i, _i, _i, _p, _i, _p, _p, _p, _p],
-    "cvft_ce_bwd": [_i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p],
+    "cvft_ce_fwd": [_i, _i, _i, _p, _i, _p, _p, _p, _f, _p],
+    "cvft_ce_bwd": [_i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p],
     "cvft_dwconv1d_fwd": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "cvft_dwconv1d_bwd": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     "cvft_sumsq": [_i64, _p, _p, _p],

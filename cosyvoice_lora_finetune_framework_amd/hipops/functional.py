@@ -1646,13 +1646,13 @@ class CfmPrepareFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mu, spk, feat, z, t_raw, keep, B: int, T: int, mel_mean: float, mel_std: float, sigma_min: float,
-                cond=None):
+                cond=None, cosine: bool = True):
         mu = _c(mu)
         xin = torch.empty((B * T, 320), dtype=mu.dtype, device=mu.device)
         u = torch.empty((B * T, 80), dtype=torch.float32, device=mu.device)
         t = torch.empty(B, dtype=torch.float32, device=mu.device)
         check(lib().cvft_cfm_prepare(dt(mu), B, T, ptr(_c(feat)), ptr(_c(z)), ptr(_c(t_raw)), ptr(_c(keep)), ptr(mu),
-                                     ptr(_c(spk)), ptr(None if cond is None else _c(cond)), mel_mean, mel_std, sigma_min, ptr(xin), ptr(u), ptr(t), stream()),
+                                     ptr(_c(spk)), ptr(None if cond is None else _c(cond)), mel_mean, mel_std, sigma_min, int(cosine), ptr(xin), ptr(u), ptr(t), stream()),
               "cvft_cfm_prepare")
         ctx.save_for_backward(keep)
         ctx.dims = (B, T)
@@ -1664,12 +1664,13 @@ class CfmPrepareFn(torch.autograd.Function):
         (keep,) = ctx.saved_tensors
         B, T = ctx.dims
         dmu = (dxin[:, 80:160].reshape(B, T, 80) * keep.view(B, 1, 1).to(dxin.dtype)).reshape(B * T, 80)
-        return dmu, None, None, None, None, None, None, None, None, None, None, None
+        return dmu, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def cfm_prepare(mu, spk, feat, z, t_raw, keep, B: int, T: int, mel_mean: float, mel_std: float, sigma_min: float,
-                cond=None):
-    return CfmPrepareFn.apply(mu, spk, feat, z, t_raw, keep, B, T, mel_mean, mel_std, sigma_min, cond)
+                cond=None, cosine: bool = True):
+    """cosine: the reference's t_scheduler == 'cosine' (flow_matching.py:176); False leaves t as drawn."""
+    return CfmPrepareFn.apply(mu, spk, feat, z, t_raw, keep, B, T, mel_mean, mel_std, sigma_min, cond, cosine)
 
 
 class MaskedMseFn(torch.autograd.Function):
@@ -1704,16 +1705,17 @@ def masked_mse(pred, u, length, denom, B: int, T: int, weight=None):
 
 
 class CrossEntropyFn(torch.autograd.Function):
-    """Token-mean CE with ignore index -1 (label_smoothing_loss.py:68-96, smoothing 0) + accuracy."""
+    """Token-mean label-smoothed CE with ignore index -1 (label_smoothing_loss.py:68-96) + accuracy."""
 
     @staticmethod
-    def forward(ctx, logits, target):
+    def forward(ctx, logits, target, smoothing: float = 0.0):
         logits = _rowc(logits)
+        ctx.smoothing = float(smoothing)
         n, V = logits.shape
         out3 = torch.zeros(3, dtype=torch.float32, device=logits.device)
         row_lse = torch.empty(n, dtype=torch.float32, device=logits.device)
         check(lib().cvft_ce_fwd(dt(logits), n, V, ptr(logits), logits.stride(0), ptr(target), ptr(out3), ptr(row_lse),
-                                stream()), "cvft_ce_fwd")
+                                ctx.smoothing, stream()), "cvft_ce_fwd")
         ctx.save_for_backward(logits, target, row_lse, out3)
         loss = out3[0] / out3[1]
         acc = out3[2] / out3[1]
@@ -1732,13 +1734,13 @@ class CrossEntropyFn(torch.autograd.Function):
             base[:, V:].zero_()
             _register_zero_padded(base)
         check(lib().cvft_ce_bwd(dt(logits), n, V, ptr(logits), logits.stride(0), ptr(target), ptr(row_lse), ptr(gs),
-                                ptr(dl), dl.stride(0), stream()), "cvft_ce_bwd")
-        return dl, None
+                                ptr(dl), dl.stride(0), ctx.smoothing, stream()), "cvft_ce_bwd")
+        return dl, None, None
 
 
-def cross_entropy(logits, target):
-    """logits [n, V]; target [n] int32 (-1 = ignore) -> (loss, accuracy)."""
-    return CrossEntropyFn.apply(logits, target)
+def cross_entropy(logits, target, smoothing: float = 0.0):
+    """logits [n, V]; target [n] int32 (-1 = ignore) -> (loss, accuracy).  smoothing = LabelSmoothingLoss's lsm_weight."""
+    return CrossEntropyFn.apply(logits, target, smoothing)
 
 
 # ---------------------------------------------------------------------------------

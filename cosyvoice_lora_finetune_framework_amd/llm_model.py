@@ -29,8 +29,9 @@ class TransformerLM(nn.Module):
                  speech_token_size: int, text_encoder: nn.Module, llm: nn.Module, sampling=None,
                  length_normalized_loss: bool = True, lsm_weight: float = 0.0, spk_embed_dim: int = 192):
         super().__init__()
-        if lsm_weight != 0.0 or not length_normalized_loss:
-            raise NotImplementedError("only smoothing 0 + length-normalised CE (the CosyVoice-300M setting) is built")
+        if not length_normalized_loss:      # (denominator = batch size: the sub-batch / DP recombination is built on token counts)
+            raise NotImplementedError("only the length-normalised CE (the CosyVoice-300M setting) is built")
+        self.lsm_weight = float(lsm_weight)
         self.llm_input_size = llm_input_size
         self.speech_token_size = speech_token_size
         self.text_embedding = nn.Embedding(text_token_size, text_encoder_input_size)
@@ -102,7 +103,7 @@ class TransformerLM(nn.Module):
         lm_in = HF.gather_rows(src, idx, float(IGNORE_ID))
         out = self.llm.forward_cl(lm_in, B, L, lm_len, num, causal=True)
         logits = hip_linear(self.llm_decoder, out)
-        loss, acc = HF.cross_entropy(logits, tgt)
+        loss, acc = HF.cross_entropy(logits, tgt, self.lsm_weight)
         return {'loss': loss, 'acc': acc}
 
     def forward(self, batch: dict, device) -> Dict[str, Any]:

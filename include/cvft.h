@@ -283,10 +283,11 @@ int cvft_lora_side_dgrad(int M, int K, int R, const void* V, int ldv, const void
                          void* out, int ldo, float p, const int64_t* seed, const unsigned* sites, void* stream);
 /* CFM prepare (flow_matching.py:173-186 == flow_model.py:143-161), channel-last:
  *   feat raw log-mel [B][T][80] fp32, z [B][T][80] fp32, t_raw [B], cfg_keep [B] (0/1), mu [B][T][80],
- *   spk [B][80], cond (or NULL = zeros)  ->  xin [B][T][320] = [y | mu*keep | spk*keep | cond*keep],  u [B][T][80] (fp32), t [B]. */
+ *   spk [B][80], cond (or NULL = zeros)  ->  xin [B][T][320] = [y | mu*keep | spk*keep | cond*keep],  u [B][T][80] (fp32), t [B].
+ *   t_cosine: t_scheduler == 'cosine' (t = 1 - cos(t_raw pi/2), the CosyVoice-300M setting); 0 = t_raw as drawn. */
 int cvft_cfm_prepare(int dtype, int B, int T, const float* feat, const float* z, const float* t_raw,
                      const float* cfg_keep, const void* mu, const void* spk, const void* cond /*[B][T][80] or NULL*/,
-                     float mel_mean, float mel_std, float sigma_min, void* xin, float* u, float* t, void* stream);
+                     float mel_mean, float mel_std, float sigma_min, int t_cosine, void* xin, float* u, float* t, void* stream);
 /* masked MSE (flow_matching.py:192): loss_sum[0] += sum(((pred-u)*m)^2) (caller divides by sum(mask)*80);
  * backward: dpred = gscale[0] * 2 * (pred-u) * m  with gscale a DEVICE scalar (= upstream grad / denominator). */
 /* w (or NULL): per-frame loss weights [B*T] fp32 -- loss_sum += sum(((pred-u) * w)^2) over frames t < len[b]
@@ -301,14 +302,16 @@ int cvft_masked_mse_bwd(int dtype, int B, int T, int C, const void* pred, const 
  * Lin/Lout and the source clamp come from eff, output frames >= eff[1] are zeros, input frames >= eff[0] get no gradient. */
 int cvft_interp_linear_fwd(int dtype, int B, int Lin, int Lout, int C, const void* x, void* y, const int32_t* eff, void* stream);
 int cvft_interp_linear_bwd(int dtype, int B, int Lin, int Lout, int C, const void* dy, void* dx, const int32_t* eff, void* stream);
-/* token-mean cross entropy with ignore index + argmax accuracy
- * (label_smoothing_loss.py:68-96 smoothing 0 ; common.py:78-97).
- * logits [n][V]; target [n] int32 (-1 ignore). out[0]+=sum nll, out[1]+=#valid, out[2]+=#correct.
- * dlogits = gscale_ptr[0] * (softmax - onehot) for valid rows, 0 otherwise (if dlogits != NULL). */
+/* token-mean label-smoothed cross entropy with ignore index + argmax accuracy
+ * (LabelSmoothingLoss.forward, label_smoothing_loss.py:68-96 ; th_accuracy, common.py:78-97).
+ * logits [n][V]; target [n] int32 (-1 ignore); smoothing in [0, 1] (0: plain NLL, the CosyVoice-300M setting):
+ * true_dist = 1 - smoothing at the target, smoothing / (V - 1) elsewhere.
+ * out[0] += sum over valid rows of sum_c true_dist_c (log true_dist_c - log_softmax_c), out[1] += #valid, out[2] += #correct.
+ * dlogits = gscale_ptr[0] * (softmax - true_dist) for valid rows, 0 otherwise. */
 int cvft_ce_fwd(int dtype, int n, int V, const void* logits, int ld, const int32_t* target, float* out3,
-                float* row_lse /*[n]*/, void* stream);
+                float* row_lse /*[n]*/, float smoothing, void* stream);
 int cvft_ce_bwd(int dtype, int n, int V, const void* logits, int ld, const int32_t* target, const float* row_lse,
-                const float* gscale /*device [1]*/, void* dlogits, int ldd, void* stream);
+                const float* gscale /*device [1]*/, void* dlogits, int ldd, float smoothing, void* stream);
 /* depthwise Conv1d (groups=C), channel-last, zero padding, optional length mask on the input
  * (cosyvoice/transformer/convolution.py:62-70,118; not executed by the 300M config). */
 int cvft_dwconv1d_fwd(int dtype, int B, int T, int C, int Kw, int pad_left, const void* x, const float* w /*[C][Kw]*/,

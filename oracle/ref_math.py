@@ -337,10 +337,10 @@ def ode_steps_for(n_frames: int) -> int:
     return 20 if n_frames > 500 else 15 if n_frames > 300 else 10
 
 
-def cfm_prepare(x1, t_raw, z, sigma_min: float):
+def cfm_prepare(x1, t_raw, z, sigma_min: float, t_scheduler: str = 'cosine'):
     """cosyvoice/flow/flow_matching.py:173-181 == flow_model.py:143-155.
     t_raw = rand(B,1,1); returns t (B,1,1), y, u."""
-    t = 1 - torch.cos(t_raw * 0.5 * torch.pi)
+    t = 1 - torch.cos(t_raw * 0.5 * torch.pi) if t_scheduler == 'cosine' else t_raw
     y = (1 - (1 - sigma_min) * t) * z + t * x1
     u = x1 - (1 - sigma_min) * z
     return t, y, u
@@ -497,6 +497,22 @@ def ce_ignore(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     lp = torch.log_softmax(x, dim=1)
     nll = -lp.gather(1, tgt.masked_fill(ign, 0).unsqueeze(1)).squeeze(1)
     return nll.masked_fill(ign, 0).sum() / total
+
+
+def ce_label_smoothing(logits: torch.Tensor, target: torch.Tensor, smoothing: float, normalize_length: bool = True) -> torch.Tensor:
+    """label_smoothing_loss.py:68-96 in full: true_dist = smoothing/(V-1) off the target, 1-smoothing on it; KL summed
+    over the non-ignored rows (a zero target probability contributes 0), divided by #non-ignored tokens
+    (normalize_length) or by the batch size."""
+    V = logits.size(-1)
+    x = logits.reshape(-1, V)
+    tgt = target.reshape(-1)
+    ign = tgt == IGNORE_ID
+    total = tgt.numel() - int(ign.sum())
+    td = torch.full_like(x, smoothing / (V - 1))
+    td.scatter_(1, tgt.masked_fill(ign, 0).unsqueeze(1), 1.0 - smoothing)
+    lp = torch.log_softmax(x, dim=1)
+    kl = torch.where(td > 0, td * (td.clamp_min(1e-45).log() - lp), torch.zeros_like(lp))
+    return kl.masked_fill(ign.unsqueeze(1), 0).sum() / (total if normalize_length else logits.size(0))
 
 
 def th_accuracy(logits2d: torch.Tensor, target: torch.Tensor, ignore_label: int = IGNORE_ID) -> torch.Tensor:

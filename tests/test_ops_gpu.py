@@ -395,6 +395,35 @@ def test_cross_entropy(dtype):
     assert rel(ld.grad, 3.0 * lr.grad) < TOL[dtype]
 
 
+def test_cross_entropy_label_smoothing_matches_reference():
+    """cvft_ce_fwd/bwd with smoothing > 0 against the REFERENCE's LabelSmoothingLoss outputs (tests/golden/lsm.npz: loss and
+    autograd gradient, fp32 1e-5) and, at the LLM's vocabulary size in both dtypes, against the oracle restatement."""
+    from oracle import ref_math as R
+    from conftest import load_npz
+    HF = HFmod()
+    g = load_npz("lsm.npz")
+    n, V = g["logits"].shape[0] * g["logits"].shape[1], g["logits"].shape[2]
+    for eps in (0.1, 0.3, 1.0):
+        ld = g["logits"].reshape(n, V).to(DEV).requires_grad_(True)
+        loss, _ = HF.cross_entropy(ld, g["target"].reshape(n).to(DEV, torch.int32), eps)
+        loss.backward()
+        assert abs(float(loss) - float(g[f"loss_eps{eps}_tok"])) / abs(float(g[f"loss_eps{eps}_tok"])) < 1e-5
+        assert rel(ld.grad.reshape(g["logits"].shape), g[f"grad_eps{eps}_tok"]) < 1e-5
+    n, V = 37, 4097
+    tg = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(2))
+    tg[:5] = -1
+    for dtype in DTYPES:
+        lg = q(rnd(n, V, seed=1) * 2, dtype)
+        lr = lg.double().requires_grad_(True)
+        loss_r = R.ce_label_smoothing(lr.view(1, n, V), tg.view(1, n), 0.1)
+        loss_r.backward()
+        ld = lg.to(DEV, dtype).requires_grad_(True)
+        loss, _ = HF.cross_entropy(ld, tg.to(DEV, torch.int32), 0.1)
+        (loss * 3.0).backward()
+        assert abs(float(loss) - float(loss_r)) / abs(float(loss_r)) < (1e-5 if dtype == torch.float32 else 1e-4)
+        assert rel(ld.grad, 3.0 * lr.grad) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_cfm_prepare_and_mse(dtype):
     from oracle import ref_math as R
@@ -416,6 +445,11 @@ def test_cfm_prepare_and_mse(dtype):
     assert rel(xin.reshape(B, T, 320), xin_r) < TOL[dtype]
     assert rel(ud.reshape(B, T, 80), u.transpose(1, 2)) < 1e-6
     assert rel(td, t.view(B)) < 1e-6
+    # t_scheduler other than 'cosine' (flow_matching.py:176): t stays as drawn
+    tl, yl, _ = R.cfm_prepare(x1, t_raw, z, 1e-6, t_scheduler='linear')
+    xl, _, tdl = HF.cfm_prepare(mud.detach(), spk.to(DEV, dtype), feat.to(DEV), z.transpose(1, 2).contiguous().to(DEV),
+                                t_raw.view(B).to(DEV), keep.to(DEV), B, T, -6.0, 2.0, 1e-6, None, False)
+    assert torch.equal(tdl.cpu(), t_raw.view(B)) and rel(xl.reshape(B, T, 320)[..., :80], yl.transpose(1, 2)) < TOL[dtype]
     # masked MSE through the packed input (grad reaches mu through the keep mask)
     pred = xin[:, 80:160] * 1.5
     ln = torch.tensor(lens, dtype=torch.int32, device=DEV)

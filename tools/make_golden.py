@@ -544,6 +544,26 @@ def gen_ops():
                        loraconv_spec=[[k, list(s)] for k, s in sspec], loraconv_seed=17), f)
 
 
+def gen_lsm():
+    """LabelSmoothingLoss with smoothing > 0 (label_smoothing_loss.py:68-96): loss and d loss / d logits, both normalisations."""
+    g = torch.Generator().manual_seed(11)
+    arr = {}
+    lg = torch.randn(3, 6, 13, generator=g)
+    tg = torch.randint(0, 13, (3, 6), generator=g)
+    tg[0, :2] = -1
+    tg[1, 5] = -1
+    arr['logits'], arr['target'] = lg, tg
+    for eps in (0.1, 0.3, 1.0):
+        for nl in (True, False):
+            x = lg.clone().requires_grad_(True)
+            loss = LabelSmoothingLoss(size=13, padding_idx=-1, smoothing=eps, normalize_length=nl)(x, tg)
+            loss.backward()
+            tag = f"eps{eps}_{'tok' if nl else 'batch'}"
+            arr['loss_' + tag], arr['grad_' + tag] = loss.detach(), x.grad
+    np.savez(os.path.join(GOLD, "lsm.npz"), **{k: v.detach().numpy() for k, v in arr.items()})
+    print("wrote lsm.npz")
+
+
 def gen_train():
     """BASELINE configs[0] plumbing reference: 8 synthetic pairs, LoRA r=4, fp32 CPU, 2 epochs,
     batch 1, accumulate 2, AdamW + warmup-cosine LambdaLR + clip 1.0 (train_joint.py:198-226,
@@ -601,6 +621,8 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if a.only in ("all", "ops"):
         gen_ops()
+    if a.only in ("all", "lsm"):
+        gen_lsm()
     if a.only in ("all", "tiny"):
         gen_tiny()
     if a.only in ("all", "pos"):
