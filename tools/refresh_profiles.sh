@@ -21,4 +21,11 @@ python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi96ELi256ELi3ELi4ELi0ELi3EL
 rm -rf $OUT/counters
 python bench.py --workload flow_only --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_flow_only_b8.json
 python bench.py --ragged 2 --steps 120 --warmup 30 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_ragged2.json
+# eager launches through the same trainer (no hipGraph): what the captured micro-step buys
+python bench.py --graph 0 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_eager.json
+# BASELINE configs[4] shape on one GPU (r = 64, 1000-frame mel, B = 16): bf16 vs the fp8 frozen-W GEMM path
+python bench.py --frames 1000 --rank-lora 64 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_cfg4_bf16.json
+python bench.py --frames 1000 --rank-lora 64 --fp8 1 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_cfg4_fp8.json
+# the driver's N = 2 launch line with both ranks on this one GPU over gloo (rehearsal of the launch path, not a scaling number)
+CVFT_SINGLE_DEVICE=1 CVFT_DIST_BACKEND=gloo timeout -k 10 280 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 4 --warmup 2 --no-roofline 2>&1 | tail -1 > $OUT/bench_dp2_one_gpu_gloo.json
 echo refreshed
