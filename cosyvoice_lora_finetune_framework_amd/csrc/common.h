@@ -161,7 +161,7 @@ template <int N> __device__ __forceinline__ void act_grad_mul_vec(int act, float
 
 // ---------------------------------------------------------------- counter-based dropout masks
 // keep(i) for element i of a tensor is a pure function of (*seed, site, i): SplitMix64 finaliser on a 64-bit counter,
-// 4 x 32 random bits per group of 4 consecutive elements.  Every kernel that needs the mask of a (seed, site) pair
+// 4 x 16 random bits per group of 4 consecutive elements.  Every kernel that needs the mask of a (seed, site) pair
 // (cvft_dropout_add, the dropout-skinny product, the LoRA side dgrad) calls these, so they all see the same mask.
 __device__ __forceinline__ unsigned long long cvft_mix64(unsigned long long z) {
     z += 0x9e3779b97f4a7c15ULL;
@@ -172,11 +172,17 @@ __device__ __forceinline__ unsigned long long cvft_mix64(unsigned long long z) {
 __device__ __forceinline__ unsigned long long cvft_drop_key(const long long* seed, unsigned site) {
     return cvft_mix64((unsigned long long)seed[0] ^ ((unsigned long long)site << 32));
 }
-__device__ __forceinline__ unsigned cvft_drop_thr(float p) { return (unsigned)fminf(4294967295.f, p * 4294967296.f); }
-// keep flags of elements 4g .. 4g+3
+// 16 random bits per element: ONE SplitMix64 draw serves a group of 4 consecutive elements (its four 16-bit fields).  The
+// draw costs two 64-bit multiplies -- quarter-rate integer work, ~35 issue slots -- and these masks are re-derived inside
+// GEMM epilogues, rank-side products and the dropout passes of every train-mode step; at 32 bits per element (two draws
+// per group) the masked-extension GEMM launches ran 1.3-1.8x their plain twins on mask arithmetic alone.  p is quantised
+// to 1/65536 (0.05 -> 0.050003), the keep scale stays 1 / (1 - p).
+__device__ __forceinline__ unsigned cvft_drop_thr(float p) { return (unsigned)fminf(65535.f, rintf(p * 65536.f)); }
+// keep flags of elements 4g .. 4g+3: field e of the draw >= thr
 __device__ __forceinline__ void cvft_keep4(unsigned long long key, unsigned long long g, unsigned thr, bool (&k)[4]) {
-    const unsigned long long r0 = cvft_mix64(key + 2 * g), r1 = cvft_mix64(key + 2 * g + 1);
-    k[0] = (unsigned)r0 >= thr; k[1] = (unsigned)(r0 >> 32) >= thr; k[2] = (unsigned)r1 >= thr; k[3] = (unsigned)(r1 >> 32) >= thr;
+    const unsigned long long r = cvft_mix64(key + g);
+    const unsigned lo = (unsigned)r, hi = (unsigned)(r >> 32);
+    k[0] = (lo & 0xffffu) >= thr; k[1] = (lo >> 16) >= thr; k[2] = (hi & 0xffffu) >= thr; k[3] = (hi >> 16) >= thr;
 }
 
 // ---------------------------------------------------------------- reductions

@@ -528,7 +528,7 @@ extern "C" int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, voi
 // Inverted dropout with an optional residual add:  y = residual + keep(x) / (1 - p).
 // (nn.Dropout call sites of the encoders: subsampling.py:84, embedding.py:285-288, encoder_layer.py:95-104 / 205-234,
 //  positionwise_feed_forward.py:54.)  The keep mask is a pure function of (*seed, site, element index) -- SplitMix64
-// finaliser on a 64-bit counter, 4 x 32 random bits per group of 4 elements -- so backward re-derives it instead of
+// finaliser on a 64-bit counter, 4 x 16 random bits per group of 4 elements -- so backward re-derives it instead of
 // storing a mask tensor, and a captured hipGraph gets fresh masks on every replay because *seed lives on the device.
 // Not torch's Philox stream: equality with the reference is statistical (keep rate, scale), as for any RNG change.
 // ------------------------------------------------------------------------------
@@ -538,7 +538,7 @@ template <typename T, int MODE, bool VEC>
 __global__ void dropout_add_kernel(size_t n, const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, float p,
                                    const long long* __restrict__ seed, unsigned site, int act) {
     const unsigned long long key = cvft_drop_key(seed, site);
-    const unsigned thr = cvft_drop_thr(p);                                    // keep when u32 >= thr
+    const unsigned thr = cvft_drop_thr(p);                                    // keep when the element's 16-bit field >= thr
     const float scale = 1.f / (1.f - p);
     const size_t n4 = (n + 3) / 4;
     typedef typename std::conditional<sizeof(T) == 2, uint2, uint4>::type V4;

@@ -928,9 +928,10 @@ def _keep_scale_host(seed: int, site: int, n: int, p: float) -> torch.Tensor:
     with np.errstate(over="ignore"):
         key = mix(np.uint64(seed) ^ (np.uint64(site) << np.uint64(32)))
         g = np.arange((n + 3) // 4, dtype=np.uint64)
-        r0, r1 = mix(key + np.uint64(2) * g), mix(key + np.uint64(2) * g + np.uint64(1))
-    u = np.stack([r0 & np.uint64(0xFFFFFFFF), r0 >> np.uint64(32), r1 & np.uint64(0xFFFFFFFF), r1 >> np.uint64(32)], 1).reshape(-1)[:n]
-    thr = int(min(4294967295.0, float(np.float32(p) * np.float32(4294967296.0))))
+        r = mix(key + g)                                        # one draw per 4 elements, 16-bit fields
+    f = np.uint64(0xFFFF)
+    u = np.stack([r & f, (r >> np.uint64(16)) & f, (r >> np.uint64(32)) & f, r >> np.uint64(48)], 1).reshape(-1)[:n]
+    thr = int(min(65535.0, float(np.rint(np.float32(p) * np.float32(65536.0)))))
     return torch.from_numpy((u >= np.uint64(thr)).astype(np.float64)) / (1.0 - float(np.float32(p)))
 
 
