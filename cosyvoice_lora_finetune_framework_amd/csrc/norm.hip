@@ -82,12 +82,17 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(int rows, int C, const T* _
     }
 }
 
-template <typename T, bool VP>
+// MK (vector path only): also writes dxm = keep(site) / (1 - p) * dx, the gradient that the dropout in front of x's producer
+// (x = residual + dropout(linear(.)), encoder_layer.py:95 / 104) hands to that linear -- its backward then needs no pass of its
+// own over dx (cvft_layernorm_bwd_mask).  The mask is cvft_dropout_add's: flat element index row * C + c, groups of 4.
+template <typename T, bool VP, bool MK = false>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       int relu, float post, const T* __restrict__ dy,
-                                                      const T* __restrict__ dres, T* __restrict__ dx) {
+                                                      const T* __restrict__ dres, T* __restrict__ dx,
+                                                      float mp = 0.f, const long long* __restrict__ mseed = nullptr,
+                                                      unsigned msite = 0, T* __restrict__ dxm = nullptr) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int NCH = 4;
     const int lane = threadIdx.x & 63;
@@ -143,6 +148,21 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o[k] = from_f32<T>(rs * (g[q][k] - s1 - xh[q][k] * s2) + add[k]);
                 *reinterpret_cast<uint4*>(ox + ch * VEC) = *reinterpret_cast<uint4*>(o);
+                if (MK) {
+                    const unsigned long long key = cvft_drop_key(mseed, msite);
+                    const unsigned thr = cvft_drop_thr(mp);
+                    const float inv = 1.f / (1.f - mp);
+                    const unsigned long long g0 = ((unsigned long long)row * C + (unsigned long long)ch * VEC) >> 2;   // C % VEC == 0
+                    T om[VEC];
+#pragma unroll
+                    for (int gq = 0; gq < VEC / 4; ++gq) {
+                        bool kp[4];
+                        cvft_keep4(key, g0 + gq, thr, kp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) om[4 * gq + e] = kp[e] ? from_f32<T>(to_f32(o[4 * gq + e]) * inv) : from_f32<T>(0.f);
+                    }
+                    *reinterpret_cast<uint4*>(dxm + (size_t)row * C + ch * VEC) = *reinterpret_cast<uint4*>(om);
+                }
             }
         }
         return;
@@ -206,6 +226,28 @@ extern "C" int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, con
     else { if (ra && ln_vec_ok<bf16_t>(C, x, dy, dx)) LN_BWD(bf16_t, true); else LN_BWD(bf16_t, false); }
 #undef LN_BWD
     CVFT_LAUNCH_CHECK("cvft_layernorm_bwd");
+    return 0;
+}
+
+extern "C" int cvft_layernorm_bwd_mask(int dtype, int rows, int C, const void* x, const float* gamma, const float* beta,
+                                       const float* mean, const float* rstd, const void* dy, const void* dres, void* dx,
+                                       float p, const int64_t* seed, unsigned site, void* dxm, void* stream) {
+    CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_layernorm_bwd_mask: bad dtype");
+    CVFT_CHECK_ARG(rows >= 0 && C > 0 && x && gamma && beta && mean && rstd && dy && dx && dxm && seed, "cvft_layernorm_bwd_mask: bad args");
+    CVFT_CHECK_ARG(p > 0.f && p < 1.f, "cvft_layernorm_bwd_mask: p outside (0, 1)");
+    const bool ra = ((reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(dxm)) & 15) == 0;
+    const bool ok = ra && (dtype == CVFT_F32 ? ln_vec_ok<float>(C, x, dy, dx) : ln_vec_ok<bf16_t>(C, x, dy, dx));
+    CVFT_CHECK_ARG(ok, "cvft_layernorm_bwd_mask: needs the vector path (C % (16 / sizeof(T)) == 0, C <= 256 chunks, 16-byte aligned pointers)");
+    if (rows == 0) return 0;
+    dim3 grid((rows + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CVFT_F32)
+        hipLaunchKernelGGL((ln_bwd_kernel<float, true, true>), grid, dim3(256), 0, st, rows, C, (const float*)x, gamma, beta, mean, rstd, 0, 1.f,
+                           (const float*)dy, (const float*)dres, (float*)dx, p, (const long long*)seed, site, (float*)dxm);
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, true, true>), grid, dim3(256), 0, st, rows, C, (const bf16_t*)x, gamma, beta, mean, rstd, 0, 1.f,
+                           (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, p, (const long long*)seed, site, (bf16_t*)dxm);
+    CVFT_LAUNCH_CHECK("cvft_layernorm_bwd_mask");
     return 0;
 }
 

@@ -254,6 +254,8 @@ def dropout_begin_step() -> None:
     _DROPOUT["seed"].add_(1)
     _DROPOUT["site"] = 0
     _DROPPED.clear()              # dropped inputs a previous forward wrote and no backward consumed
+    _ODROP_OUT.clear()
+    _PRE_MASKED.clear()
 
 
 class DropoutAddFn(torch.autograd.Function):
@@ -344,6 +346,27 @@ _DROPPED = {}       # mask site -> drop(x) written by the forward skinny kernel,
 
 
 _PRE_U = {}        # LN output data_ptr -> (U, A data_ptr, alpha, p, sites): the rank-side product the LayerNorm launch already made
+
+# The residual-branch dropout of an encoder sublayer, y = residual + dropout(linear(.)), has its mask applied in the GEMM epilogue;
+# in backward the linear needs keep / (1 - p) * dy.  dy is written by the LayerNormForkFn that consumed y (its one consumer), so
+# that launch writes the masked copy too (cvft_layernorm_bwd_mask) and the linear's own mask pass over dy disappears.
+_ODROP_OUT = {}     # data_ptr of y -> (p, site), noted by the producing Function, read by the LayerNormForkFn that takes y
+_PRE_MASKED = {}    # data_ptr of the dx a LayerNormForkFn backward wrote -> (dxm, p, site)
+import os as _os  # noqa: E402
+LN_BWD_MASK = _os.environ.get("CVFT_LN_BWD_MASK", "1") != "0"
+
+
+def _note_out_drop(y: torch.Tensor, od) -> None:
+    if LN_BWD_MASK and od is not None:
+        _ODROP_OUT[y.data_ptr()] = (float(od[0]), int(od[1]))
+
+
+def _masked_dy(dy: torch.Tensor, od) -> torch.Tensor:
+    """keep(site) / (1 - p) * dy: the copy the LayerNorm backward already wrote for exactly this (p, site), else one mask pass."""
+    ent = _PRE_MASKED.pop(dy.data_ptr(), None)
+    if ent is not None and ent[1] == float(od[0]) and ent[2] == int(od[1]) and ent[0].shape == dy.shape and ent[0].dtype == dy.dtype:
+        return ent[0]
+    return dropout_raw(dy, od[0], od[1])
 
 
 def take_pre_u(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, nsites: int):
@@ -927,6 +950,7 @@ class LinearFn(torch.autograd.Function):
             ctx.save_for_backward(x, None, None)
             return y[:, :pack.N]
         y, U, z, ops = _lin_fwd(x, A, B, pack, scale, act, residual, need_grad, ctx.drop, ctx.odrop)
+        _note_out_drop(y, ctx.odrop)
         ctx.pack, ctx.scale, ctx.act = pack, scale, act
         ctx.ops, ctx.A_ref, ctx.B_ref = ops, A, B
         ctx.save_for_backward(x, U, z)
@@ -941,7 +965,7 @@ class LinearFn(torch.autograd.Function):
         dy = _c(dy) if (ctx.act or ctx.odrop) else _rowc(dy)
         dres = dy if ctx.needs_input_grad[3] else None
         if ctx.odrop is not None:
-            dy = dropout_raw(dy, ctx.odrop[0], ctx.odrop[1])
+            dy = _masked_dy(dy, ctx.odrop)
         dz = act_bwd(z, dy, ctx.act) if ctx.act else dy
         dx, dA, dB = _lin_bwd(x, U, ctx.ops, ctx.A_ref, ctx.B_ref, ctx.pack, ctx.scale, dz, ctx.needs_input_grad[0],
                               ctx.needs_input_grad[1] or ctx.needs_input_grad[2], drop=ctx.drop)
@@ -1151,6 +1175,7 @@ class FeedForwardFn(torch.autograd.Function):
         ctx.drops = (d1, d2, od_in, od_out)
         h, U1, z, ops1 = _lin_fwd(x, A1, B1, pack1, s1, act, None, need_grad, d1, od_in)
         y, U2, _, ops2 = _lin_fwd(h, A2, B2, pack2, s2, None, residual, False, d2, od_out)
+        _note_out_drop(y, od_out)
         ctx.cfg = (pack1, pack2, s1, s2, act, ops1, ops2, (A1, B1), (A2, B2))
         ctx.save_for_backward(x, U1, z, h if A2 is not None else None, U2)      # (h: dA2 = V2^T h, or drop(h) re-derived)
         return y
@@ -1163,7 +1188,7 @@ class FeedForwardFn(torch.autograd.Function):
         dy = _c(dy) if od_out is not None else _rowc(dy)
         dres = dy if ctx.needs_input_grad[5] else None
         if od_out is not None:
-            dy = dropout_raw(dy, od_out[0], od_out[1])
+            dy = _masked_dy(dy, od_out)
         need1 = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         need2 = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         need_dx = ctx.needs_input_grad[0]
@@ -1403,6 +1428,7 @@ class LayerNormForkFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps: float, side=None):
         x = _c(x)
         rows, Cn = x.shape
+        ctx.prev_odrop = _ODROP_OUT.pop(x.data_ptr(), None)      # x = residual + dropout(linear(.)): (p, site) of that mask
         if side is not None:                  # (A [R, K] compute dtype, alpha, p, nsites): the adapter that will read y
             y, mean, rstd = ln_skinny_dropout(x, gamma, beta, eps, *side)
         else:
@@ -1422,6 +1448,16 @@ class LayerNormForkFn(torch.autograd.Function):
         dy = _c(dy)
         dres = None if dres is None else _c(dres)
         dx = torch.empty_like(x)
+        od = ctx.prev_odrop
+        vec = 16 // x.element_size()
+        if (od is not None and x.shape[1] % vec == 0 and x.shape[1] <= 256 * vec and
+                all(t is None or (t.data_ptr() & 15) == 0 for t in (x, dy, dres, dx))):
+            dxm = torch.empty_like(x)          # dx under the mask of x's producer, parked for that Function's backward
+            check(lib().cvft_layernorm_bwd_mask(dt(x), x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                                ptr(dy), ptr(dres), ptr(dx), od[0], ptr(_DROPOUT["seed"]), od[1], ptr(dxm), stream()),
+                  "cvft_layernorm_bwd_mask")
+            _PRE_MASKED[dx.data_ptr()] = (dxm, od[0], od[1])
+            return dx, None, None, None, None
         check(lib().cvft_layernorm_bwd(dt(x), x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                        0, 1.0, ptr(dy), ptr(dres), ptr(dx), stream()), "cvft_layernorm_bwd")
         return dx, None, None, None, None

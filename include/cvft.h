@@ -171,6 +171,13 @@ int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, const float* g
                        const float* mean, const float* rstd, int relu, float post_scale,
                        const void* dy, const void* dres, void* dx, void* stream);
 /* dres (or NULL): a second gradient of x (the residual branch of a pre-norm block), added into dx by the same launch */
+/* cvft_layernorm_bwd (relu 0, post_scale 1) that ALSO writes dxm = keep(seed, site) / (1 - p) * dx with the mask of
+ * cvft_dropout_add over the flat [rows][C] index: when x = residual + dropout(linear(.)) (encoder_layer.py:95 / 104) the
+ * linear's backward takes dxm as its incoming gradient instead of running its own mask pass over dx.  Vector path only
+ * (C a multiple of 16 bytes of elements, 16-byte aligned pointers), else CVFT_EINVAL. */
+int cvft_layernorm_bwd_mask(int dtype, int rows, int C, const void* x, const float* gamma, const float* beta,
+                            const float* mean, const float* rstd, const void* dy, const void* dres, void* dx,
+                            float p, const int64_t* seed, unsigned site, void* dxm, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * GroupNorm(G) + Mish (+ length mask, + per-(batch,channel) additive term), channel-last.

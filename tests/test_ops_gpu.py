@@ -792,6 +792,52 @@ def test_feed_forward_train_mode_fused_matches_unfused(act, lora, lora_p):
     assert rel(ff(x.detach(), res.detach()), a[0]) > 5e-2
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_backward_writes_the_producer_mask_copy(dtype):
+    """x = residual + dropout(linear(h)) -> (x, LN(x)) (encoder_layer.py:95-106): the LayerNormForkFn backward also writes
+    keep / (1 - p) * dx for the linear in front of it (cvft_layernorm_bwd_mask), which then skips its own mask pass over dx.
+    Against the same chain with that hand-over switched off, same seed and sites: every gradient bit-identical; and the
+    hand-over really happened (no entry left parked, one cvft_dropout_add launch fewer is visible as an empty registry)."""
+    HF = HFmod()
+    torch.manual_seed(5)
+    M, d, hid = 333, 256, 512
+    lin = torch.nn.Linear(hid, d).to(DEV)
+    pack = HF.LinearPack(lin.weight, lin.bias, dtype)
+    gamma, beta = (torch.rand(d, device=DEV) + 0.5), torch.randn(d, device=DEV) * 0.1
+    h = torch.randn(M, hid, device=DEV).to(dtype).requires_grad_(True)
+    res = torch.randn(M, d, device=DEV).to(dtype).requires_grad_(True)
+    g1, g2 = torch.randn(M, d, device=DEV).to(dtype), torch.randn(M, d, device=DEV).to(dtype)
+    HF.dropout_begin_step()
+
+    def run(handover: bool):
+        HF.LN_BWD_MASK = handover
+        HF._DROPOUT["site"] = 7
+        HF._ODROP_OUT.clear()
+        HF._PRE_MASKED.clear()
+        h.grad = res.grad = None
+        x = HF.lora_linear(h, pack, residual=res, out_drop_p=0.1)
+        xr, xn = HF.layernorm_fork(x, gamma, beta, 1e-5)
+        assert (len(HF._ODROP_OUT) == 0)                     # taken by the LayerNorm (or never noted)
+        torch.autograd.backward([xr, xn], [g1, g2])
+        torch.cuda.synchronize()
+        assert len(HF._PRE_MASKED) == 0                      # consumed by the linear's backward
+        return x.detach().clone(), h.grad.clone(), res.grad.clone()
+    try:
+        a = run(True)
+        b = run(False)
+    finally:
+        HF.LN_BWD_MASK = True
+    for u, w in zip(a, b):
+        assert torch.equal(u, w)
+    # the mask is on: about p of the rows' branch gradient is zero -> compare with p = 0
+    HF._DROPOUT["site"] = 7
+    h.grad = None
+    x0 = HF.lora_linear(h, pack, residual=res)
+    xr, xn = HF.layernorm_fork(x0, gamma, beta, 1e-5)
+    torch.autograd.backward([xr, xn], [g1, g2])
+    assert rel(h.grad, a[1]) > 5e-2
+
+
 def test_encoder_train_mode_applies_dropout(tiny_meta=None):
     """RelPosEncoder in .train(): output differs from eval, differs between steps, p = 0 reproduces eval exactly."""
     HF = HFmod()
