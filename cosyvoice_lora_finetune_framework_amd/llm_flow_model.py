@@ -30,6 +30,9 @@ from .modules import Numerics
 SPLIT = {'llm': int(os.environ.get("CVFT_LLM_SPLIT", "1")), 'flow': int(os.environ.get("CVFT_FLOW_SPLIT", "2"))}      # joint / flow_only
 SPLIT_LLM_ONLY = int(os.environ.get("CVFT_LLM_SPLIT", "2"))                                                             # llm_only
 SPLIT_MIN_PART = int(os.environ.get("CVFT_SPLIT_MIN_PART", "4"))      # utterances per sub-batch below which a branch is not split
+# flow_only has no LLM chain to overlap with: two Flow chains of 4 utterances are SLOWER than one of 8 (BASELINE configs[1], B = 8:
+# 13.89 vs 13.56 ms/step, same-box A/B), two of 8 faster than one of 16 (18.1 vs 18.6)
+SPLIT_MIN_PART_FLOW_ONLY = int(os.environ.get("CVFT_SPLIT_MIN_PART_FLOW_ONLY", "8"))
 BRANCH_STREAMS = os.environ.get("CVFT_BRANCH_STREAMS", "1") != "0"      # LLM branch on a second stream (joint mode): 35.9 -> 30.1 ms/step
 
 
@@ -156,7 +159,8 @@ class JointLLMFlowModel(nn.Module):
         for kind in ('llm', 'flow'):
             runs = self.training_mode in ('joint', f'{kind}_only')          # a branch the mode does not run is never split
             n = SPLIT_LLM_ONLY if (kind == 'llm' and self.training_mode == 'llm_only') else SPLIT[kind]
-            if not (split and runs) or B < n * SPLIT_MIN_PART:
+            min_part = SPLIT_MIN_PART_FLOW_ONLY if self.training_mode == 'flow_only' else SPLIT_MIN_PART
+            if not (split and runs) or B < n * min_part:
                 n = 1
             parts[kind] = self._split_parts(batch, device, n, kind, lm_pad) if n > 1 else [dict(whole, _w_llm=1.0, _w_flow=1.0)]
         return parts

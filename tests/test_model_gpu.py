@@ -332,7 +332,11 @@ def test_bench_batch_equals_accumulated_small_batches(branch, B):
             total += float(out["loss"]) * w
         torch.cuda.synchronize()
         return total, opt.flat_g.clone()
-    big_loss, big = run([slice(0, B)])
+    min_part_fo, J.SPLIT_MIN_PART_FLOW_ONLY = J.SPLIT_MIN_PART_FLOW_ONLY, 4      # (flow_only splits from 2 x 8 by default)
+    try:
+        big_loss, big = run([slice(0, B)])
+    finally:
+        J.SPLIT_MIN_PART_FLOW_ONLY = min_part_fo
     small_loss, small = run([slice(i, i + 2) for i in range(0, B, 2)])
     assert abs(big_loss - small_loss) / abs(small_loss) < 2e-3, (big_loss, small_loss)
     assert float(small.norm()) > 0
