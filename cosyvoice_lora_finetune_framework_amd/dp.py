@@ -53,9 +53,15 @@ def loss_weights(local_denoms: Dict[str, float], device) -> Dict[str, float | to
     before backward makes all-reduce(sum)/world of the gradients equal the gradient of the
     global-batch mean.  Uniform shards -> 1.0.  Device tensors, no host sync."""
     keys = sorted(local_denoms)
-    t = torch.tensor([float(local_denoms[k]) for k in keys], dtype=torch.float32, device=device)
     if world_size() == 1:
         return {k: 1.0 for k in keys}
+    t = torch.tensor([float(local_denoms[k]) for k in keys], dtype=torch.float32)
+    if torch.device(device).type == "cuda":
+        # pinned + non_blocking: a pageable host -> device copy synchronises the stream, i.e. the host would wait for the whole
+        # previous step before it may start enqueueing the next one (the captured step takes the host ~10 ms to enqueue)
+        t = t.pin_memory().to(device, non_blocking=True)
+    else:
+        t = t.to(device)
     tot = t.clone()
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     w = t * world_size() / tot.clamp_min(1e-12)
