@@ -875,16 +875,21 @@ def _lora_param_grads(x, U, V, dz, A_ref, B_ref, ops):
 
 
 def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_dx: bool, need_dAB: bool,
-             dx_residual=None, dact_src=None, dact: Optional[str] = None, drop=None, odrop=None):
+             dx_residual=None, dact_src=None, dact: Optional[str] = None, drop=None, odrop=None, out_scale: float = 1.0):
     """Backward of one LoRA linear given dz = gradient at its pre-activation output.
     dx = (dz W + (scale * dz B) A) [* act'(dact_src)] [* keep(odrop) / (1 - p)] [+ dx_residual]  -- the bracketed links ride in
     the dgrad epilogue (fused producer-activation backward, the producer's dropout mask, fused gradient accumulation);
     dA / dB go to the parameters' flat .grad buffers (through the active LoraGradSink when there is one) or are returned."""
     dx = dA = dB = V = None
     has_lora = ops is not None
+    # out_scale (a constant factor on dx, applied as the dgrad launch's alpha before act'): the keep scale of a producer whose
+    # mask is already in dact_src (FeedForwardFn's ReLU form); not combined with dx_residual
+    assert out_scale == 1.0 or dx_residual is None
 
     def producer_chain(dh):
         """act'(z) and the producer's dropout mask as passes of their own (launches whose epilogue could not take them)"""
+        if out_scale != 1.0:
+            dh = dh * out_scale
         if dact_src is None:
             return dh if odrop is None else dropout_raw(dh, odrop[0], odrop[1])
         if odrop is None:
@@ -902,7 +907,7 @@ def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_d
         if need_dx:
             if _can_xdrop(dz, pack.Wb, V, At, dx_residual):
                 dx = gemm(dz, pack.Wb, U=V, Bl=At, residual=dx_residual, xdrop=(drop[0], [drop[1]] * (V.shape[1] // 16)),
-                          dact_src=dact_src, dact=dact, odrop=odrop)
+                          dact_src=dact_src, dact=dact, odrop=odrop, alpha=out_scale)
             else:
                 assert dx_residual is None or (dact_src is None and odrop is None)
                 dx = gemm(dz, pack.Wb, residual=dx_residual)
@@ -916,12 +921,12 @@ def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_d
             # dgrad with the side path fused: V = s * dz B is produced by the same launch
             V = torch.empty((dz.shape[0], Bt.shape[0]), dtype=dz.dtype, device=dz.device)
             dx = gemm(dz, pack.Wb, La=Bt, lora_scale=scale, Uout=V, Bl=At, dact_src=dact_src, dact=dact, residual=dx_residual,
-                      odrop=odrop)
+                      odrop=odrop, alpha=out_scale)
         elif need_dx or need_dAB:
             V = gemm(dz, Bt, alpha=scale)                         # [M, r] = s * dz B
     if need_dx and dx is None:
         dx = _mm(dz, pack, 'b', pack.Wb, U=V, Bl=None if V is None else ops[1], dact_src=dact_src, dact=dact, residual=dx_residual,
-                 odrop=odrop)
+                 odrop=odrop, alpha=out_scale)
     if has_lora and need_dAB:
         dA, dB = _lora_param_grads(x, U, V, dz, A_ref, B_ref, ops)
     return dx, dA, dB
@@ -1173,7 +1178,10 @@ class FeedForwardFn(torch.autograd.Function):
         d2 = [float(p2), _next_drop_site()] if (p2 > 0 and A2 is not None) else None
         od_out = (float(p_out), _next_drop_site()) if p_out > 0 else None
         ctx.drops = (d1, d2, od_in, od_out)
-        h, U1, z, ops1 = _lin_fwd(x, A1, B1, pack1, s1, act, None, need_grad, d1, od_in)
+        # ReLU: relu'(z) * keep_in / (1 - p_in) == (h > 0) / (1 - p_in) with h = drop_in(relu(z)), which is saved for dA2 anyway --
+        # no pre-activation copy in forward (43 MB per LLM layer), no inner-mask draws in backward
+        ctx.relu_h = RELU_FROM_H and act == "relu" and A2 is not None
+        h, U1, z, ops1 = _lin_fwd(x, A1, B1, pack1, s1, act, None, need_grad and not ctx.relu_h, d1, od_in)
         y, U2, _, ops2 = _lin_fwd(h, A2, B2, pack2, s2, None, residual, False, d2, od_out)
         _note_out_drop(y, od_out)
         ctx.cfg = (pack1, pack2, s1, s2, act, ops1, ops2, (A1, B1), (A2, B2))
@@ -1192,8 +1200,12 @@ class FeedForwardFn(torch.autograd.Function):
         need1 = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         need2 = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         need_dx = ctx.needs_input_grad[0]
-        dz, dA2, dB2 = _lin_bwd(h, U2, ops2, A2, B2, pack2, s2, dy, need_dx or need1, need2, dact_src=z, dact=act, drop=d2,
-                                odrop=od_in)
+        if ctx.relu_h:
+            dz, dA2, dB2 = _lin_bwd(h, U2, ops2, A2, B2, pack2, s2, dy, need_dx or need1, need2, dact_src=h, dact=act, drop=d2,
+                                    out_scale=1.0 / (1.0 - od_in[0]) if od_in is not None else 1.0)
+        else:
+            dz, dA2, dB2 = _lin_bwd(h, U2, ops2, A2, B2, pack2, s2, dy, need_dx or need1, need2, dact_src=z, dact=act, drop=d2,
+                                    odrop=od_in)
         dx = dA1 = dB1 = None
         if dz is not None:
             dx, dA1, dB1 = _lin_bwd(x, U1, ops1, A1, B1, pack1, s1, dz, need_dx, need1, drop=d1)
@@ -1242,6 +1254,8 @@ def lora_linear(x, pack: LinearPack, A=None, B=None, scale: float = 1.0, act: Op
 OUT_DROP_FUSE = _os.environ.get("CVFT_OUT_DROP_FUSE", "1") != "0"
 # train-mode feed-forward as ONE Function (activation + inner mask in W1's epilogue, act' + inner mask in W2's dgrad epilogue)
 FFN_TRAIN_FUSE = _os.environ.get("CVFT_FFN_TRAIN_FUSE", "1") != "0"
+# ReLU feed-forward backward from the saved (dropped) hidden activations instead of a pre-activation copy (FeedForwardFn)
+RELU_FROM_H = _os.environ.get("CVFT_RELU_FROM_H", "1") != "0"
 
 _QKV_STACKS = {}
 QKV_STACKING = _os.environ.get("CVFT_QKV_STACK", "1") != "0"
