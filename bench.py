@@ -32,6 +32,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / shared device tensors fail with hipIpcGetMemHandle otherwise);
+# the driver's environment exports it already -- this only covers a launch from a shell that lost it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md chip table)
