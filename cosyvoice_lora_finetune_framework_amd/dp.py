@@ -17,6 +17,7 @@ import torch.distributed as dist
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
     """(rank, local_rank, world).  Reads RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set by torch.distributed.run."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL (read when the HIP runtime initialises)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
