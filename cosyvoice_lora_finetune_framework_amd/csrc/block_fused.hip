@@ -1,0 +1,575 @@
+// block_fused.hip -- the estimator's transformer block (matcha transformer.py:243-316 == modules.py:296-375) as row-tile
+// kernels: a workgroup owns 32 rows of the [batch*time, 256] residual stream and carries them through a whole CHAIN of
+// linears, so the [M, 1024] hidden activations and the LayerNorm outputs never touch HBM.
+//
+//   cvft_block_tail_fwd:  x1 = x0 + o Wo^T + bo ;  out = x1 + W2 act(W1 LN(x1) + b1) + b2          (one launch)
+//   cvft_block_tail_bwd:  dx1 = dy + LN'(W1^T (act'(z) . (W2^T dy))) ;  do = dx1 Wo                 (one launch)
+//
+// Structure (MI355X): d = 256 is small, so a row tile's activations fit in ONE wave's registers as MFMA B-operand
+// fragments (32 rows x 256 = 64 VGPRs), and every product is computed TRANSPOSED -- D^T[feature, row] = W[feature, k] .
+// X^T[k, row], weights as the A operand -- so that
+//   * the frozen weights are pre-packed on the host in MFMA A-fragment order and IN THE ORDER THE WAVE CONSUMES THEM
+//     (hipops/blockpack.py): a wave's weights are one linear stream of 1-KB fragments loaded straight into VGPRs (no LDS
+//     image, no barrier, no bank conflicts: the weights of a row tile are read once per wave and never shared --
+//     cdna_hip_programming.md section 5, "GEMV / M <= 16 ... neither").  The stream runs through a ring of 32 fragment
+//     registers; every register is re-requested for stream position p + 32 right behind the MFMA that consumed position p,
+//     so 32 KB per wave stay in flight through every phase of the kernel, barriers and LayerNorm included;
+//   * the hidden tile a wave has just produced (accumulator layout: row on the lane, feature in the register index) is,
+//     after activation and bf16 packing, directly the B operand of the next product (cdna_hip_programming.md section 3,
+//     "An accumulator tile as the next MFMA's operand"); the k permutation that costs is folded into the packed weights.
+// The 4 waves of a workgroup split the REDUCTION dimension of each chain link (hidden units of the feed-forward, input
+// features of the output projection) and meet once per link in LDS (fp32 partial tiles, 128 KB).
+// Bound: the per-CU L2 -> register rate (~120 GB/s per CU with one workgroup per CU, tools/ub/mfma_rate.hip): 1.25 MB of
+// packed weights per row tile each way; 125 workgroups at M = 4000.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// Diagnostic build only (-DBF_STAMPS, tools/block_stamps.py): s_memtime at the phase boundaries of wave 0 of one block of the
+// forward kernel, read back by cvft_debug_block_stamps of that build (never in the product library).
+#ifdef BF_STAMPS
+__device__ unsigned long long bf_stamps[32];
+#define BF_STAMP_BLOCK 7
+#define BF_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+        __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == BF_STAMP_BLOCK && threadIdx.x == 0) bf_stamps[i] = t__; } while (0)
+extern "C" int cvft_debug_block_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bf_stamps), sizeof(bf_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define BF_STAMP(i)
+#endif
+
+#define BF_ROWS 32
+#define BF_D 256
+#define BF_CT (BF_D / 32)                 // 8 output-feature tiles of the residual stream
+#define BF_KS (BF_D / 16)                 // 16 k-steps over the residual stream
+#define BF_RING 32                        // weight fragments in flight per wave
+
+// LDS carve (dynamic, 16-byte aligned base)
+#define BF_LDS_PART 0                     // 4 waves x [8 ct][4 g][64 lanes] f32x4 = 128 KB
+#define BF_LDS_TILE (4 * 32768)           // [32 rows][256] bf16, 16-byte chunks XOR-swizzled by (row & 15): 16 KB
+#define BF_LDS_STAT (BF_LDS_TILE + 16384) // [3][4 waves][32 rows] floats
+#define BF_LDS_BIAS (BF_LDS_STAT + 3 * 4 * 32 * 4)   // F floats: the hidden bias (read per tile without touching vmcnt)
+#define BF_MAX_F 2048
+#define BF_LDS_PAR (BF_LDS_BIAS + 4 * BF_MAX_F)      // 4 x 256 floats: bo | gamma | beta | b2 (a late global load would queue
+                                                     // behind the 32 KB of weight fragments in flight: vmcnt retires in order)
+#define BF_LDS_TOTAL (BF_LDS_PAR + 4 * 4 * BF_D)
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// GELU and its derivative (the feed-forward's activation runs on 32 x F values per row tile in a kernel with a single wave per
+// SIMD: its VALU cost sits beside the MFMAs of the same wave).  erf form (diffusers GELU, approximate="none"):
+// Abramowitz-Stegun 7.1.26 on u = |x| / sqrt(2), t = 1 / (1 + p u), 1 - erf(u) = poly(t) exp(-u^2), |error| <= 1.5e-7;
+// Phi(x) = 1 - q (x >= 0) or q (x < 0) with q = poly(t) exp(-x^2 / 2) / 2;  gelu = x Phi,  gelu' = Phi + x phi(x).
+// tanh form ("gelu-approximate"): Phi ~ sigmoid(2 k0 (x + k1 x^3)).
+template <int ACT, bool GRAD>
+__device__ __forceinline__ float bf_gelu(float x) {
+    if (ACT == CVFT_ACT_GELU_ERF) {
+        const float ax = fabsf(x);
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.23164190f, ax, 1.f));           // p / sqrt(2)
+        float q = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+        q = fmaf(q, t, 0.5f * 1.421413741f);
+        q = fmaf(q, t, 0.5f * -0.284496736f);
+        q = fmaf(q, t, 0.5f * 0.254829592f);
+        const float e2 = __builtin_amdgcn_exp2f(-0.72134752f * x * x);               // exp(-x^2 / 2)
+        q = q * t * e2;
+        const float cdf = x >= 0.f ? 1.f - q : q;
+        return GRAD ? fmaf(x * 0.39894228f, e2, cdf) : x * cdf;
+    } else {
+        const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
+        const float x2 = x * x;
+        const float u = k0 * x * fmaf(k1, x2, 1.f);
+        const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008f * u));   // sigmoid(2u) = (1 + tanh u) / 2
+        // d/dx [x sigmoid(2u)] = sg + x * 2 sg (1 - sg) * du/dx,  du/dx = k0 (1 + 3 k1 x^2)
+        return GRAD ? fmaf(x * 2.f * sg * (1.f - sg), k0 * fmaf(3.f * k1, x2, 1.f), sg) : x * sg;
+    }
+}
+
+// Sum the four waves' partial tiles acc[8] (feature tile ct, rows on the lanes) through LDS; afterwards wave w holds feature
+// tiles 2w, 2w+1 of all 32 rows: v[c2][4g + i] = element (row lane&31, feature 64w + 32 c2 + 8g + 4 (lane>>5) + i).
+__device__ __forceinline__ void bf_reduce(char* smem, int wave, int lane, const f32x16 (&acc)[BF_CT], float (&v)[2][16]) {
+    f32x4* part = reinterpret_cast<f32x4*>(smem + BF_LDS_PART);
+#pragma unroll
+    for (int ct = 0; ct < BF_CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 t = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
+            part[((wave * BF_CT + ct) * 4 + g) * 64 + lane] = t;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 s = part[((0 * BF_CT + 2 * wave + c2) * 4 + g) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) s += part[((w * BF_CT + 2 * wave + c2) * 4 + g) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[c2][4 * g + i] = s[i];
+        }
+}
+
+// per-row sum over the 256 features of a quantity each wave holds for its 64 features: lanes of both halves return the total
+__device__ __forceinline__ float bf_rowsum(char* smem, int slot, int wave, int lane, float partial) {
+    float* st = reinterpret_cast<float*>(smem + BF_LDS_STAT) + slot * 128;
+    partial += __shfl_xor(partial, 32, 64);
+    if (lane < 32) st[wave * 32 + lane] = partial;
+    __syncthreads();
+    const int m = lane & 31;
+    return st[m] + st[32 + m] + st[64 + m] + st[96 + m];
+}
+
+// [32][256] bf16 tile in LDS: 16-byte chunk ch (0..31) of row m lives at chunk ch ^ (m & 15)
+__device__ __forceinline__ int bf_tile_off(int m, int col) { return m * 512 + ((((col >> 3) ^ (m & 15))) << 4) + ((col & 7) << 1); }
+
+__device__ __forceinline__ void bf_tile_read(const char* smem, int lane, bf16x8 (&f)[BF_KS]) {
+    const int m = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < BF_KS; ++ks)
+        f[ks] = *reinterpret_cast<const bf16x8*>(smem + BF_LDS_TILE + m * 512 + (((2 * ks + h) ^ (m & 15)) << 4));
+}
+
+// accumulator initialised with the 32 bias values of hidden tile ht (register q of lane half h = feature (q&3) + 8 (q>>2) + 4 h)
+__device__ __forceinline__ f32x16 bf_bias_init(const float* b1s, int ht, int h) {
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + 32 * ht + 8 * g + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * g + i] = bb[i];
+    }
+    return acc;
+}
+
+struct TailFwd {
+    int M;
+    const bf16_t* o; int ldo;
+    const bf16_t* x0;
+    const bf16x8* Wst; int wave_frags;
+    const float* bo;
+    bf16_t* x1;
+    const float* gamma; const float* beta; float eps;
+    const float* b1; int F;
+    const float* b2;
+    bf16_t* z;
+    float* mean; float* rstd;
+    bf16_t* out;
+};
+
+// W2 product of one hidden tile: z (accumulator layout, bias included) -> save, GELU, pack -> acc2 += W2 fragments (ring slots
+// S0 .. S0+15, order [s][ct]) . h;  RELOAD: re-request the 16 slots for stream positions +32 (nx points at this product's
+// first fragment + 32)
+template <int ACT, int S0, bool RELOAD>
+__device__ __forceinline__ void bf_ffn_second(bf16x8 (&ring)[BF_RING], const bf16x8* nx, const f32x16& z, f32x16 (&acc2)[BF_CT], bf16x8* zdst) {
+    bf16x8 hb[2], zs[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        zs[i >> 3][i & 7] = (bf16_t)z[i];
+        hb[i >> 3][i & 7] = (bf16_t)bf_gelu<ACT, false>(z[i]);
+    }
+    if (zdst != nullptr) {
+        zdst[0] = zs[0];
+        zdst[1] = zs[1];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int ct = 0; ct < BF_CT; ++ct) {
+            acc2[ct] = mfma32(ring[S0 + s2 * 8 + ct], hb[s2], acc2[ct]);
+            if (RELOAD) ring[S0 + s2 * 8 + ct] = nx[(s2 * 8 + ct) * 64];
+        }
+}
+
+// AR = rounds of 32 fragments in the output projection's stream (DI / 256; 0 = no projection, x1 is the input)
+template <int ACT, int AR>
+__global__ __launch_bounds__(256, 1) void block_tail_fwd_kernel(TailFwd a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BF_ROWS;
+    const int row = min(m0 + m, a.M - 1);              // clamped for loads; stores are predicated on rvalid
+    const bool rvalid = m0 + m < a.M;
+    BF_STAMP(0);
+
+    // ---- loads in the order they are needed (vmcnt retires in order): activations, small parameters (-> LDS), then the ring
+    bf16x8 of[AR > 0 ? 4 * AR : 1];
+    bf16x4 xb[2][4];                                   // this wave's 64 features of x0, later of x1 (as stored: bf16)
+    if (AR > 0) {
+        const bf16_t* op = a.o + (size_t)row * a.ldo + wave * (64 * AR) + 8 * h;
+#pragma unroll
+        for (int k = 0; k < 4 * AR; ++k) of[k] = *reinterpret_cast<const bf16x8*>(op + 16 * k);
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            xb[c2][g] = *reinterpret_cast<const bf16x4*>((AR > 0 ? a.x0 : a.x1) + (size_t)row * BF_D + 64 * wave + 32 * c2 + 8 * g + 4 * h);
+    {
+        f32x4* par = reinterpret_cast<f32x4*>(smem + BF_LDS_PAR);
+        const int i = threadIdx.x & 63;                // wave w stages parameter w: 256 floats = 64 x 16 B
+        const float* srcp = wave == 0 ? a.bo : wave == 1 ? a.gamma : wave == 2 ? a.beta : a.b2;
+        if (srcp != nullptr) par[wave * 64 + i] = reinterpret_cast<const f32x4*>(srcp)[i];
+        for (int k = threadIdx.x; k < a.F / 4; k += 256)
+            reinterpret_cast<f32x4*>(smem + BF_LDS_BIAS)[k] = reinterpret_cast<const f32x4*>(a.b1)[k];
+    }
+    // the wave's weight stream: fill the ring, `nx` = address of stream position (next to consume) + 32
+    const bf16x8* nx = a.Wst + (size_t)wave * a.wave_frags * 64 + lane;
+    bf16x8 ring[BF_RING];
+#pragma unroll
+    for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
+    nx += BF_RING * 64;
+    const float* pbo = reinterpret_cast<const float*>(smem + BF_LDS_PAR), *pgam = pbo + BF_D, *pbet = pbo + 2 * BF_D, *pb2 = pbo + 3 * BF_D;
+
+    if (AR > 0) {
+        // ---- x1 = x0 + o Wo^T + bo: wave w reduces over input features [w*DI/4, (w+1)*DI/4); stream order [ks][ct]
+        f32x16 acc[BF_CT];
+#pragma unroll
+        for (int ct = 0; ct < BF_CT; ++ct) acc[ct] = zero16();
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+#pragma unroll
+            for (int j = 0; j < BF_RING; ++j) {
+                acc[j & 7] = mfma32(ring[j], of[4 * r + (j >> 3)], acc[j & 7]);
+                ring[j] = nx[j * 64];
+            }
+            nx += BF_RING * 64;
+        }
+        BF_STAMP(1);
+        float v[2][16];
+        bf_reduce(smem, wave, lane, acc, v);
+        BF_STAMP(2);
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 64 * wave + 32 * c2 + 8 * g + 4 * h;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(pbo + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xb[c2][g][i] = (bf16_t)(v[c2][4 * g + i] + bb[i] + (float)xb[c2][g][i]);
+                if (rvalid) *reinterpret_cast<bf16x4*>(a.x1 + (size_t)row * BF_D + c) = xb[c2][g];
+            }
+    } else {
+        __syncthreads();                               // (the staged parameters)
+    }
+    BF_STAMP(3);
+    // ---- LayerNorm (two-pass fp32 statistics, like ln_fwd_kernel) -> y tile in LDS -> every wave's B fragments
+    float s = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += (float)xb[c2][g][i];
+    const float mean = bf_rowsum(smem, 0, wave, lane, s) * (1.f / BF_D);
+    s = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float d = (float)xb[c2][g][i] - mean; s += d * d; }
+    const float rstd = rsqrtf(bf_rowsum(smem, 1, wave, lane, s) * (1.f / BF_D) + a.eps);
+    if (wave == 0 && lane < 32 && rvalid) { a.mean[row] = mean; a.rstd[row] = rstd; }
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 64 * wave + 32 * c2 + 8 * g + 4 * h;
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(pgam + c);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(pbet + c);
+            bf16x4 y;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = (bf16_t)(((float)xb[c2][g][i] - mean) * rstd * gg[i] + be[i]);
+            *reinterpret_cast<bf16x4*>(smem + BF_LDS_TILE + bf_tile_off(m, c)) = y;
+        }
+    __syncthreads();
+    bf16x8 yf[BF_KS];
+    bf_tile_read(smem, lane, yf);
+    BF_STAMP(4);
+
+    // ---- feed-forward: wave w owns hidden tiles [w*F/128, (w+1)*F/128); acc2 = its share of W2 act(.)
+    // stream: W1(0), then per tile t: W1(t+1) (slots 16..31), W2(t) (slots 0..15); the last tile's W2 sits in slots 16..31.
+    // The W1 product of tile t+1 (matrix core) is issued in front of the GELU of tile t (VALU): one wave per SIMD has nobody
+    // else to overlap them with.
+    const int ntw = a.F / 128;
+    const int ht0 = wave * ntw;
+    const float* b1s = reinterpret_cast<const float*>(smem + BF_LDS_BIAS);
+    f32x16 acc2[BF_CT];
+#pragma unroll
+    for (int ct = 0; ct < BF_CT; ++ct) acc2[ct] = zero16();
+    f32x16 acc1 = bf_bias_init(b1s, ht0, h);
+#pragma unroll
+    for (int ks = 0; ks < BF_KS; ++ks) {
+        acc1 = mfma32(ring[ks], yf[ks], acc1);
+        ring[ks] = nx[ks * 64];
+    }
+    nx += BF_KS * 64;
+    bf16x8* zp = a.z == nullptr ? nullptr : reinterpret_cast<bf16x8*>(a.z) + ((size_t)(blockIdx.x * (a.F / 32) + ht0) * 64 + lane) * 2;
+    BF_STAMP(5);
+    for (int t = 0; t + 1 < ntw; ++t) {
+        BF_STAMP(8 + t);
+        const f32x16 z = acc1;
+        acc1 = bf_bias_init(b1s, ht0 + t + 1, h);
+#pragma unroll
+        for (int ks = 0; ks < BF_KS; ++ks) {
+            acc1 = mfma32(ring[16 + ks], yf[ks], acc1);
+            ring[16 + ks] = nx[ks * 64];
+        }
+        bf_ffn_second<ACT, 0, true>(ring, nx + 16 * 64, z, acc2, zp == nullptr ? nullptr : zp + (size_t)t * 128);
+        nx += BF_RING * 64;
+    }
+    BF_STAMP(8 + ntw - 1);
+    bf_ffn_second<ACT, 16, false>(ring, nx, acc1, acc2, zp == nullptr ? nullptr : zp + (size_t)(ntw - 1) * 128);
+    float v[2][16];
+    BF_STAMP(6);
+    __syncthreads();                                   // (the y tile / statistics reads are done before `part` is rewritten)
+    bf_reduce(smem, wave, lane, acc2, v);
+    BF_STAMP(7);
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 64 * wave + 32 * c2 + 8 * g + 4 * h;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(pb2 + c);
+            bf16x4 yo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yo[i] = (bf16_t)(v[c2][4 * g + i] + bb[i] + (float)xb[c2][g][i]);
+            if (rvalid) *reinterpret_cast<bf16x4*>(a.out + (size_t)row * BF_D + c) = yo;
+        }
+}
+
+struct TailBwd {
+    int M;
+    const bf16_t* x1; const bf16_t* dy;
+    const float* gamma; const float* mean; const float* rstd;
+    const bf16_t* z;
+    const bf16x8* Wst; int wave_frags; int F;
+    bf16_t* dx1;
+    bf16_t* dout; int lddo;
+};
+
+// W1^T product of one hidden tile: g = W2^T dy (accumulator layout), zs = the tile's saved pre-activations -> dz = g act'(z),
+// packed -> accd += W1^T fragments (ring slots S0 .. S0+15, order [s][dt]) . dz
+template <int ACT, int S0, bool RELOAD>
+__device__ __forceinline__ void bf_ffn_second_bwd(bf16x8 (&ring)[BF_RING], const bf16x8* nx, const f32x16& g, const bf16x8 (&zs)[2], f32x16 (&accd)[BF_CT]) {
+    bf16x8 hb[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hb[i >> 3][i & 7] = (bf16_t)(g[i] * bf_gelu<ACT, true>((float)zs[i >> 3][i & 7]));
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int ct = 0; ct < BF_CT; ++ct) {
+            accd[ct] = mfma32(ring[S0 + s2 * 8 + ct], hb[s2], accd[ct]);
+            if (RELOAD) ring[S0 + s2 * 8 + ct] = nx[(s2 * 8 + ct) * 64];
+        }
+}
+
+// CR = rounds of 32 fragments in the output projection's dgrad stream (DI / 256; 0 = none)
+template <int ACT, int CR>
+__global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BF_ROWS;
+    const int row = min(m0 + m, a.M - 1);
+    const bool rvalid = m0 + m < a.M;
+
+    // ---- loads in the order they are needed (vmcnt retires in order): dy fragments, the first tile's pre-activations, the
+    // LayerNorm backward's operands (used at the end: requested now so that they never queue behind the ring), then the ring
+    // dy as B fragments (natural k order): lane (m, h) holds dy[row][16 ks + 8 h .. + 7]
+    bf16x8 dyf[BF_KS];
+#pragma unroll
+    for (int ks = 0; ks < BF_KS; ++ks) dyf[ks] = *reinterpret_cast<const bf16x8*>(a.dy + (size_t)row * BF_D + 16 * ks + 8 * h);
+    const int ntw = a.F / 128;
+    const bf16x8* zp = reinterpret_cast<const bf16x8*>(a.z) + ((size_t)(blockIdx.x * (a.F / 32) + wave * ntw) * 64 + lane) * 2;
+    bf16x8 zs[2] = {zp[0], zp[1]};
+    bf16x4 xr[2][4], dr[2][4];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 64 * wave + 32 * c2 + 8 * g + 4 * h;
+            xr[c2][g] = *reinterpret_cast<const bf16x4*>(a.x1 + (size_t)row * BF_D + c);
+            dr[c2][g] = *reinterpret_cast<const bf16x4*>(a.dy + (size_t)row * BF_D + c);
+        }
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    if (wave == 0) reinterpret_cast<f32x4*>(smem + BF_LDS_PAR)[lane] = reinterpret_cast<const f32x4*>(a.gamma)[lane];
+    const float* pgam = reinterpret_cast<const float*>(smem + BF_LDS_PAR);
+    const bf16x8* nx = a.Wst + (size_t)wave * a.wave_frags * 64 + lane;
+    bf16x8 ring[BF_RING];
+#pragma unroll
+    for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
+    nx += BF_RING * 64;
+
+    // stream: W2^T(0), then per tile t: W2^T(t+1) (slots 16..31), W1^T(t) (slots 0..15); the last tile's W1^T in slots 16..31;
+    // then the output projection's dgrad (CR rounds of 32)
+    f32x16 accd[BF_CT];
+#pragma unroll
+    for (int ct = 0; ct < BF_CT; ++ct) accd[ct] = zero16();
+    f32x16 accg = zero16();
+#pragma unroll
+    for (int ks = 0; ks < BF_KS; ++ks) {
+        accg = mfma32(ring[ks], dyf[ks], accg);
+        ring[ks] = nx[ks * 64];
+    }
+    nx += BF_KS * 64;
+    for (int t = 0; t + 1 < ntw; ++t) {
+        const f32x16 g = accg;
+        const bf16x8 zc[2] = {zs[0], zs[1]};
+        zs[0] = zp[(size_t)(t + 1) * 128];
+        zs[1] = zp[(size_t)(t + 1) * 128 + 1];
+        accg = zero16();
+#pragma unroll
+        for (int ks = 0; ks < BF_KS; ++ks) {
+            accg = mfma32(ring[16 + ks], dyf[ks], accg);
+            ring[16 + ks] = nx[ks * 64];
+        }
+        bf_ffn_second_bwd<ACT, 0, true>(ring, nx + 16 * 64, g, zc, accd);
+        nx += BF_RING * 64;
+    }
+    bf_ffn_second_bwd<ACT, 16, (CR > 0)>(ring, nx, accg, zs, accd);
+    nx += 16 * 64;
+    float v[2][16];
+    bf_reduce(smem, wave, lane, accd, v);              // v = dL/dy_norm for this wave's 64 features
+    // ---- LayerNorm backward + residual branch: dx1 = dy + rstd (g.v - mean_c(g.v) - xhat mean_c(g.v.xhat))
+    float xh[2][16], gv[2][16];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(pgam + 64 * wave + 32 * c2 + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * g + i;
+                xh[c2][e] = ((float)xr[c2][g][i] - mean) * rstd;
+                gv[c2][e] = gg[i] * v[c2][e];
+                s1 += gv[c2][e];
+                s2 += gv[c2][e] * xh[c2][e];
+            }
+        }
+    const float m1 = bf_rowsum(smem, 0, wave, lane, s1) * (1.f / BF_D);
+    const float m2 = bf_rowsum(smem, 1, wave, lane, s2) * (1.f / BF_D);
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 64 * wave + 32 * c2 + 8 * g + 4 * h;
+            bf16x4 dx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * g + i;
+                dx[i] = (bf16_t)((float)dr[c2][g][i] + rstd * (gv[c2][e] - m1 - xh[c2][e] * m2));
+            }
+            if (rvalid) *reinterpret_cast<bf16x4*>(a.dx1 + (size_t)row * BF_D + c) = dx;
+            if (CR > 0) *reinterpret_cast<bf16x4*>(smem + BF_LDS_TILE + bf_tile_off(m, c)) = dx;
+        }
+    if (CR == 0) return;
+    __syncthreads();
+    // ---- do = dx1 Wo: wave w owns output features [w*DI/4, (w+1)*DI/4): 2 feature tiles per round, stream order [ks][f2]
+    bf16x8 dxf[BF_KS];
+    bf_tile_read(smem, lane, dxf);
+#pragma unroll
+    for (int r = 0; r < CR; ++r) {
+        f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int j = 0; j < BF_RING; ++j) {
+            acc[j & 1] = mfma32(ring[j], dxf[j >> 1], acc[j & 1]);
+            if (r + 1 < CR) ring[j] = nx[j * 64];
+        }
+        nx += BF_RING * 64;
+        if (rvalid) {
+#pragma unroll
+            for (int f2 = 0; f2 < 2; ++f2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 d;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d[i] = (bf16_t)acc[f2][4 * g + i];
+                    *reinterpret_cast<bf16x4*>(a.dout + (size_t)row * a.lddo + 32 * (wave * 2 * CR + 2 * r + f2) + 8 * g + 4 * h) = d;
+                }
+        }
+    }
+}
+
+template <typename K>
+static int bf_prepare(K kernel) {
+    // (cheap and idempotent; called per launch so that every instantiation gets its LDS size without a registry)
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_TOTAL) != hipSuccess) {
+        cvft_set_error("block_fused: cannot reserve %d bytes of LDS", BF_LDS_TOTAL);
+        return -2;
+    }
+    return 0;
+}
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int ACT, int AR>
+static int launch_fwd(const TailFwd& a, hipStream_t st) {
+    static int ready = 0;
+    if (!ready) { if (bf_prepare(block_tail_fwd_kernel<ACT, AR>)) return -2; ready = 1; }
+    hipLaunchKernelGGL((block_tail_fwd_kernel<ACT, AR>), dim3((a.M + BF_ROWS - 1) / BF_ROWS), dim3(256), BF_LDS_TOTAL, st, a);
+    return 0;
+}
+template <int ACT, int CR>
+static int launch_bwd(const TailBwd& a, hipStream_t st) {
+    static int ready = 0;
+    if (!ready) { if (bf_prepare(block_tail_bwd_kernel<ACT, CR>)) return -2; ready = 1; }
+    hipLaunchKernelGGL((block_tail_bwd_kernel<ACT, CR>), dim3((a.M + BF_ROWS - 1) / BF_ROWS), dim3(256), BF_LDS_TOTAL, st, a);
+    return 0;
+}
+
+extern "C" int cvft_block_tail_fwd(const cvft_block_tail_args* p, void* stream) {
+    CVFT_CHECK_ARG(p && p->M > 0 && p->F > 0 && p->F % 128 == 0 && p->F <= BF_MAX_F, "cvft_block_tail_fwd: need M > 0, F %% 128 == 0, F <= 2048 (F=%d)", p ? p->F : -1);
+    CVFT_CHECK_ARG(p->x1 && p->out && p->W_fwd && p->b1 && p->b2 && p->gamma && p->beta && p->mean && p->rstd, "cvft_block_tail_fwd: null operand");
+    CVFT_CHECK_ARG(p->act == CVFT_ACT_GELU_ERF || p->act == CVFT_ACT_GELU_TANH, "cvft_block_tail_fwd: act must be a GELU form");
+    const int DI = p->o ? p->DI : 0;
+    if (p->o) CVFT_CHECK_ARG(p->x0 && p->bo && (DI == 256 || DI == 512) && p->ldo % 8 == 0 && al16(p->o),
+                             "cvft_block_tail_fwd: output projection needs x0, bo, DI in {256, 512}, 16-byte aligned o rows");
+    CVFT_CHECK_ARG(al16(p->x1) && al16(p->out) && al16(p->W_fwd) && al16(p->b1) && al16(p->b2) && al16(p->gamma) && al16(p->beta) &&
+                   (!p->z || al16(p->z)) && (!p->x0 || al16(p->x0)) && (!p->bo || al16(p->bo)), "cvft_block_tail_fwd: operands must be 16-byte aligned");
+    TailFwd a;
+    a.M = p->M; a.o = (const bf16_t*)p->o; a.ldo = p->ldo; a.x0 = (const bf16_t*)p->x0;
+    a.Wst = (const bf16x8*)p->W_fwd; a.wave_frags = DI / 8 + p->F / 4; a.bo = p->bo; a.x1 = (bf16_t*)p->x1;
+    a.gamma = p->gamma; a.beta = p->beta; a.eps = p->eps; a.b1 = p->b1; a.F = p->F; a.b2 = p->b2;
+    a.z = (bf16_t*)p->z; a.mean = p->mean; a.rstd = p->rstd; a.out = (bf16_t*)p->out;
+    const bool erf = p->act == CVFT_ACT_GELU_ERF;
+    int rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (DI == 0) rc = erf ? launch_fwd<CVFT_ACT_GELU_ERF, 0>(a, st) : launch_fwd<CVFT_ACT_GELU_TANH, 0>(a, st);
+    else if (DI == 256) rc = erf ? launch_fwd<CVFT_ACT_GELU_ERF, 1>(a, st) : launch_fwd<CVFT_ACT_GELU_TANH, 1>(a, st);
+    else rc = erf ? launch_fwd<CVFT_ACT_GELU_ERF, 2>(a, st) : launch_fwd<CVFT_ACT_GELU_TANH, 2>(a, st);
+    if (rc) return rc;
+    CVFT_LAUNCH_CHECK("cvft_block_tail_fwd");
+    return 0;
+}
+
+extern "C" int cvft_block_tail_bwd(const cvft_block_tail_bwd_args* p, void* stream) {
+    CVFT_CHECK_ARG(p && p->M > 0 && p->F > 0 && p->F % 128 == 0 && p->F <= BF_MAX_F, "cvft_block_tail_bwd: need M > 0, F %% 128 == 0, F <= 2048");
+    CVFT_CHECK_ARG(p->x1 && p->dy && p->gamma && p->mean && p->rstd && p->z && p->W_bwd && p->dx1, "cvft_block_tail_bwd: null operand");
+    CVFT_CHECK_ARG(p->act == CVFT_ACT_GELU_ERF || p->act == CVFT_ACT_GELU_TANH, "cvft_block_tail_bwd: act must be a GELU form");
+    const int DI = p->dout ? p->DI : 0;
+    if (p->dout) CVFT_CHECK_ARG((DI == 256 || DI == 512) && p->lddo % 4 == 0 && al16(p->dout), "cvft_block_tail_bwd: output-projection dgrad needs DI in {256, 512}, aligned dout");
+    CVFT_CHECK_ARG(al16(p->x1) && al16(p->dy) && al16(p->gamma) && al16(p->z) && al16(p->W_bwd) && al16(p->dx1), "cvft_block_tail_bwd: operands must be 16-byte aligned");
+    TailBwd a;
+    a.M = p->M; a.x1 = (const bf16_t*)p->x1; a.dy = (const bf16_t*)p->dy; a.gamma = p->gamma; a.mean = p->mean; a.rstd = p->rstd;
+    a.z = (const bf16_t*)p->z; a.Wst = (const bf16x8*)p->W_bwd; a.wave_frags = p->F / 4 + p->DI / 8; a.F = p->F;
+    a.dx1 = (bf16_t*)p->dx1; a.dout = (bf16_t*)p->dout; a.lddo = p->lddo;
+    const bool erf = p->act == CVFT_ACT_GELU_ERF;
+    int rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (DI == 0) rc = erf ? launch_bwd<CVFT_ACT_GELU_ERF, 0>(a, st) : launch_bwd<CVFT_ACT_GELU_TANH, 0>(a, st);
+    else if (DI == 256) rc = erf ? launch_bwd<CVFT_ACT_GELU_ERF, 1>(a, st) : launch_bwd<CVFT_ACT_GELU_TANH, 1>(a, st);
+    else rc = erf ? launch_bwd<CVFT_ACT_GELU_ERF, 2>(a, st) : launch_bwd<CVFT_ACT_GELU_TANH, 2>(a, st);
+    if (rc) return rc;
+    CVFT_LAUNCH_CHECK("cvft_block_tail_bwd");
+    return 0;
+}

@@ -35,6 +35,22 @@ class RankProbM(C.Structure):
                 ("part", C.c_void_p), ("transpose_out", C.c_int), ("rows_per_block", C.c_int)]
 
 
+class BlockTailArgs(C.Structure):
+    """mirror of cvft_block_tail_args (include/cvft.h)"""
+    _fields_ = [("M", C.c_int), ("o", C.c_void_p), ("ldo", C.c_int), ("DI", C.c_int), ("x0", C.c_void_p),
+                ("W_fwd", C.c_void_p), ("bo", C.c_void_p), ("x1", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+                ("b1", C.c_void_p), ("F", C.c_int), ("b2", C.c_void_p),
+                ("act", C.c_int), ("z", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("out", C.c_void_p)]
+
+
+class BlockTailBwdArgs(C.Structure):
+    """mirror of cvft_block_tail_bwd_args (include/cvft.h)"""
+    _fields_ = [("M", C.c_int), ("x1", C.c_void_p), ("dy", C.c_void_p), ("gamma", C.c_void_p), ("mean", C.c_void_p),
+                ("rstd", C.c_void_p), ("z", C.c_void_p), ("W_bwd", C.c_void_p), ("F", C.c_int), ("DI", C.c_int),
+                ("act", C.c_int), ("dx1", C.c_void_p), ("dout", C.c_void_p), ("lddo", C.c_int)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
@@ -111,6 +127,8 @@ SIGNATURES = {
     "cvft_sumsq_ordered": [_i64, _p, _p, _p, _p],
     "cvft_adamw_flat": [_i64, _p, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p, _f, _f, _p],
     "cvft_cast_f32_to_bf16": [_i64, _p, _p, _p],
+    "cvft_block_tail_fwd": [C.POINTER(BlockTailArgs), _p],
+    "cvft_block_tail_bwd": [C.POINTER(BlockTailBwdArgs), _p],
 }
 
 _lib: Optional[C.CDLL] = None

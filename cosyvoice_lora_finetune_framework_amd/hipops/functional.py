@@ -1312,6 +1312,75 @@ def lora_feed_forward(x, pack1, pack2, lora1=(None, None), lora2=(None, None), s
 
 
 # ---------------------------------------------------------------------------------
+# estimator transformer block as row-tile chain kernels (csrc/block_fused.hip)
+# ---------------------------------------------------------------------------------
+class BlockTailFn(torch.autograd.Function):
+    """out = x1 + W2 gelu(W1 LN(x1) + b1) + b2 with x1 = x0 + o Wo^T + bo (o given) or x1 = x0 (o None): the second half of a
+    BasicTransformerBlock (matcha transformer.py:290-316 == modules.py:362-375) as ONE launch each way.  No LoRA on to_out /
+    ff.net.* in the flow target list (config.py), so backward is input gradients only."""
+
+    @staticmethod
+    def forward(ctx, o, x0, pack, act: str):
+        x0 = _c(x0)
+        M = x0.shape[0]
+        a = cb.BlockTailArgs()
+        a.M = M
+        x1 = x0
+        assert (o is not None) == (pack.DI > 0), "BlockTailPack built with / without to_out must match the call"
+        a.DI, a.W_fwd = pack.DI, ptr(pack.W_fwd)
+        if o is not None:
+            assert o.shape == (M, pack.DI) and o.stride(1) == 1
+            x1 = torch.empty_like(x0)
+            a.o, a.ldo, a.x0, a.bo = ptr(o), o.stride(0), ptr(x0), ptr(pack.bo)
+        need = (o is not None and ctx.needs_input_grad[0]) or ctx.needs_input_grad[1]
+        out = torch.empty_like(x0)
+        mean = torch.empty(M, dtype=torch.float32, device=x0.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x0.device)
+        z = torch.empty(-(-M // 32) * 32 * pack.F, dtype=x0.dtype, device=x0.device) if need else None
+        a.x1, a.gamma, a.beta, a.eps = ptr(x1), ptr(pack.gamma), ptr(pack.beta), pack.eps
+        a.b1, a.F, a.b2, a.act = ptr(pack.b1), pack.F, ptr(pack.b2), ACT[act]
+        a.z, a.mean, a.rstd, a.out = ptr(z), ptr(mean), ptr(rstd), ptr(out)
+        with _Bracket("block_tail_fwd", 2.0 * M * 256 * (2 * pack.F + (pack.DI if o is not None else 0)),
+                      2.0 * (M * (3 * 256 + pack.DI) + 256 * (2 * pack.F + pack.DI))):
+            check(lib().cvft_block_tail_fwd(C.byref(a), stream()), "cvft_block_tail_fwd")
+        ctx.save_for_backward(x1, z, mean, rstd)
+        ctx.pack, ctx.act, ctx.has_o = pack, act, o is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, z, mean, rstd = ctx.saved_tensors
+        pack = ctx.pack
+        dy = _c(dy)
+        M = x1.shape[0]
+        a = cb.BlockTailBwdArgs()
+        dx1 = torch.empty_like(x1)
+        do = None
+        a.M, a.x1, a.dy, a.gamma, a.mean, a.rstd, a.z = M, ptr(x1), ptr(dy), ptr(pack.gamma), ptr(mean), ptr(rstd), ptr(z)
+        a.W_bwd, a.F, a.DI, a.act, a.dx1 = ptr(pack.W_bwd), pack.F, pack.DI, ACT[ctx.act], ptr(dx1)
+        if ctx.has_o and ctx.needs_input_grad[0]:
+            do = torch.empty((M, pack.DI), dtype=x1.dtype, device=x1.device)
+            a.dout, a.lddo = ptr(do), do.stride(0)
+        with _Bracket("block_tail_bwd", 2.0 * M * 256 * (2 * pack.F + (pack.DI if do is not None else 0)),
+                      2.0 * (M * (3 * 256 + pack.F + pack.DI) + 256 * (2 * pack.F + pack.DI))):
+            check(lib().cvft_block_tail_bwd(C.byref(a), stream()), "cvft_block_tail_bwd")
+        return do, dx1, None, None
+
+
+def block_tail(o, x0, pack, act: str = "gelu_erf"):
+    """x0 [M, 256] bf16 residual stream, o [M, DI] attention output (or None: feed-forward half only)."""
+    return BlockTailFn.apply(o, x0, pack, act)
+
+
+def can_block_tail(x: torch.Tensor, d_ff: int, d_inner: int) -> bool:
+    return (BLOCK_FUSE and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and d_ff % 128 == 0
+            and d_ff <= 2048 and d_inner in (256, 512))
+
+
+BLOCK_FUSE = _os.environ.get("CVFT_BLOCK_FUSE", "1") != "0"
+
+
+# ---------------------------------------------------------------------------------
 # 1-D convolutions as tap-GEMMs (frozen weights, no LoRA)
 # ---------------------------------------------------------------------------------
 class ConvPack:

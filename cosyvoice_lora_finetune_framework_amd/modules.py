@@ -332,9 +332,35 @@ class BasicTransformerBlock(nn.Module):
         x, y = hip_layernorm_fork(self.norm1, x, consumers=(a.to_q, a.to_k, a.to_v))
         q, k, v = hip_qkv(a.to_q, a.to_k, a.to_v, y)
         o = HF.attn_bias(q, k, v, B, a.heads, T, length, a.scale, iso_len)
-        x = hip_linear(a.to_out[0], o, residual=x)
-        x, y = hip_layernorm_fork(self.norm3, x)
+        return self._tail(o, x, gelu)
+
+    def _tail_pack(self):
+        """Packed frozen weights of the block's second half for the row-tile chain kernels, or None when a layer of it carries
+        an adapter / trains (the flow target list has none on to_out / ff.net.*: config.py FLOW LoRA target_modules)."""
+        to_out, ln, w1, w2 = self.attn1.to_out[0], self.norm3, self.ff.net[0].proj, self.ff.net[2]
+        if not all(type(m) is nn.Linear for m in (to_out, w1, w2)):
+            return None
+        ps = [to_out.weight, to_out.bias, ln.weight, ln.bias, w1.weight, w1.bias, w2.weight, w2.bias]
+        if any(p is not None and p.requires_grad for p in ps) or self.ff.net[1].p > 0 or self.attn1.to_out[1].p > 0:
+            return None
+        tag = tuple((p._version, p.data_ptr()) for p in ps if p is not None)
+        hit = self.__dict__.get("_cvft_tail")
+        if hit is None or hit[0] != tag:
+            from .hipops.blockpack import BlockTailPack
+            hit = (tag, BlockTailPack(to_out.weight, to_out.bias, ln.weight, ln.bias, ln.eps, w1.weight, w1.bias, w2.weight, w2.bias))
+            self.__dict__["_cvft_tail"] = hit
+        return hit[1]
+
+    def _tail(self, o, x, gelu: str):
+        """x + to_out(o), then + ff(norm3(.)): one row-tile chain launch each way (HF.block_tail) on the bf16 path, else
+        the launch-per-stage form (GEMM, LayerNorm, two GEMMs)."""
         act = "gelu_tanh" if self.ff.net[0].approximate == "tanh" else gelu
+        if HF.can_block_tail(x, self.ff.net[0].proj.out_features, self.attn1.to_out[0].in_features) and o.dtype == x.dtype:
+            pack = self._tail_pack()
+            if pack is not None:
+                return HF.block_tail(o, x, pack, act)
+        x = hip_linear(self.attn1.to_out[0], o, residual=x)
+        x, y = hip_layernorm_fork(self.norm3, x)
         return hip_ffn(self.ff.net[0].proj, self.ff.net[2], y, act, residual=x)
 
 

@@ -341,6 +341,61 @@ int cvft_adamw_flat(int64_t n, float* p, const float* g, float* m, float* v, con
 /* fp32 -> bf16 cast of a flat buffer */
 int cvft_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Estimator transformer block as row-tile chain kernels (bf16, residual width d = 256).
+ * Replaces, per BasicTransformerBlock (matcha/models/components/transformer.py:243-316 == modules.py:296-375; diffusers
+ * Attention.to_out / FeedForward / GELU), the torch-op sequence
+ *     x1  = x0 + to_out(o)                       (attention output projection + residual)
+ *     out = x1 + ff.net[2](gelu(ff.net[0].proj(norm3(x1))))
+ * and its backward.  The [M, F] hidden activations and LN(x1) stay on chip; the pre-activations go to an opaque workspace z.
+ *
+ * Packed weights (made once per frozen weight by hipops/blockpack.py; element type bf16).  A fragment = what one
+ * v_mfma_f32_32x32x16_bf16 takes as its A operand = 64 lanes x 8 elements = 1 KB, lane l = 32 h + r, element j:
+ *   natural(Wm, rt, ks)[l][j]    = Wm[32 rt + r][16 ks + 8 h + j]
+ *   chained(Wm, rt, kt, s)[l][j] = Wm[32 rt + r][32 kt + 16 s + 8 (j>>2) + 4 h + (j&3)]
+ *               (k order of a bf16-packed 32x32 accumulator tile used as the next product's B operand)
+ * W_fwd / W_bwd are the four waves' weight STREAMS, [4 waves][wave_frags] fragments, each wave's fragments in the order the
+ * wave consumes them (n = F / 128 hidden tiles per wave, ht = n w + t; q = DI / 64 k-steps per wave in the projection):
+ *   W_fwd, wave w:  natural(Wo [256][DI], ct, q w + ks)            for ks < q, ct < 8                (absent when DI == 0)
+ *                   natural(W1 [F][256], ht(0), ks)                for ks < 16
+ *                   for t < n: [ natural(W1, ht(t+1), ks) for ks < 16   (t + 1 < n) ],  chained(W2 [256][F], ct, ht(t), s) for s < 2, ct < 8
+ *                   wave_frags = DI / 8 + F / 4
+ *   W_bwd, wave w:  natural(W2^T [F][256], ht(0), ks)              for ks < 16
+ *                   for t < n: [ natural(W2^T, ht(t+1), ks) for ks < 16 (t + 1 < n) ],  chained(W1^T [256][F], dt, ht(t), s) for s < 2, dt < 8
+ *                   natural(Wo^T [DI][256], (DI/128) w + 2 r + f2, ks)  for r < DI/256, ks < 16, f2 < 2   (absent when DI == 0)
+ *                   wave_frags = F / 4 + DI / 8
+ * z: [ceil(M/32)][F/32][64 lanes][16] bf16 pre-activations (accumulator order of the producing wave; only
+ *    cvft_block_tail_bwd reads it).
+ * M rows, any M > 0; F % 128 == 0, F <= 2048; DI in {0, 256, 512} (the pack's: o != NULL iff DI > 0);
+ * act = CVFT_ACT_GELU_ERF | CVFT_ACT_GELU_TANH; all pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------- */
+typedef struct {
+    int M;
+    const void* o; int ldo; int DI;      /* attention output [M][DI] (row pitch ldo); NULL iff DI == 0: then x1 is an INPUT */
+    const void* x0;                      /* [M][256] residual in front of the attention (DI > 0) */
+    const void* W_fwd;                   /* weight streams (above) */
+    const float* bo;                     /* to_out bias [256] (DI > 0) */
+    void* x1;                            /* [M][256]: written when DI > 0 (saved for backward), read otherwise */
+    const float* gamma; const float* beta; float eps;      /* norm3 */
+    const float* b1; int F;
+    const float* b2;
+    int act;
+    void* z;                             /* pre-activation workspace or NULL (inference) */
+    float* mean; float* rstd;            /* [M] LayerNorm statistics of x1 (saved for backward) */
+    void* out;                           /* [M][256] */
+} cvft_block_tail_args;
+int cvft_block_tail_fwd(const cvft_block_tail_args* a, void* stream);
+typedef struct {
+    int M;
+    const void* x1; const void* dy;      /* [M][256] saved x1; gradient at the block output */
+    const float* gamma; const float* mean; const float* rstd;
+    const void* z;
+    const void* W_bwd; int F; int DI; int act;
+    void* dx1;                           /* [M][256] gradient at x1 (= gradient of x0 through the residual) */
+    void* dout; int lddo;                /* dout [M][DI] = dx1 . to_out.weight, or NULL (not wanted / DI == 0) */
+} cvft_block_tail_bwd_args;
+int cvft_block_tail_bwd(const cvft_block_tail_bwd_args* a, void* stream);
+
 /* Diagnostics (development only): cycle stamps of the default 128x128 LDS-DMA GEMM kernel (CVFT_GLDS_BIG=15 launches its
  * stamped build; tools/glds_stamps.py); host_out receives 256 uint64. */
 int cvft_debug_glds_stamps(unsigned long long* host_out);
