@@ -43,6 +43,36 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0      # HBM3E (same table)
 
 
+# algorithmic work per utterance, forward + backward, 2 x MAC (torch flop counter on the oracle, LoRA r = 16)
+GFLOP_PER_UTT = {500: {"joint": 468.9, "flow_only": 154.08, "llm_only": 314.83},
+                 1000: {"joint": 1015.0, "flow_only": 386.08, "llm_only": 628.94}}
+
+
+def step_record(workload, frames, utt_per_s_per_gpu, dtype):
+    """what north_star grades: the whole step's share of the dense MFMA peak of ONE GPU"""
+    gf = GFLOP_PER_UTT.get(frames, {}).get(workload)
+    if gf is None:
+        return None
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    tf = utt_per_s_per_gpu * gf / 1e3
+    return {"tflops": tf, "frac_of_mfma_peak": tf / peak, "gflop_per_utt": gf, "peak_tflops": peak}
+
+
+def trace_summary(workload, batch, frames):
+    """launches and kernel time per step of this configuration from the committed rocprofv3 kernel trace of the same command
+    (profiles/*step_summary.json, written by tools/prof_summary.py; the trace cannot be taken inside the bench process)"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*step_summary*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("batch") == batch and d.get("frames") == frames:
+            return {"launches_per_step": d["launches_per_step"], "kernel_ms_per_step": d["kernel_ms_per_step"],
+                    "source": os.path.join("profiles", os.path.basename(f))}
+    return None
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -170,6 +200,57 @@ def pmc_mfma_busy(kernel: str):
     return None, None
 
 
+def trainer_run(a, jm, workload, dev, dtype, rank, world, steps, warmup):
+    """The product loop: train_joint.Trainer.fit over W + K fresh synthetic batches; the timed region is bracketed from the
+    trainer's per-step hook (barrier + synchronize on both sides).  Returns (seconds of the K steps, MAX over ranks; loss;
+    graph statistics; the trainer)."""
+    from cosyvoice_lora_finetune_framework_amd import dp
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, SyntheticLoader, Trainer
+    module = JointLightningModule(workload, learning_rate=2e-4, min_lr=1e-6, warmup_steps=10, weight_decay=0.01,
+                                  model=jm, numerics=Numerics(dtype=dtype))
+    # per-rank host budget: the replay thread and the prefetch thread need a core each; torch's intra-op pool gets the rest
+    # of this rank's share of the host (cores // world), so eight ranks do not oversubscribe one host
+    torch.set_num_threads(max(1, min(host_cores() // max(world, 1), 16)))
+    B, T = a.batch, a.frames
+    loader = SyntheticLoader(warmup + steps, B, T, seed=1234, ragged=a.ragged, rank=rank, cache=True)
+    marks = {}
+
+    def hook(tr):
+        if tr.global_step == warmup:
+            dp.barrier()
+            torch.cuda.synchronize()
+            marks["t0"] = time.perf_counter()
+        elif tr.global_step == warmup + steps:
+            torch.cuda.synchronize()
+            dp.barrier()
+            torch.cuda.synchronize()
+            marks["t1"] = time.perf_counter()
+
+    tr = Trainer(max_epochs=1, accumulate_grad_batches=1, gradient_clip_val=1.0, save_checkpoints=False,
+                 log_every_n_steps=0, train_mode=bool(a.dropout), use_graph=bool(a.graph), on_step_end=hook)
+    log(f"[bench] rank {rank}: Trainer.fit [{workload}] ({'hipGraph micro-step' if a.graph else 'eager'}); warm-up {warmup}, timing {steps} steps")
+    with contextlib.redirect_stdout(sys.stderr):
+        tr.fit(module, loader)
+    from cosyvoice_lora_finetune_framework_amd import train_joint as _tj
+    if _tj._TIMING:
+        torch.cuda.synchronize()
+        TL = _tj._TIMING[-10:]
+        cp = sum(e[0].elapsed_time(e[1]) for e in TL) / len(TL)
+        gr = sum(e[1].elapsed_time(e[2]) for e in TL) / len(TL)
+        gap = sum(TL[i][2].elapsed_time(TL[i + 1][0]) for i in range(len(TL) - 1)) / (len(TL) - 1)
+        hc = sum(e[3][1] - e[3][0] for e in TL) / len(TL) * 1e3
+        hr = sum(e[3][2] - e[3][1] for e in TL) / len(TL) * 1e3
+        hg = sum(TL[i + 1][3][0] - TL[i][3][2] for i in range(len(TL) - 1)) / (len(TL) - 1) * 1e3
+        log(f"[bench] trainer host timeline: copies {hc:.2f} ms, replay call {hr:.2f} ms, replay return -> next step's copies {hg:.2f} ms")
+        log(f"[bench] trainer GPU timeline: static copies {cp:.3f} ms, graph {gr:.3f} ms, graph end -> next step's copies {gap:.3f} ms")
+        _tj._TIMING.clear()
+    el = torch.tensor([marks["t1"] - marks["t0"]], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    return float(el), float(tr.callback_metrics.get("train_loss_epoch", float("nan"))), dict(tr.graph_stats), tr
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +268,7 @@ def main():
     ap.add_argument("--ragged", type=int, default=0, help="--via-trainer: 1 = utterance lengths uniform in [0.6 T, T], one utterance keeps T (one batch layout); 2 = none pinned: every batch has its own T_max / Lt_max and the trainer fits it to a captured layout (SHAPE_SLACK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-branches", action="store_true", help="skip the llm_only / flow_only legs of roofline.branches (joint, N = 1)")
     a = ap.parse_args()
 
     from cosyvoice_lora_finetune_framework_amd import dp
@@ -217,54 +299,11 @@ def main():
     static_loss = None
     trainer_stats = None
     if a.via_trainer:
-        # the product loop: train_joint.Trainer.fit over W + K fresh synthetic batches; the timed region is bracketed
-        # from the trainer's per-step hook (barrier + synchronize on both sides, like the direct mode below)
-        from cosyvoice_lora_finetune_framework_amd.modules import Numerics
-        from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, SyntheticLoader, Trainer
         if a.warmup < 1:
             log("[bench] --via-trainer captures the batch layout in its first step: raising --warmup to 1")
             a.warmup = 1
-        module = JointLightningModule(a.workload, learning_rate=2e-4, min_lr=1e-6, warmup_steps=10, weight_decay=0.01,
-                                      model=jm, numerics=Numerics(dtype=dtype))
-        torch.set_num_threads(min(host_cores(), 16))
-        loader = SyntheticLoader(a.warmup + a.steps, B, T, seed=1234, ragged=a.ragged, rank=rank, cache=True)
-        marks = {}
-
-        def hook(tr):
-            if tr.global_step == a.warmup:
-                dp.barrier()
-                torch.cuda.synchronize()
-                marks["t0"] = time.perf_counter()
-            elif tr.global_step == a.warmup + a.steps:
-                torch.cuda.synchronize()
-                dp.barrier()
-                torch.cuda.synchronize()
-                marks["t1"] = time.perf_counter()
-
-        tr = Trainer(max_epochs=1, accumulate_grad_batches=1, gradient_clip_val=1.0, save_checkpoints=False,
-                     log_every_n_steps=0, train_mode=bool(a.dropout), use_graph=bool(a.graph), on_step_end=hook)
-        log(f"[bench] rank {rank}: Trainer.fit ({'hipGraph micro-step' if a.graph else 'eager'}); warm-up {a.warmup}, timing {a.steps} steps")
-        with contextlib.redirect_stdout(sys.stderr):
-            tr.fit(module, loader)
+        elapsed, final_loss, trainer_stats, tr = trainer_run(a, jm, a.workload, dev, dtype, rank, world, a.steps, a.warmup)
         opt = tr.optimizer
-        trainer_stats = dict(tr.graph_stats)
-        from cosyvoice_lora_finetune_framework_amd import train_joint as _tj
-        if _tj._TIMING:
-            torch.cuda.synchronize()
-            TL = _tj._TIMING[-10:]
-            cp = sum(e[0].elapsed_time(e[1]) for e in TL) / len(TL)
-            gr = sum(e[1].elapsed_time(e[2]) for e in TL) / len(TL)
-            gap = sum(TL[i][2].elapsed_time(TL[i + 1][0]) for i in range(len(TL) - 1)) / (len(TL) - 1)
-            hc = sum(e[3][1] - e[3][0] for e in TL) / len(TL) * 1e3
-            hr = sum(e[3][2] - e[3][1] for e in TL) / len(TL) * 1e3
-            hg = sum(TL[i + 1][3][0] - TL[i][3][2] for i in range(len(TL) - 1)) / (len(TL) - 1) * 1e3
-            log(f"[bench] trainer host timeline: copies {hc:.2f} ms, replay call {hr:.2f} ms, replay return -> next step's copies {hg:.2f} ms")
-            log(f"[bench] trainer GPU timeline: static copies {cp:.3f} ms, graph {gr:.3f} ms, graph end -> next step's copies {gap:.3f} ms")
-        el = torch.tensor([marks["t1"] - marks["t0"]], device=dev)
-        if world > 1:
-            torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(el)
-        final_loss = float(tr.callback_metrics.get("train_loss_epoch", float("nan")))
         graph = True if (a.graph and trainer_stats["replays"] > 0) else None
     elif a.graph:
         try:
@@ -327,6 +366,7 @@ def main():
             hs.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
         log(f"[bench] idle-GPU replay: host call {min(hs):.2f} ms, to completion {min(tot):.2f} ms")
     roof = None
+    cabi_calls = None
     if rank == 0 and not a.no_roofline:              # (the instrumented step has no collective in it: rank 0 alone runs it)
         # event-instrumented eager step: every tap-GEMM launch bracketed by HIP events on the launch stream
         # An event pair costs time of its own (two timestamp packets on the queue): the empty bracket is measured here and
@@ -350,9 +390,12 @@ def main():
         branch_streams, J.BRANCH_STREAMS = J.BRANCH_STREAMS, False
         HF.PROFILE = []
         torch.cuda.synchronize()
+        from cosyvoice_lora_finetune_framework_amd.hipops import binding as _cb
+        c_before = _cb.CALLS
         h0 = time.perf_counter()
         fwd_bwd()                                   # pass 1: host enqueue time of the instrumented step (records dropped)
         host_ms = (time.perf_counter() - h0) * 1e3
+        cabi_calls = _cb.CALLS - c_before           # libcvft entry-point calls of one forward + backward (one chain per branch)
         opt.zero_grad()
         torch.cuda.synchronize()
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -410,6 +453,25 @@ def main():
                                              "avg_us": v["ms"] * 1e3 / v["n"], "n": v["n"]}
                                          for k, v in groups.items() if k.startswith("attn_")}
 
+    # what north_star grades: whole-step share of the bf16 MFMA peak, per branch too (single-branch legs through the same trainer)
+    if roof is not None:
+        roof["step"] = step_record(a.workload, T, B * a.steps / elapsed, a.dtype)
+        if roof["step"] is not None:
+            roof["step"]["cabi_calls_per_step"] = cabi_calls
+            ts = trace_summary(a.workload, B, T)
+            roof["step"].update(ts or {"launches_per_step": None, "kernel_ms_per_step": None, "source": None})
+        if a.workload == "joint" and world == 1 and a.via_trainer and not a.no_branches:
+            roof["branches"] = {}
+            for wl in ("llm_only", "flow_only"):
+                try:
+                    jb = build(wl, dtype, dev, a.rank_lora, 2 * a.rank_lora, a.dropout)
+                    el_b, _, _, trb = trainer_run(a, jb, wl, dev, dtype, rank, world, 10, 3)
+                    rec = step_record(wl, T, B * 10 / el_b, a.dtype) or {}
+                    roof["branches"][wl] = dict(ms_per_step=el_b / 10 * 1e3, utt_per_s=B * 10 / el_b, **rec)
+                    del jb, trb
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    log(f"[bench] branch leg {wl} failed: {type(e).__name__}: {e}")
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:

@@ -807,7 +807,7 @@ extern "C" int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* 
                                     const int32_t* len, int causal, float scale, void* o, int ldo, float* lse,
                                     float drop_p, const int64_t* drop_seed, unsigned drop_site, void* stream) {
     if (check_common("cvft_attn_relpos_fwd", dtype, B, H, L, ld, ldo, q, k, v)) return -1;
-    CVFT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || drop_seed), "cvft_attn_relpos_fwd: bad dropout args");
+    CVFT_CHECK_ARG(cvft_drop_rate_ok(drop_p) && (drop_p == 0.f || drop_seed), "cvft_attn_relpos_fwd: bad dropout args (p == 0 or 2^-16 <= p <= 1 - 2^-16, seed)");
     int vec = dtype == CVFT_BF16 ? 8 : 4;
     CVFT_CHECK_ARG(pp && bias_u && bias_v && o && lse && ldp >= H * 64 && ldp % vec == 0 && (((uintptr_t)pp) & 15) == 0,
                    "cvft_attn_relpos_fwd: bad args");
@@ -831,7 +831,7 @@ extern "C" int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* 
                                     const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg, float* dp,
                                     float drop_p, const int64_t* drop_seed, unsigned drop_site, void* stream) {
     if (check_common("cvft_attn_relpos_bwd", dtype, B, H, L, ld, ldo, q, k, v)) return -1;
-    CVFT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || drop_seed), "cvft_attn_relpos_bwd: bad dropout args");
+    CVFT_CHECK_ARG(cvft_drop_rate_ok(drop_p) && (drop_p == 0.f || drop_seed), "cvft_attn_relpos_bwd: bad dropout args (p == 0 or 2^-16 <= p <= 1 - 2^-16, seed)");
     int vec = dtype == CVFT_BF16 ? 8 : 4;
     CVFT_CHECK_ARG(pp && bias_u && bias_v && ldp >= H * 64 && ldp % vec == 0 && (((uintptr_t)pp) & 15) == 0,
                    "cvft_attn_relpos_bwd: bad p");

@@ -177,6 +177,10 @@ __device__ __forceinline__ unsigned long long cvft_drop_key(const long long* see
 // GEMM epilogues, rank-side products and the dropout passes of every train-mode step; at 32 bits per element (two draws
 // per group) the masked-extension GEMM launches ran 1.3-1.8x their plain twins on mask arithmetic alone.  p is quantised
 // to 1/65536 (0.05 -> 0.050003), the keep scale stays 1 / (1 - p).
+// Rates the 16-bit fields represent without bias: p == 0 (off) or 2^-16 <= p <= 1 - 2^-16.  Below 2^-16 the threshold rounds to
+// 0 (nothing dropped, everything still scaled by 1 / (1 - p)); above 1 - 2^-16 it clamps (1 in 65536 kept, scaled by a huge
+// factor): every C entry that takes a dropout rate rejects those (CVFT_CHECK_ARG), see include/cvft.h "Dropout masks".
+static inline bool cvft_drop_rate_ok(float p) { return p == 0.f || (p >= 1.f / 65536.f && p <= 1.f - 1.f / 65536.f); }
 __device__ __forceinline__ unsigned cvft_drop_thr(float p) { return (unsigned)fminf(65535.f, rintf(p * 65536.f)); }
 // keep flags of elements 4g .. 4g+3: field e of the draw >= thr
 __device__ __forceinline__ void cvft_keep4(unsigned long long key, unsigned long long g, unsigned thr, bool (&k)[4]) {

@@ -591,7 +591,7 @@ static void dropout_launch(int dtype, int64_t n, const void* x, const void* res,
 extern "C" int cvft_dropout_add(int dtype, int64_t n, const void* x, const void* residual, void* y, float p,
                                 const int64_t* seed, unsigned site, void* stream) {
     CHECK_DTYPE("cvft_dropout_add", dtype);
-    CVFT_CHECK_ARG(n >= 0 && x && y && seed && p >= 0.f && p < 1.f, "cvft_dropout_add: bad args (0 <= p < 1)");
+    CVFT_CHECK_ARG(n >= 0 && x && y && seed && cvft_drop_rate_ok(p), "cvft_dropout_add: bad args (p == 0 or 2^-16 <= p <= 1 - 2^-16)");
     if (n == 0) return 0;
     dropout_launch<0>(dtype, n, x, residual, y, p, seed, site, 0, (hipStream_t)stream);
     CVFT_LAUNCH_CHECK("cvft_dropout_add");
@@ -602,7 +602,7 @@ extern "C" int cvft_dropout_add(int dtype, int64_t n, const void* x, const void*
 extern "C" int cvft_act_dropout(int dtype, int64_t n, int act, const void* z, const void* dh, void* y, float p,
                                 const int64_t* seed, unsigned site, void* stream) {
     CHECK_DTYPE("cvft_act_dropout", dtype);
-    CVFT_CHECK_ARG(n >= 0 && z && y && seed && p >= 0.f && p < 1.f, "cvft_act_dropout: bad args (0 <= p < 1)");
+    CVFT_CHECK_ARG(n >= 0 && z && y && seed && cvft_drop_rate_ok(p), "cvft_act_dropout: bad args (p == 0 or 2^-16 <= p <= 1 - 2^-16)");
     if (n == 0) return 0;
     if (dh) dropout_launch<2>(dtype, n, z, dh, y, p, seed, site, act, (hipStream_t)stream);
     else dropout_launch<1>(dtype, n, z, nullptr, y, p, seed, site, act, (hipStream_t)stream);
@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(256) lora_side_dgrad_kernel(int M, int K, cons
 extern "C" int cvft_lora_side_dgrad(int M, int K, int R, const void* V, int ldv, const void* A, int lda, const void* dx, int ldi,
                                     void* out, int ldo, float p, const int64_t* seed, const unsigned* sites, void* stream) {
     CVFT_CHECK_ARG(M > 0 && K > 0 && K % 4 == 0 && (R == 16 || R == 48) && V && A && dx && out && seed && sites && ldv >= R && lda >= K &&
-                   ldi >= K && ldo >= K && ldi % 4 == 0 && ldo % 4 == 0 && p > 0.f && p < 1.f &&
+                   ldi >= K && ldo >= K && ldi % 4 == 0 && ldo % 4 == 0 && p > 0.f && cvft_drop_rate_ok(p) &&
                    (((uintptr_t)dx | (uintptr_t)out) & 7) == 0, "cvft_lora_side_dgrad: bad args (bf16, K %% 4 == 0, R in {16, 48})");
     dim3 grid((K + 63) / 64, (M + 63) / 64);
     uint4 st = make_uint4(sites[0], R > 16 ? sites[1] : 0u, R > 16 ? sites[2] : 0u, 0u);

@@ -355,15 +355,15 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
     for (int i = 0; i < 4; ++i) p.xdrop_sites[i] = a->xdrop_sites[i];
     p.odrop_p = a->odrop_p; p.odrop_site = a->odrop_site;
     if (p.odrop_p > 0.f) {
-        if (!p.xdrop_seed || p.odrop_p >= 1.f || p.N % 4 != 0 || p.ldc != p.N || p.Tm != p.M || p.out_stride != 1 || p.out_off != 0 || p.Tout != p.Tm) {
-            cvft_set_error("cvft_gemm: output dropout needs a seed, 0 < p < 1, N %% 4 == 0, ldc == N and identity row geometry");
+        if (!p.xdrop_seed || !cvft_drop_rate_ok(p.odrop_p) || p.N % 4 != 0 || p.ldc != p.N || p.Tm != p.M || p.out_stride != 1 || p.out_off != 0 || p.Tout != p.Tm) {
+            cvft_set_error("cvft_gemm: output dropout needs a seed, 2^-16 <= p <= 1 - 2^-16, N %% 4 == 0, ldc == N and identity row geometry");
             return -1;
         }
     }
     if (p.fuse) { p.R = a->R; p.U = nullptr; }
     if (p.xdrop_p > 0.f) {
-        if (sizeof(T) != 2 || p.fuse || !a->U || !p.xdrop_seed || p.R % 16 != 0 || p.R > 64 || p.xdrop_p >= 1.f) {
-            cvft_set_error("cvft_gemm: masked rank extension needs bf16, U / Bl with R %% 16 == 0, R <= 64, a seed and 0 < p < 1");
+        if (sizeof(T) != 2 || p.fuse || !a->U || !p.xdrop_seed || p.R % 16 != 0 || p.R > 64 || !cvft_drop_rate_ok(p.xdrop_p)) {
+            cvft_set_error("cvft_gemm: masked rank extension needs bf16, U / Bl with R %% 16 == 0, R <= 64, a seed and 2^-16 <= p <= 1 - 2^-16");
             return -1;
         }
     }

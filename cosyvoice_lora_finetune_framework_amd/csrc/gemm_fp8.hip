@@ -239,7 +239,7 @@ extern "C" int cvft_gemm_fp8(const cvft_gemm_args* a, const void* A8, int lda8, 
     p.bytesA = p.bytesW = p.bytesU = p.bytesB = p.bytesL = 0;
     p.vecA = p.vecW = 1; p.vecU = p.vecB = 1;
     p.xdrop_p = 0.f; p.xdrop_seed = (const long long*)a->xdrop_seed; p.odrop_p = a->odrop_p; p.odrop_site = a->odrop_site;
-    CVFT_CHECK_ARG(p.odrop_p <= 0.f || (p.xdrop_seed && p.odrop_p < 1.f && p.ldc == p.N), "cvft_gemm_fp8: output dropout needs a seed, p < 1 and ldc == N");
+    CVFT_CHECK_ARG(p.odrop_p <= 0.f || (p.xdrop_seed && cvft_drop_rate_ok(p.odrop_p) && p.ldc == p.N), "cvft_gemm_fp8: output dropout needs a seed, p < 1 and ldc == N");
     for (int i = 0; i < 4; ++i) p.xdrop_sites[i] = 0;
     if (p.R > 0)
         CVFT_CHECK_ARG(p.Bl && p.R % 8 == 0 && p.R <= 64 && p.ldu % 8 == 0 && p.ldbl % 8 == 0 &&

@@ -234,7 +234,7 @@ extern "C" int cvft_layernorm_bwd_mask(int dtype, int rows, int C, const void* x
                                        float p, const int64_t* seed, unsigned site, void* dxm, void* stream) {
     CVFT_CHECK_ARG(dtype == CVFT_F32 || dtype == CVFT_BF16, "cvft_layernorm_bwd_mask: bad dtype");
     CVFT_CHECK_ARG(rows >= 0 && C > 0 && x && gamma && beta && mean && rstd && dy && dx && dxm && seed, "cvft_layernorm_bwd_mask: bad args");
-    CVFT_CHECK_ARG(p > 0.f && p < 1.f, "cvft_layernorm_bwd_mask: p outside (0, 1)");
+    CVFT_CHECK_ARG(p > 0.f && cvft_drop_rate_ok(p), "cvft_layernorm_bwd_mask: p outside [2^-16, 1 - 2^-16]");
     const bool ra = ((reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(dxm)) & 15) == 0;
     const bool ok = ra && (dtype == CVFT_F32 ? ln_vec_ok<float>(C, x, dy, dx) : ln_vec_ok<bf16_t>(C, x, dy, dx));
     CVFT_CHECK_ARG(ok, "cvft_layernorm_bwd_mask: needs the vector path (C % (16 / sizeof(T)) == 0, C <= 256 chunks, 16-byte aligned pointers)");

@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(512) skinny_dropout_kernel(int M, int K, const
 extern "C" int cvft_skinny_dropout(int M, int K, int R, const void* X, int ldx, const void* A, int lda, float alpha, void* C,
                                    int ldc, float p, const int64_t* seed, const unsigned* sites, void* const* xd, void* stream) {
     CVFT_CHECK_ARG(M > 0 && K >= 32 && K % 32 == 0 && (R == 16 || R == 32 || R == 48 || R == 64) && X && A && C && seed && sites &&
-                   ldx == K && lda >= K && ldc >= R && p > 0.f && p < 1.f && (((uintptr_t)X | (uintptr_t)A) & 15) == 0 && lda % 8 == 0,
+                   ldx == K && lda >= K && ldc >= R && p > 0.f && cvft_drop_rate_ok(p) && (((uintptr_t)X | (uintptr_t)A) & 15) == 0 && lda % 8 == 0,
                    "cvft_skinny_dropout: bad args (bf16, contiguous X rows, K %% 32 == 0, R in {16, 32, 48, 64})");
     const int nt = R / 16;
     bool shared = true;                 // one adapter: every rank tile under the same mask site
@@ -356,7 +356,7 @@ extern "C" int cvft_ln_skinny_dropout(int M, int K, int R, const void* X, const 
                                       float* mean, float* rstd, const void* A, int lda, float alpha, void* U, int ldu, float p,
                                       const int64_t* seed, const unsigned* sites, void* const* xd, void* stream) {
     CVFT_CHECK_ARG(M > 0 && K >= 32 && K % 32 == 0 && K <= 1024 && (R == 16 || R == 48) && X && gamma && beta && Y && mean && rstd && A && U &&
-                   seed && sites && lda >= K && ldu >= R && p > 0.f && p < 1.f && lda % 8 == 0 &&
+                   seed && sites && lda >= K && ldu >= R && p > 0.f && cvft_drop_rate_ok(p) && lda % 8 == 0 &&
                    (((uintptr_t)X | (uintptr_t)A | (uintptr_t)Y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
                    "cvft_ln_skinny_dropout: bad args (bf16 contiguous rows, K %% 32 == 0, K <= 1024, R in {16, 48}, 16-byte aligned operands)");
     const int nt = R / 16;

@@ -154,7 +154,12 @@ def lib() -> C.CDLL:
     return _lib
 
 
+CALLS = 0          # C-ABI calls that went through check() (bench.py: roofline.step.cabi_calls_per_step)
+
+
 def check(rc: int, what: str = "") -> None:
+    global CALLS
+    CALLS += 1
     if rc != 0:
         msg = lib().cvft_last_error()
         raise CvftError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

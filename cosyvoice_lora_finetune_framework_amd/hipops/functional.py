@@ -243,19 +243,42 @@ def act_bwd(z: torch.Tensor, dy: torch.Tensor, act: str) -> torch.Tensor:
 _DROPOUT = {"seed": None, "site": 0}
 
 
+_SEED_MASK = 0x7fffffffffff
+_RANK_STRIDE = 0x9E3779B97F4A7C15      # per-rank offset of the mask stream: DP replicas must not draw the same masks
+
+
+def _dist_rank() -> int:
+    return torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+
+
+def dropout_seed_state():
+    """Rank-free state of the dropout stream (what a checkpoint stores): this rank's device seed minus its rank offset."""
+    if _DROPOUT["seed"] is None:
+        return None
+    return (int(_DROPOUT["seed"].item()) - _RANK_STRIDE * _dist_rank()) & _SEED_MASK
+
+
+def set_dropout_seed_state(base: int) -> None:
+    """Resume the dropout stream from a checkpointed rank-free state: every rank re-applies ITS offset, and the value is copied
+    INTO the existing seed tensor when there is one (a hipGraph captured earlier by this process increments that address)."""
+    val = (int(base) + _RANK_STRIDE * _dist_rank()) & _SEED_MASK
+    if _DROPOUT["seed"] is None:
+        _DROPOUT["seed"] = torch.full((1,), val, dtype=torch.int64, device="cuda")
+    else:
+        _DROPOUT["seed"].fill_(val)
+
+
 def dropout_begin_step() -> None:
     """Advance the device-side dropout seed (a captured op: every hipGraph replay draws new masks) and restart the
     call-site numbering.  JointLLMFlowModel.forward calls it once per training forward."""
     if _DROPOUT["seed"] is None:
-        # per-rank stream: data-parallel replicas must not draw the same masks for their shards of the global batch
-        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-        seed0 = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * rank) & 0x7fffffffffff
-        _DROPOUT["seed"] = torch.full((1,), seed0, dtype=torch.int64, device="cuda")
+        set_dropout_seed_state(int(torch.initial_seed()))
     _DROPOUT["seed"].add_(1)
     _DROPOUT["site"] = 0
     _DROPPED.clear()              # dropped inputs a previous forward wrote and no backward consumed
     _ODROP_OUT.clear()
     _PRE_MASKED.clear()
+    _PRE_U.clear()                # a LayerNorm hand-off no adapter took (with the dropped copies it keeps alive)
 
 
 class DropoutAddFn(torch.autograd.Function):

@@ -124,8 +124,11 @@ class JointLLMFlowModel(nn.Module):
             out.update(self.llm.prepare_batch(batch, device, lm_pad, lm_min))
         return out
 
-    def _split_parts(self, batch: dict, device, nparts: int, kind: str = 'llm', lm_pad: int = 1):
-        """Host side: contiguous sub-batches + their share of the global loss denominators (frames / target tokens)."""
+    def _split_parts(self, batch: dict, device, nparts: int, kind: str = 'llm', lm_pad: int = 1, lm_min: int = 0):
+        """Host side: contiguous sub-batches + their share of the global loss denominators (frames / target tokens).
+        lm_min: LM length every sub-batch's index maps are padded to -- the captured layout's (Trainer._fit_layout matches
+        layouts on the WHOLE batch's length; a sub-batch that derived its own shorter length would miss the captured step
+        and be captured again)."""
         B = batch['speech_token'].shape[0]
         bounds = [round(i * B / nparts) for i in range(nparts + 1)]
         feat_len = batch['speech_feat_len'].detach().cpu().double()
@@ -137,7 +140,7 @@ class JointLLMFlowModel(nn.Module):
                    for k, v in batch.items() if not k.startswith('_')}
             if '_true_dims' in batch:                   # exact batch maxima of a shape-bucketed batch: whole-batch values
                 sub['_true_dims'] = batch['_true_dims']
-            part = self._prepare_one(sub, device, lm_pad, with_llm=(kind == 'llm'))      # index maps only where the LM runs
+            part = self._prepare_one(sub, device, lm_pad, with_llm=(kind == 'llm'), lm_min=lm_min)   # index maps only where the LM runs
             part['_rows'] = sl
             # device scalars, not Python floats: a captured step is replayed on other batches (other length mixes)
             part['_w_flow'] = torch.tensor(float(feat_len[sl].sum() / feat_len.sum()), dtype=torch.float32).to(device)
@@ -149,10 +152,10 @@ class JointLLMFlowModel(nn.Module):
         """Move a collated batch to `device` and attach the host-computed LLM index maps (and the sub-batch split), so
         that the training step itself performs no host<->device transfers (hipGraph-capturable)."""
         out = self._prepare_one(batch, device, lm_pad, lm_min=lm_min)
-        out['_parts'] = self._make_parts(batch, out, device, True, lm_pad)
+        out['_parts'] = self._make_parts(batch, out, device, True, lm_pad, lm_min)
         return out
 
-    def _make_parts(self, batch: dict, whole: dict, device, split: bool, lm_pad: int = 1) -> dict:
+    def _make_parts(self, batch: dict, whole: dict, device, split: bool, lm_pad: int = 1, lm_min: int = 0) -> dict:
         """per branch: the list of sub-batches its chains run on (one entry aliasing `whole` when the branch is not split)"""
         B = batch['speech_token'].shape[0]
         parts = {}
@@ -162,7 +165,7 @@ class JointLLMFlowModel(nn.Module):
             min_part = SPLIT_MIN_PART_FLOW_ONLY if self.training_mode == 'flow_only' else SPLIT_MIN_PART
             if not (split and runs) or B < n * min_part:
                 n = 1
-            parts[kind] = self._split_parts(batch, device, n, kind, lm_pad) if n > 1 else [dict(whole, _w_llm=1.0, _w_flow=1.0)]
+            parts[kind] = self._split_parts(batch, device, n, kind, lm_pad, lm_min) if n > 1 else [dict(whole, _w_llm=1.0, _w_flow=1.0)]
         return parts
 
     def _forward_llm(self, batch: dict, device) -> Dict[str, Any]:

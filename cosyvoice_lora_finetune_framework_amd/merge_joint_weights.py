@@ -35,7 +35,7 @@ def find_latest_joint_checkpoint(output_dir: str, mode: Optional[str] = None) ->
 
 
 def _read_state(ckpt_path: str) -> Dict[str, torch.Tensor]:
-    ckpt = torch.load(ckpt_path, map_location='cpu', weights_only=False)
+    ckpt = torch.load(ckpt_path, map_location='cpu', weights_only=True)     # tensors + plain scalars / strings only
     return ckpt.get('state_dict', ckpt)
 
 

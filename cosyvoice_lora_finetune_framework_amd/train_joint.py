@@ -262,18 +262,31 @@ class _Prefetcher:
         import threading
         self.q = queue.Queue(maxsize=depth)
         self._end = object()
+        self._stop = threading.Event()
+        self._queue_mod = queue
 
         dev_index = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def put(item) -> bool:
+            """blocking put that gives up when the consumer has closed the prefetcher"""
+            while not self._stop.is_set():
+                try:
+                    self.q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
 
         def work():
             try:
                 if dev_index is not None:       # a new thread starts on device 0: bind it to this rank's GPU (one process per GPU)
                     torch.cuda.set_device(dev_index)
                 for item in iterable:
-                    self.q.put(fn(item))
-                self.q.put(self._end)
+                    if self._stop.is_set() or not put(fn(item)):
+                        return
+                put(self._end)
             except BaseException as e:          # forwarded to the consumer
-                self.q.put(e)
+                put(e)
         self.t = threading.Thread(target=work, daemon=True)
         self.t.start()
 
@@ -285,6 +298,18 @@ class _Prefetcher:
             if isinstance(item, BaseException):
                 raise item
             yield item
+
+    def close(self):
+        """Stop the worker (early stop, an exception in the step, KeyboardInterrupt): it would otherwise stay blocked in
+        q.put forever, holding the dataloader iterator, prepared device slabs and pinned buffers, and keep issuing
+        copy-stream work during checkpoint save / teardown."""
+        self._stop.set()
+        try:
+            while True:
+                self.q.get_nowait()
+        except self._queue_mod.Empty:
+            pass
+        self.t.join(timeout=30)
 
 
 _TIMING = [] if os.environ.get('CVFT_TRAINER_TIMING') else None      # diagnostic: per-replay (events, host stamps), read by bench.py
@@ -403,12 +428,12 @@ class Trainer:
     def _ckpt(self, module, opt):
         from .hipops import functional as HF
         sd = {f"model.{k}": v.detach().cpu() for k, v in module.model.state_dict().items()}
-        seed = HF._DROPOUT["seed"]
+        seed = HF.dropout_seed_state()          # rank-free: every rank re-applies its own offset on resume
         return {"state_dict": sd, "optimizer": opt.state_dict(), "epoch": self.current_epoch,
                 "global_step": self.global_step, "best": self.best,
                 "callbacks": [dict(type=type(c).__name__, **{k: v for k, v in vars(c).items() if isinstance(v, (int, float))})
                               for c in self.callbacks],
-                "dropout_seed": None if seed is None else int(seed.item()),
+                "dropout_seed": seed,
                 "hyper_parameters": dict(training_mode=module.training_mode,
                 learning_rate=module.learning_rate, min_lr=module.min_lr, warmup_steps=module.warmup_steps,
                 weight_decay=module.weight_decay)}
@@ -438,7 +463,7 @@ class Trainer:
                     if k != "type" and hasattr(c, k):
                         setattr(c, k, v)
         if ck.get("dropout_seed") is not None and torch.cuda.is_available():
-            HF._DROPOUT["seed"] = torch.full((1,), int(ck["dropout_seed"]), dtype=torch.int64, device="cuda")
+            HF.set_dropout_seed_state(int(ck["dropout_seed"]))
 
     # -- one micro-step ---------------------------------------------------------------------
     def _prepare(self, module, batch):
@@ -569,38 +594,45 @@ class Trainer:
             losses = None
             if self.use_graph and self._copy_stream is None:
                 self._copy_stream = torch.cuda.Stream()
-            for bi, (batch, prepared, ready) in enumerate(_Prefetcher(dataloader, lambda b: self._prepare(module, b))):
-                # A rank whose batch failed to decode (collate_fn -> None) still takes part in every collective of the
-                # step with a zero-weight contribution: no rank ever skips an all-reduce the others enter.
-                w = ones
-                if self.world > 1:
-                    lw = dp.loss_weights(_batch_denoms(batch, module.training_mode), dev)
-                    w = torch.stack([torch.as_tensor(lw[k], dtype=torch.float32, device=dev) for k in term_keys])
-                if batch is not None:
-                    draws = self.draws_fn(epoch, bi, batch) if self.draws_fn else None
-                    losses = self._micro_step(module, opt, batch, draws, w, prepared, ready)
-                    ep_sum += torch.stack([losses[k].float() if k in losses else ep_sum.new_zeros(()) for k in keys])
-                    ep_cnt += 1
-                rec = None
-                if (bi + 1) % self.accum == 0 or bi + 1 == nb:
-                    lr = module.lr_at(self.global_step, total_steps)
-                    opt.set_lr(lr)
-                    gscale = dp.allreduce_flat_grads(opt.flat_g)
-                    opt.step(gscale)
-                    if self.log_every and self.global_step % self.log_every == 0 and losses is not None:
-                        rec = dict(epoch=epoch, step=self.global_step, lr=lr, grad_norm=float(opt.grad_norm(gscale)),
-                                   **{k: float(losses[k]) for k in keys if k in losses})
-                    opt.zero_grad()
-                    self.global_step += 1
-                    if self.on_step_end is not None:
-                        self.on_step_end(self)
-                if rec is not None:
-                    self.history.append(rec)
-                    if logf:
-                        logf.write(json.dumps(rec) + "\n")
-                        logf.flush()
-                if self.should_stop:
-                    break
+            prefetch = _Prefetcher(dataloader, lambda b: self._prepare(module, b))
+            try:
+                for bi, (batch, prepared, ready) in enumerate(prefetch):
+                    # A rank whose batch failed to decode (collate_fn -> None) still takes part in every collective of the
+                    # step with a zero-weight contribution: no rank ever skips an all-reduce the others enter.
+                    w = ones
+                    if self.world > 1:
+                        lw = dp.loss_weights(_batch_denoms(batch, module.training_mode), dev)
+                        w = torch.stack([torch.as_tensor(lw[k], dtype=torch.float32, device=dev) for k in term_keys])
+                    if batch is not None:
+                        draws = self.draws_fn(epoch, bi, batch) if self.draws_fn else None
+                        losses = self._micro_step(module, opt, batch, draws, w, prepared, ready)
+                        ep_sum += torch.stack([losses[k].float() if k in losses else ep_sum.new_zeros(()) for k in keys])
+                        ep_cnt += 1
+                    rec = None
+                    if (bi + 1) % self.accum == 0 or bi + 1 == nb:
+                        lr = module.lr_at(self.global_step, total_steps)
+                        opt.set_lr(lr)
+                        gscale = dp.allreduce_flat_grads(opt.flat_g)
+                        hook = getattr(module, "on_before_optimizer_step", None)      # (Lightning's module hook of that name)
+                        if hook is not None:
+                            hook(opt)
+                        opt.step(gscale)
+                        if self.log_every and self.global_step % self.log_every == 0 and losses is not None:
+                            rec = dict(epoch=epoch, step=self.global_step, lr=lr, grad_norm=float(opt.grad_norm(gscale)),
+                                       **{k: float(losses[k]) for k in keys if k in losses})
+                        opt.zero_grad()
+                        self.global_step += 1
+                        if self.on_step_end is not None:
+                            self.on_step_end(self)
+                    if rec is not None:
+                        self.history.append(rec)
+                        if logf:
+                            logf.write(json.dumps(rec) + "\n")
+                            logf.flush()
+                    if self.should_stop:
+                        break
+            finally:
+                prefetch.close()
             means = dp.reduce_metrics(torch.cat([ep_sum, ep_sum.new_tensor([float(ep_cnt)])]))
             means = (means[:-1] / means[-1].clamp_min(1.0)).tolist()      # (an epoch with no decodable batch: zeros, not NaN)
             self.callback_metrics = {"train_loss_epoch": means[0], "train_loss": means[0]}

@@ -40,6 +40,31 @@ def test_flow_tiny_loss_and_grads(tiny_meta, variant):
     assert worst < GRAD_TOL, worst
 
 
+@pytest.mark.parametrize("variant", ["vendored", "twin"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_flow_odd_padded_length_backward_matches_reference(tiny_meta, variant, dtype):
+    """Reference-pinned BACKWARD with an odd padded T_max (25; ragged 25 / 18): the U-Net's ceil(T/2) down path and the
+    transposed-conv up path cropped from T + 1 to T (cosyvoice/flow/decoder.py:256, 276), fixture tests/golden/flow_oddT.npz
+    (tools/make_golden.py gen_oddT: the reference's own forward + autograd)."""
+    g = load_npz("flow_oddT.npz")
+    m = build_flow_product(tiny_meta["flow"], DEV, _numerics(variant, dtype))
+    draws = dict(t_raw=g["draw_t_raw"], z=g["draw_z"], cfg_rand=g["draw_cfg_rand"])
+    out = m.forward_no_prompt(_batch(g), DEV, draws)
+    ref = float(g[f"loss_{variant}"])
+    out["loss"].backward()
+    grads = lora_grads(m)
+    refg = {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith(f"grad_{variant}/")}
+    assert set(grads) == set(refg)
+    if dtype == torch.float32:
+        assert abs(float(out["loss"]) - ref) / ref < LOSS_TOL, (float(out["loss"]), ref)
+        assert max(rel(grads[k], refg[k]) for k in refg) < GRAD_TOL
+    else:
+        assert abs(float(out["loss"]) - ref) / ref < 3e-2
+        num = math.sqrt(sum(float(((grads[k].double().cpu() - refg[k].double()) ** 2).sum()) for k in refg))
+        den = math.sqrt(sum(float((refg[k].double() ** 2).sum()) for k in refg))
+        assert num / den < 0.1
+
+
 def test_flow_tiny_bf16_close(tiny_meta):
     g = load_npz("flow_tiny.npz")
     m = build_flow_product(tiny_meta["flow"], DEV, _numerics("vendored", torch.bfloat16))
@@ -193,11 +218,20 @@ def test_full_size_llm_matches_reference(case):
     assert abs(lb - c["loss"]) / c["loss"] < 2e-2, lb
 
 
-# Stated tolerances of the reduced-precision BACKWARD at full size (relative L2 against the reference's fp32 CPU
-# gradients; measured: bf16 loss <= 4e-4, gradient norm <= 8e-3, worst single adapter tensor 4e-2 .. 1.4e-1 (the largest at
-# T = 1000 / r = 64 on an early-layer adapter), fp8 loss 1e-4 / norm 1.2e-3; the fp32 path is at 1e-7 / 5e-6 / 8e-4):
-BF16_LOSS_TOL, BF16_GRAD_TENSOR_TOL, BF16_GRAD_NORM_TOL = 2e-2, 2.5e-1, 5e-2
-FP8_LOSS_TOL, FP8_GRAD_NORM_TOL = 3e-2, 1e-1
+# Stated tolerances of the reduced-precision BACKWARD at full size (relative L2 against the reference's fp32 CPU gradients) --
+# each <= 3x the value measured on MI355X in round 3 (printed by _check_backward):
+#   bf16: loss 3.1e-5 .. 4.5e-4, total gradient norm 3.6e-4 .. 4.3e-3, worst picked adapter tensor 3.6e-2 .. 7.3e-2 at T = 500 / LLM
+#         and 2.1e-1 at the flow's T = 1000 / r = 64 case;  fp8 (LLM, T = 1000): loss 1.05e-4, norm 1.2e-3;  fp32: 1e-6 / 5e-6 / 8e-4.
+# Where the 2.1e-1 comes from (tools/grad_error_profile.py, T = 1000 / r = 64, bf16 against the fp32 product path): it sits on the
+# to_q / to_k adapters of the estimator's MID blocks only -- tensors that hold 3e-4 .. 5e-4 of the gradient norm each (|g| ~ 1e-3
+# against 0.6 for the first block's to_v).  With 500 keys per query at that U-Net level the softmax is nearly flat, and the
+# score gradient dS = P (dP - delta) is a small difference of nearly equal bf16-rounded numbers; the to_v adapters of the very same
+# blocks are at 2e-2, so it is neither depth (mid_blocks.5 and .11 read alike) nor the slab accumulation order.  Tensors holding
+# > 2 % of the gradient norm are all <= 4.3e-2 and the whole-gradient error is 2.2e-2 -- hence a per-tensor bound that scales
+# with the tensor's share of the norm (BF16_SMALL_TENSOR_TOL for shares < 0.2 %).
+BF16_LOSS_TOL, BF16_GRAD_NORM_TOL = 1.5e-3, 1.5e-2
+BF16_GRAD_TENSOR_TOL, BF16_SMALL_TENSOR_TOL, SMALL_SHARE = 2.2e-1, 6.5e-1, 2e-3
+FP8_LOSS_TOL, FP8_GRAD_NORM_TOL = 5e-4, 4e-3
 
 
 def _full_case(branch, tag):
@@ -228,12 +262,18 @@ def _check_backward(grads, c, ref, loss, mode):
     rn = abs(tot - c["grads"]["total_norm"]) / c["grads"]["total_norm"]
     rl = abs(loss - c["loss"]) / c["loss"]
     worst = max(rel(grads[k], v) for k, v in ref.items())
-    print(f"[{mode}] loss rel {rl:.2e}  grad-norm rel {rn:.2e}  worst picked tensor rel-L2 {worst:.2e}")
+    # tensors that carry a visible share of the gradient norm / the tiny ones (see the note above)
+    share = {k: float(v.double().norm()) / c["grads"]["total_norm"] for k, v in ref.items()}
+    worst_big = max([rel(grads[k], v) for k, v in ref.items() if share[k] >= SMALL_SHARE] or [0.0])
+    worst_small = max([rel(grads[k], v) for k, v in ref.items() if share[k] < SMALL_SHARE] or [0.0])
+    print(f"[{mode}] loss rel {rl:.2e}  grad-norm rel {rn:.2e}  worst picked tensor rel-L2 {worst:.2e} "
+          f"(norm share >= {SMALL_SHARE}: {worst_big:.2e}, smaller: {worst_small:.2e})")
     assert set(ref) <= set(grads)
     if mode == "fp32":
         assert rl < LOSS_TOL and rn < 1e-3 and worst < GRAD_TOL, (rl, rn, worst)
     elif mode == "bf16":
-        assert rl < BF16_LOSS_TOL and rn < BF16_GRAD_NORM_TOL and worst < BF16_GRAD_TENSOR_TOL, (rl, rn, worst)
+        assert rl < BF16_LOSS_TOL and rn < BF16_GRAD_NORM_TOL, (rl, rn)
+        assert worst_big < BF16_GRAD_TENSOR_TOL and worst_small < BF16_SMALL_TENSOR_TOL, (worst_big, worst_small)
     else:
         assert rl < FP8_LOSS_TOL and rn < FP8_GRAD_NORM_TOL, (rl, rn, worst)
 

@@ -209,6 +209,33 @@ def gen_tiny():
         json.dump(meta, f, indent=0)
 
 
+def gen_oddT():
+    """Odd padded T_max (VERDICT round 2 item 4 / SURVEY Appendix C): the U-Net's stride-2 down path gives ceil(T/2) frames and the
+    transposed-conv up path 2*ceil(T/2) = T + 1, cropped back to T (cosyvoice/flow/decoder.py:256, 276 == modules.py:1049, 1080).
+    Ragged B = 2, T in {25, 18} (T_max = 25 odd, and an odd + an even utterance), all LoRA gradients, both numerics variants."""
+    batch = synth_batch([25, 18], text_lens=[6, 5], token_lens=[14, 10], seed=21, text_vocab=100, speech_vocab=50)
+    draws = cfm_draws(2, 25, seed=78)
+    arr = dict(**{f"in_{k}": v for k, v in batch.items()}, draw_t_raw=draws['t_raw'], draw_z=draws['z'], draw_cfg_rand=draws['cfg_rand'])
+    for variant in ('vendored', 'twin'):
+        torch.manual_seed(0)
+        m = build_ref_flow(variant, **TINY_FLOW)
+        wrap_and_fill(m, r=4, alpha=8, targets=FLOW_TARGETS, seed=3)
+        cap = {}
+        if variant == 'vendored':
+            m.decoder.estimator.register_forward_hook(lambda mod, i, o: cap.update(pred=o.detach()))
+        loss, grads = run_flow(m, batch, seed=78)
+        print(f"odd-T flow {variant}: loss={loss.item():.8f}  lora tensors={len(grads)}")
+        arr[f"loss_{variant}"] = loss
+        if cap:
+            arr["pred"] = cap["pred"]
+        for k, g in grads.items():
+            arr[f"grad_{variant}/{k}"] = g
+    npz_save(os.path.join(GOLD, "flow_oddT.npz"), **arr)
+    with open(os.path.join(GOLD, "flow_oddT_meta.json"), "w") as f:
+        json.dump(dict(feat_lens=[25, 18], text_lens=[6, 5], token_lens=[14, 10], seed=21, draw_seed=78, text_vocab=100,
+                       speech_vocab=50), f)
+
+
 def gen_pos():
     """LLM tiny with the reference's DEFAULT target list (lora.py:155-166: target_modules=None), which wraps linear_pos:
     the gradient then also flows into the projected positional encoding (rel-pos attention's p operand)."""
@@ -627,6 +654,8 @@ if __name__ == "__main__":
         gen_tiny()
     if a.only in ("all", "pos"):
         gen_pos()
+    if a.only in ("all", "oddT"):
+        gen_oddT()
     if a.only in ("all", "fullgrads"):
         gen_full_grads()
     if a.only in ("all", "sampler"):
