@@ -21,133 +21,7 @@
 // features of the output projection) and meet once per link in LDS (fp32 partial tiles, 128 KB).
 // Bound: the per-CU L2 -> register rate (~120 GB/s per CU with one workgroup per CU, tools/ub/mfma_rate.hip): 1.25 MB of
 // packed weights per row tile each way; 125 workgroups at M = 4000.
-#include "common.h"
-
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-// Diagnostic build only (-DBF_STAMPS, tools/block_stamps.py): s_memtime at the phase boundaries of wave 0 of one block of the
-// forward kernel, read back by cvft_debug_block_stamps of that build (never in the product library).
-#ifdef BF_STAMPS
-__device__ unsigned long long bf_stamps[32];
-#define BF_STAMP_BLOCK 7
-#define BF_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
-        __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == BF_STAMP_BLOCK && threadIdx.x == 0) bf_stamps[i] = t__; } while (0)
-extern "C" int cvft_debug_block_stamps(unsigned long long* host_out) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bf_stamps), sizeof(bf_stamps)) == hipSuccess ? 0 : -1;
-}
-#else
-#define BF_STAMP(i)
-#endif
-
-#define BF_ROWS 32
-#define BF_D 256
-#define BF_CT (BF_D / 32)                 // 8 output-feature tiles of the residual stream
-#define BF_KS (BF_D / 16)                 // 16 k-steps over the residual stream
-#define BF_RING 32                        // weight fragments in flight per wave
-
-// LDS carve (dynamic, 16-byte aligned base)
-#define BF_LDS_PART 0                     // 4 waves x [8 ct][4 g][64 lanes] f32x4 = 128 KB
-#define BF_LDS_TILE (4 * 32768)           // [32 rows][256] bf16, 16-byte chunks XOR-swizzled by (row & 15): 16 KB
-#define BF_LDS_STAT (BF_LDS_TILE + 16384) // [3][4 waves][32 rows] floats
-#define BF_LDS_BIAS (BF_LDS_STAT + 3 * 4 * 32 * 4)   // F floats: the hidden bias (read per tile without touching vmcnt)
-#define BF_MAX_F 2048
-#define BF_LDS_PAR (BF_LDS_BIAS + 4 * BF_MAX_F)      // 4 x 256 floats: bo | gamma | beta | b2 (a late global load would queue
-                                                     // behind the 32 KB of weight fragments in flight: vmcnt retires in order)
-#define BF_LDS_TOTAL (BF_LDS_PAR + 4 * 4 * BF_D)
-
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 zero16() {
-    f32x16 z;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.f;
-    return z;
-}
-
-// GELU and its derivative (the feed-forward's activation runs on 32 x F values per row tile in a kernel with a single wave per
-// SIMD: its VALU cost sits beside the MFMAs of the same wave).  erf form (diffusers GELU, approximate="none"):
-// Abramowitz-Stegun 7.1.26 on u = |x| / sqrt(2), t = 1 / (1 + p u), 1 - erf(u) = poly(t) exp(-u^2), |error| <= 1.5e-7;
-// Phi(x) = 1 - q (x >= 0) or q (x < 0) with q = poly(t) exp(-x^2 / 2) / 2;  gelu = x Phi,  gelu' = Phi + x phi(x).
-// tanh form ("gelu-approximate"): Phi ~ sigmoid(2 k0 (x + k1 x^3)).
-template <int ACT, bool GRAD>
-__device__ __forceinline__ float bf_gelu(float x) {
-    if (ACT == CVFT_ACT_GELU_ERF) {
-        const float ax = fabsf(x);
-        const float t = __builtin_amdgcn_rcpf(fmaf(0.23164190f, ax, 1.f));           // p / sqrt(2)
-        float q = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
-        q = fmaf(q, t, 0.5f * 1.421413741f);
-        q = fmaf(q, t, 0.5f * -0.284496736f);
-        q = fmaf(q, t, 0.5f * 0.254829592f);
-        const float e2 = __builtin_amdgcn_exp2f(-0.72134752f * x * x);               // exp(-x^2 / 2)
-        q = q * t * e2;
-        const float cdf = x >= 0.f ? 1.f - q : q;
-        return GRAD ? fmaf(x * 0.39894228f, e2, cdf) : x * cdf;
-    } else {
-        const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
-        const float x2 = x * x;
-        const float u = k0 * x * fmaf(k1, x2, 1.f);
-        const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008f * u));   // sigmoid(2u) = (1 + tanh u) / 2
-        // d/dx [x sigmoid(2u)] = sg + x * 2 sg (1 - sg) * du/dx,  du/dx = k0 (1 + 3 k1 x^2)
-        return GRAD ? fmaf(x * 2.f * sg * (1.f - sg), k0 * fmaf(3.f * k1, x2, 1.f), sg) : x * sg;
-    }
-}
-
-// Sum the four waves' partial tiles acc[8] (feature tile ct, rows on the lanes) through LDS; afterwards wave w holds feature
-// tiles 2w, 2w+1 of all 32 rows: v[c2][4g + i] = element (row lane&31, feature 64w + 32 c2 + 8g + 4 (lane>>5) + i).
-__device__ __forceinline__ void bf_reduce(char* smem, int wave, int lane, const f32x16 (&acc)[BF_CT], float (&v)[2][16]) {
-    f32x4* part = reinterpret_cast<f32x4*>(smem + BF_LDS_PART);
-#pragma unroll
-    for (int ct = 0; ct < BF_CT; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 t = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
-            part[((wave * BF_CT + ct) * 4 + g) * 64 + lane] = t;
-        }
-    __syncthreads();
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 s = part[((0 * BF_CT + 2 * wave + c2) * 4 + g) * 64 + lane];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) s += part[((w * BF_CT + 2 * wave + c2) * 4 + g) * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[c2][4 * g + i] = s[i];
-        }
-}
-
-// per-row sum over the 256 features of a quantity each wave holds for its 64 features: lanes of both halves return the total
-__device__ __forceinline__ float bf_rowsum(char* smem, int slot, int wave, int lane, float partial) {
-    float* st = reinterpret_cast<float*>(smem + BF_LDS_STAT) + slot * 128;
-    partial += __shfl_xor(partial, 32, 64);
-    if (lane < 32) st[wave * 32 + lane] = partial;
-    __syncthreads();
-    const int m = lane & 31;
-    return st[m] + st[32 + m] + st[64 + m] + st[96 + m];
-}
-
-// [32][256] bf16 tile in LDS: 16-byte chunk ch (0..31) of row m lives at chunk ch ^ (m & 15)
-__device__ __forceinline__ int bf_tile_off(int m, int col) { return m * 512 + ((((col >> 3) ^ (m & 15))) << 4) + ((col & 7) << 1); }
-
-__device__ __forceinline__ void bf_tile_read(const char* smem, int lane, bf16x8 (&f)[BF_KS]) {
-    const int m = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < BF_KS; ++ks)
-        f[ks] = *reinterpret_cast<const bf16x8*>(smem + BF_LDS_TILE + m * 512 + (((2 * ks + h) ^ (m & 15)) << 4));
-}
-
-// accumulator initialised with the 32 bias values of hidden tile ht (register q of lane half h = feature (q&3) + 8 (q>>2) + 4 h)
-__device__ __forceinline__ f32x16 bf_bias_init(const float* b1s, int ht, int h) {
-    f32x16 acc;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + 32 * ht + 8 * g + 4 * h);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * g + i] = bb[i];
-    }
-    return acc;
-}
+#include "block_common.h"
 
 struct TailFwd {
     int M;
@@ -199,6 +73,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_fwd_kernel(TailFwd a) {
     const bool rvalid = m0 + m < a.M;
     BF_STAMP(0);
 
+    const unsigned touched = BF_TOUCH ? bf_touch_stream(a.Wst, 4 * a.wave_frags) : 0u;
     // ---- loads in the order they are needed (vmcnt retires in order): activations, small parameters (-> LDS), then the ring
     bf16x8 of[AR > 0 ? 4 * AR : 1];
     bf16x4 xb[2][4];                                   // this wave's 64 features of x0, later of x1 (as stored: bf16)
@@ -344,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_fwd_kernel(TailFwd a) {
             for (int i = 0; i < 4; ++i) yo[i] = (bf16_t)(v[c2][4 * g + i] + bb[i] + (float)xb[c2][g][i]);
             if (rvalid) *reinterpret_cast<bf16x4*>(a.out + (size_t)row * BF_D + c) = yo;
         }
+    if (touched == 0x7fc07fc1u && a.M < 0) a.mean[0] = 0.f;      // (keeps the prefetch loads alive; never true)
 }
 
 struct TailBwd {
@@ -382,6 +258,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
     const int row = min(m0 + m, a.M - 1);
     const bool rvalid = m0 + m < a.M;
 
+    const unsigned touched = BF_TOUCH ? bf_touch_stream(a.Wst, 4 * a.wave_frags) : 0u;
     // ---- loads in the order they are needed (vmcnt retires in order): dy fragments, the first tile's pre-activations, the
     // LayerNorm backward's operands (used at the end: requested now so that they never queue behind the ring), then the ring
     // dy as B fragments (natural k order): lane (m, h) holds dy[row][16 ks + 8 h .. + 7]
@@ -472,6 +349,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
             if (rvalid) *reinterpret_cast<bf16x4*>(a.dx1 + (size_t)row * BF_D + c) = dx;
             if (CR > 0) *reinterpret_cast<bf16x4*>(smem + BF_LDS_TILE + bf_tile_off(m, c)) = dx;
         }
+    if (touched == 0x7fc07fc1u && a.M < 0) a.dx1[0] = (bf16_t)0.f;  // (keeps the prefetch loads alive; never true)
     if (CR == 0) return;
     __syncthreads();
     // ---- do = dx1 Wo: wave w owns output features [w*DI/4, (w+1)*DI/4): 2 feature tiles per round, stream order [ks][f2]
@@ -499,18 +377,6 @@ __global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
         }
     }
 }
-
-template <typename K>
-static int bf_prepare(K kernel) {
-    // (cheap and idempotent; called per launch so that every instantiation gets its LDS size without a registry)
-    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_TOTAL) != hipSuccess) {
-        cvft_set_error("block_fused: cannot reserve %d bytes of LDS", BF_LDS_TOTAL);
-        return -2;
-    }
-    return 0;
-}
-
-static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int ACT, int AR>
 static int launch_fwd(const TailFwd& a, hipStream_t st) {

@@ -51,6 +51,24 @@ class BlockTailBwdArgs(C.Structure):
                 ("act", C.c_int), ("dx1", C.c_void_p), ("dout", C.c_void_p), ("lddo", C.c_int)]
 
 
+class BlockQkvArgs(C.Structure):
+    """mirror of cvft_block_qkv_args (include/cvft.h)"""
+    _fields_ = [("M", C.c_int), ("x", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("W_fwd", C.c_void_p), ("bias", C.c_void_p), ("N3", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int), ("Bb", C.c_void_p), ("ldb", C.c_int),
+                ("alpha", C.c_float), ("p", C.c_float), ("seed", C.c_void_p), ("sites", C.c_uint * 3),
+                ("U", C.c_void_p), ("ldu", C.c_int), ("xd", C.c_void_p * 3), ("y_out", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int)]
+
+
+class BlockQkvBwdArgs(C.Structure):
+    """mirror of cvft_block_qkv_bwd_args (include/cvft.h)"""
+    _fields_ = [("M", C.c_int), ("dY", C.c_void_p), ("lddy", C.c_int), ("dres", C.c_void_p), ("x", C.c_void_p),
+                ("gamma", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("W_bwd", C.c_void_p), ("N3", C.c_int),
+                ("At", C.c_void_p), ("ldat", C.c_int), ("Bbt", C.c_void_p), ("ldbt", C.c_int),
+                ("alpha", C.c_float), ("p", C.c_float), ("seed", C.c_void_p), ("sites", C.c_uint * 3),
+                ("V", C.c_void_p), ("ldv", C.c_int), ("dx", C.c_void_p)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
@@ -129,6 +147,8 @@ SIGNATURES = {
     "cvft_cast_f32_to_bf16": [_i64, _p, _p, _p],
     "cvft_block_tail_fwd": [C.POINTER(BlockTailArgs), _p],
     "cvft_block_tail_bwd": [C.POINTER(BlockTailBwdArgs), _p],
+    "cvft_block_qkv_fwd": [C.POINTER(BlockQkvArgs), _p],
+    "cvft_block_qkv_bwd": [C.POINTER(BlockQkvBwdArgs), _p],
 }
 
 _lib: Optional[C.CDLL] = None

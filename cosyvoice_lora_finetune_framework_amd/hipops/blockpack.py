@@ -97,3 +97,24 @@ class BlockTailPack:
         self.W_fwd, nf = _streams(fwd)
         self.W_bwd, nb = _streams(bwd)
         assert nf == self.DI // 8 + self.F // 4 and nb == nf
+
+
+class BlockQkvPack:
+    """Frozen stacked q|k|v weight [3N][256] of one estimator block (rows of to_q | to_k | to_v) as the weight streams of
+    cvft_block_qkv_fwd / _bwd (include/cvft.h), plus the bias and the norm1 affine parameters."""
+
+    def __init__(self, wqkv, bias, gamma, beta, eps: float):
+        dev = wqkv.device
+        self.N3, self.D = wqkv.shape
+        assert self.D == 256 and self.N3 == 1536
+        f32 = lambda t, n: (torch.zeros(n, device=dev) if t is None else t.detach().float()).contiguous()
+        self.eps = float(eps)
+        self.gamma, self.beta = f32(gamma, self.D), f32(beta, self.D)
+        self.bias = None if bias is None else f32(bias, self.N3)
+        Wn = pack_a(wqkv, "natural")                                 # [48 nt][16 ks]
+        WTn = pack_a(wqkv.detach().t().contiguous(), "natural")      # [8 ct][96 ks]
+        fwd = [[Wn[12 * w:12 * (w + 1)]] for w in range(4)]                                  # [nt][ks]
+        bwd = [[WTn[:, 24 * w:24 * (w + 1)].permute(1, 0, 2, 3)] for w in range(4)]          # [ks][ct]
+        self.W_fwd, nf = _streams(fwd)
+        self.W_bwd, nb = _streams(bwd)
+        assert nf == nb == self.N3 // 8

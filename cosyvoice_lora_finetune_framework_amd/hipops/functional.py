@@ -1390,6 +1390,131 @@ class BlockTailFn(torch.autograd.Function):
         return do, dx1, None, None
 
 
+class BlockQkvFn(torch.autograd.Function):
+    """(x, q, k, v) with q|k|v = stacked LoRA projections of norm1(x): LayerNorm, the adapters' rank-side products under
+    lora_dropout and the projection in ONE launch (cvft_block_qkv_fwd); backward = V, the dgrad with the masked side term and the
+    LayerNorm backward joined with the residual branch's gradient in ONE launch (cvft_block_qkv_bwd).  The adapter gradients go
+    through the LoraGradSink exactly as LinearQKVStackedFn's (dA_t = V_t^T drop_t(y), dB = dY^T U)."""
+
+    @staticmethod
+    def forward(ctx, x, Aq, Bq, Ak, Bk, Av, Bv, pack, ops, scale: float, drop_p: float):
+        x = _c(x)
+        M = x.shape[0]
+        A, At, Bb, Bbt = ops
+        N3 = pack.N3
+        need = any(ctx.needs_input_grad[:7])
+        Y = torch.empty((M, N3), dtype=x.dtype, device=x.device)
+        U = torch.empty((M, 48), dtype=x.dtype, device=x.device)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        a = cb.BlockQkvArgs()
+        a.M, a.x, a.gamma, a.beta, a.eps, a.mean, a.rstd = M, ptr(x), ptr(pack.gamma), ptr(pack.beta), pack.eps, ptr(mean), ptr(rstd)
+        a.W_fwd, a.bias, a.N3 = ptr(pack.W_fwd), ptr(pack.bias), N3
+        a.A, a.lda, a.Bb, a.ldb = ptr(A), A.stride(0), ptr(Bb), Bb.stride(0)
+        a.alpha, a.p = float(scale), float(drop_p)
+        xds, y = [], None
+        ctx.sites = None
+        if drop_p > 0:
+            sites = [_next_drop_site() for _ in range(3)]
+            ctx.sites = sites
+            a.seed = ptr(_DROPOUT["seed"])
+            for i, st in enumerate(sites):
+                a.sites[i] = st
+            if need:
+                xds = [torch.empty_like(x) for _ in range(3)]
+                for i, t in enumerate(xds):
+                    a.xd[i] = t.data_ptr()
+        elif need:
+            y = torch.empty_like(x)
+            a.y_out = ptr(y)
+        a.U, a.ldu, a.Y, a.ldy = ptr(U), U.stride(0), ptr(Y), Y.stride(0)
+        with _Bracket("block_qkv_fwd", 2.0 * M * 256 * (N3 + 48) + 2.0 * M * 48 * 512, 2.0 * (M * (256 + N3) + 256 * N3)):
+            check(lib().cvft_block_qkv_fwd(C.byref(a), stream()), "cvft_block_qkv_fwd")
+        ctx.pack, ctx.ops, ctx.scale, ctx.p = pack, ops, float(scale), float(drop_p)
+        ctx.refs = ((Aq, Bq), (Ak, Bk), (Av, Bv))
+        ctx.nx = len(xds)
+        ctx.save_for_backward(x, mean, rstd, U, y, *xds)
+        N = N3 // 3
+        return x.view_as(x), Y[:, :N], Y[:, N:2 * N], Y[:, 2 * N:]
+
+    @staticmethod
+    def backward(ctx, dres, dq, dk, dv):
+        x, mean, rstd, U, y, *xds = ctx.saved_tensors
+        pack, (A, At, Bb, Bbt), scale, p = ctx.pack, ctx.ops, ctx.scale, ctx.p
+        M, N3 = x.shape[0], pack.N3
+        N = N3 // 3
+        es = dq.element_size()
+        if (dq.stride() == (N3, 1) and dk.stride() == (N3, 1) and dv.stride() == (N3, 1)
+                and dk.data_ptr() == dq.data_ptr() + N * es and dv.data_ptr() == dq.data_ptr() + 2 * N * es):
+            dY = torch.as_strided(dq, (M, N3), (N3, 1), dq.storage_offset())      # the attention backward's fused buffer
+        else:
+            dY = torch.cat([dq, dk, dv], 1)
+        V = torch.empty((M, 48), dtype=x.dtype, device=x.device)
+        dx = torch.empty_like(x)
+        a = cb.BlockQkvBwdArgs()
+        a.M, a.dY, a.lddy, a.dres, a.x = M, ptr(dY), dY.stride(0), ptr(None if dres is None else _c(dres)), ptr(x)
+        a.gamma, a.mean, a.rstd, a.W_bwd, a.N3 = ptr(pack.gamma), ptr(mean), ptr(rstd), ptr(pack.W_bwd), N3
+        a.At, a.ldat, a.Bbt, a.ldbt = ptr(At), At.stride(0), ptr(Bbt), Bbt.stride(0)
+        a.alpha, a.p = scale, p
+        if p > 0:
+            a.seed = ptr(_DROPOUT["seed"])
+            for i, st in enumerate(ctx.sites):
+                a.sites[i] = st
+        a.V, a.ldv, a.dx = ptr(V), V.stride(0), ptr(dx)
+        with _Bracket("block_qkv_bwd", 2.0 * M * N3 * (256 + 48) + 2.0 * M * 48 * 256, 2.0 * (M * (N3 + 3 * 256) + 256 * N3)):
+            check(lib().cvft_block_qkv_bwd(C.byref(a), stream()), "cvft_block_qkv_bwd")
+        if not any(ctx.needs_input_grad[1:7]):
+            return (dx, None, None, None, None, None, None, None, None, None, None)
+        # adapter gradients: dA_t = V_t^T drop_t(y) (three rank-16 products, or one rank-48 product on y when p == 0), dB = dY^T U
+        r3, K = 48, x.shape[1]
+        r = r3 // 3
+        sink = LoraGradSink.active
+        grads = [(a_.grad, b_.grad) for a_, b_ in ctx.refs]
+        direct = all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for pair in grads for g in pair)
+        srcs = xds if ctx.nx == 3 else [y, y, y]
+        if sink is not None and direct and sink.side is None:
+            defer = sink.will_defer(x, dY)
+            rpa, nsa = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, K)
+            rpb_, nsb = LoraGradSink.plan_deferred(M) if defer else LoraGradSink.plan(M, N3)
+            wsB = sink.workspace(ctx.refs[0][1], nsb * 9)
+            keep = [sink.workspace(ctx.refs[i][0], nsa) for i in range(3)]
+            if defer:
+                for i in range(3):
+                    sink.defer_one(M, r, K, srcs[i], V[:, i * r:(i + 1) * r], keep[i], 0, rpa, keep=(V,))
+                sink.defer_one(M, r3, N3, dY, U, wsB, 1, rpb_)
+            else:
+                probs = (cb.RankProb * 3)()
+                for i in range(3):
+                    Vi = V[:, i * r:(i + 1) * r]
+                    probs[i].C, probs[i].Wd, probs[i].ldw = K, srcs[i].data_ptr(), srcs[i].stride(0)
+                    probs[i].Rk, probs[i].ldr, probs[i].part = Vi.data_ptr(), V.stride(0), keep[i].data_ptr()
+                    probs[i].transpose_out, probs[i].rows_per_block = 0, rpa
+                check(lib().cvft_lora_rank_partial_multi(M, r, 3, probs, stream()), "cvft_lora_rank_partial_multi")
+                check(lib().cvft_lora_rank_partial(dt(dY), M, N3, r3, ptr(dY), dY.stride(0), ptr(U), U.stride(0), ptr(wsB), 1, rpb_,
+                                                   stream()), "cvft_lora_rank_partial")
+            for i, (gA, _) in enumerate(grads):
+                sink.add(keep[i], gA, gA.numel(), nsa)
+            for i, (_, gB) in enumerate(grads):
+                sink.add_block(wsB.data_ptr() + (i * N * r3 + i * r) * 4, gB, N, r, r3, N3 * r3, nsb)
+            sink.keep.append((srcs, V, U, dY))
+            out = [None] * 6
+        else:
+            out = []
+            for i, (gA, gB) in enumerate(grads):
+                tA = gA if direct else torch.zeros((r, K), dtype=torch.float32, device=x.device)
+                tB = gB if direct else torch.zeros((N, r), dtype=torch.float32, device=x.device)
+                rank_accum(srcs[i], V[:, i * r:(i + 1) * r], tA, False)
+                rank_accum(dY[:, i * N:(i + 1) * N], U[:, i * r:(i + 1) * r], tB, True)
+                out += [None, None] if direct else [tA, tB]
+        return (dx, *out, None, None, None, None)
+
+
+def block_qkv(x, loras, pack, ops, scale: float, drop_p: float = 0.0):
+    """-> (x_residual, q, k, v); loras = ((Aq, Bq), (Ak, Bk), (Av, Bv)) masters, ops = their stacked bf16 shadows (A, At, Bb, Bbt)."""
+    (Aq, Bq), (Ak, Bk), (Av, Bv) = loras
+    return BlockQkvFn.apply(x, Aq, Bq, Ak, Bk, Av, Bv, pack, ops, scale, drop_p)
+
+
 def block_tail(o, x0, pack, act: str = "gelu_erf"):
     """x0 [M, 256] bf16 residual stream, o [M, DI] attention output (or None: feed-forward half only)."""
     return BlockTailFn.apply(o, x0, pack, act)
@@ -1401,6 +1526,7 @@ def can_block_tail(x: torch.Tensor, d_ff: int, d_inner: int) -> bool:
 
 
 BLOCK_FUSE = _os.environ.get("CVFT_BLOCK_FUSE", "1") != "0"
+BLOCK_QKV_FUSE = _os.environ.get("CVFT_BLOCK_QKV_FUSE", "1") != "0"      # first half of the block (norm1 + stacked LoRA q|k|v)
 
 
 # ---------------------------------------------------------------------------------

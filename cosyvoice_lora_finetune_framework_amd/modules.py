@@ -329,10 +329,44 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, B, T, length, gelu: str, iso_len: int = 0):
         a = self.attn1
-        x, y = hip_layernorm_fork(self.norm1, x, consumers=(a.to_q, a.to_k, a.to_v))
-        q, k, v = hip_qkv(a.to_q, a.to_k, a.to_v, y)
+        head = self._head_fused(x)
+        if head is not None:           # norm1 + stacked LoRA q|k|v projection as one row-tile chain launch each way
+            x, q, k, v = HF.block_qkv(x, *head)
+        else:
+            x, y = hip_layernorm_fork(self.norm1, x, consumers=(a.to_q, a.to_k, a.to_v))
+            q, k, v = hip_qkv(a.to_q, a.to_k, a.to_v, y)
         o = HF.attn_bias(q, k, v, B, a.heads, T, length, a.scale, iso_len)
         return self._tail(o, x, gelu)
+
+    def _head_fused(self, x):
+        """(loras, pack, stacked operands, scale, p) for HF.block_qkv when the block's first half can take the row-tile chain
+        kernels: bf16, d = 256, three rank-16 LoRALinear projections of 512 features with one lora_dropout rate, frozen base
+        weights / norm1, and the optimiser-maintained stacked bf16 shadows (optim.FlatAdamW.stack_for)."""
+        a, ln = self.attn1, self.norm1
+        mods = (a.to_q, a.to_k, a.to_v)
+        if not (HF.BLOCK_FUSE and HF.BLOCK_QKV_FUSE and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256
+                and all(isinstance(m, LoRALinear) for m in mods)):
+            return None
+        parts = [_lin_parts(m) for m in mods]
+        if any(p[1].shape != (512, 256) or p[3].shape[0] != 16 or p[1].requires_grad or (p[2] is not None and p[2].requires_grad)
+               for p in parts) or ln.weight.requires_grad or ln.bias.requires_grad:
+            return None
+        drops = [p[6].p if _lora_dropout_on(m, p[6]) else 0.0 for m, p in zip(mods, parts)]
+        if not (drops[0] == drops[1] == drops[2]) or any(d > 0 and type(p[6]) is not nn.Dropout for d, p in zip(drops, parts)):
+            return None
+        packs = [_cached(p[0], "lin", p[0].weight, x.dtype, lambda p=p: HF.LinearPack(p[1], p[2], x.dtype)) for p in parts]
+        loras = [(p[3], p[4]) for p in parts]
+        st = HF._qkv_stacked_operands(x, packs, loras, [p[5] for p in parts])
+        if st is None:
+            return None
+        ws, ops = st
+        tag = (ws.Wf.data_ptr(), ws.Wf._version, ln.weight._version, ln.weight.data_ptr(), ln.bias._version)
+        hit = self.__dict__.get("_cvft_head")
+        if hit is None or hit[0] != tag:
+            from .hipops.blockpack import BlockQkvPack
+            hit = (tag, BlockQkvPack(ws.Wf, ws.bias, ln.weight, ln.bias, ln.eps))
+            self.__dict__["_cvft_head"] = hit
+        return tuple(loras), hit[1], ops, parts[0][5], drops[0]
 
     def _tail_pack(self):
         """Packed frozen weights of the block's second half for the row-tile chain kernels, or None when a layer of it carries

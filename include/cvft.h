@@ -401,6 +401,47 @@ typedef struct {
 } cvft_block_tail_bwd_args;
 int cvft_block_tail_bwd(const cvft_block_tail_bwd_args* a, void* stream);
 
+/* First half of the same block (matcha transformer.py:255-289 == modules.py:349-361: norm1, the three LoRALinear projections
+ * to_q / to_k / to_v of lora.py:64-76 with their lora_dropout, stacked), forward and backward, as row-tile chain kernels:
+ *   fwd:  y = LN(x);   U[m, 16 t + j] = alpha / (1 - p) * sum_k keep_t[m, k] y[m, k] A[16 t + j, k]   (t = q, k, v);
+ *         Y[m, n] = sum_k y[m, k] Wqkv[n, k] + bias[n] + sum_r U[m, r] Bb[n, r];   xd[t] = keep_t y / (1 - p)   (p > 0)
+ *   bwd:  V = alpha * dY Bb;   dy[m, c] = sum_n dY[m, n] Wqkv[n, c] + sum_t keep_t[m, c] / (1 - p) * sum_j V[m, 16 t + j] A[16 t + j, c];
+ *         dx = dres + LN'(dy)
+ * keep_t = the counter-based mask of (seed, sites[t]) over the [M, 256] elements (index m * 256 + k), the one cvft_skinny_dropout
+ * and cvft_gemm's masked rank extension draw -- so this form and the launch-per-stage form agree mask for mask; p == 0: no masks.
+ * Wqkv [3N][256] = rows of to_q | to_k | to_v (3N = 1536); A [48][lda] = the adapters' lora_A stacked, At its transpose [256][48];
+ * Bb [3N][48] block-diagonal (rows of adapter t hold its lora_B in columns 16 t .. 16 t + 15, zeros elsewhere), Bbt its transpose
+ * -- the optimiser's bf16 shadows (optim.FlatAdamW.stack_for), read in place.
+ * W_fwd: per wave w the fragments natural(Wqkv, 12 w + i, ks) for i < 12, ks < 16;  W_bwd: natural(Wqkv^T [256][3N], ct, 24 w + k)
+ * for k < 24, ct < 8 (order [k][ct]);  each [4 waves][192 fragments] + 32 fragments of padding (hipops/blockpack.py).
+ * Adapter gradients stay with cvft_lora_rank_partial*: dA_t = V_t^T xd[t] (or y_out when p == 0), dB = dY^T U. */
+typedef struct {
+    int M;
+    const void* x;                       /* [M][256] block input */
+    const float* gamma; const float* beta; float eps;      /* norm1 */
+    float* mean; float* rstd;            /* [M] out (saved for backward) */
+    const void* W_fwd; const float* bias; int N3;          /* bias [3N] or NULL */
+    const void* A; int lda; const void* Bb; int ldb;
+    float alpha; float p; const int64_t* seed; unsigned sites[3];
+    void* U; int ldu;                    /* [M][48] out */
+    void* xd[3];                         /* p > 0: dropped copies [M][256] (entries may be NULL) */
+    void* y_out;                         /* p == 0: LN(x) [M][256] or NULL */
+    void* Y; int ldy;                    /* [M][3N] out */
+} cvft_block_qkv_args;
+int cvft_block_qkv_fwd(const cvft_block_qkv_args* a, void* stream);
+typedef struct {
+    int M;
+    const void* dY; int lddy;            /* [M][3N] gradient of q | k | v */
+    const void* dres;                    /* [M][256] gradient of the residual branch, or NULL */
+    const void* x; const float* gamma; const float* mean; const float* rstd;
+    const void* W_bwd; int N3;
+    const void* At; int ldat; const void* Bbt; int ldbt;
+    float alpha; float p; const int64_t* seed; unsigned sites[3];
+    void* V; int ldv;                    /* [M][48] out */
+    void* dx;                            /* [M][256] out */
+} cvft_block_qkv_bwd_args;
+int cvft_block_qkv_bwd(const cvft_block_qkv_bwd_args* a, void* stream);
+
 /* Diagnostics (development only): cycle stamps of the default 128x128 LDS-DMA GEMM kernel (CVFT_GLDS_BIG=15 launches its
  * stamped build; tools/glds_stamps.py); host_out receives 256 uint64. */
 int cvft_debug_glds_stamps(unsigned long long* host_out);

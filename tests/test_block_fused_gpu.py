@@ -96,3 +96,116 @@ def test_block_tail_equals_launch_per_stage_form():
             HF.BLOCK_FUSE = True
     for a, b in zip(res[True], res[False]):
         assert rel(a, b) < 1e-2, rel(a, b)
+
+
+def _qkv_case(M, p, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    bq = lambda t: t.to(torch.bfloat16).float()
+    w = dict(wqkv=bq(r(1536, 256, sc=256 ** -0.5)), bias=r(1536, sc=0.1), gamma=1.0 + r(256, sc=0.2), beta=r(256, sc=0.1),
+             A=[bq(r(16, 256, sc=0.2)) for _ in range(3)], B=[bq(r(512, 16, sc=0.2)) for _ in range(3)])
+    x = bq(r(M, 256) * 1.5 + 0.2)
+    dY = bq(r(M, 1536))
+    dres = bq(r(M, 256))
+    return w, x, dY, dres
+
+
+def _keep_mask(M, Kd, p, seed, site):
+    """host replica of the counter-based mask (csrc/common.h): SplitMix64 finaliser, one draw per 4 elements, 16-bit fields"""
+    import numpy as np
+    M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mix(z):
+        z = (z + np.uint64(0x9e3779b97f4a7c15)) & M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & M64
+        return z ^ (z >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        key = mix(np.uint64(seed) ^ (np.uint64(site) << np.uint64(32)))
+        grp = np.arange(M * Kd // 4, dtype=np.uint64)
+        rnd = mix((key + grp) & M64)
+    thr = min(65535, int(round(p * 65536)))
+    fields = np.stack([(rnd >> np.uint64(16 * e)) & np.uint64(0xffff) for e in range(4)], 1).reshape(M, Kd)
+    return torch.from_numpy((fields >= thr).astype("float32"))
+
+
+@pytest.mark.parametrize("M,p", [(64, 0.0), (250, 0.05), (37, 0.3), (2000, 0.05)])
+def test_block_qkv_matches_fp64_reference(M, p):
+    """norm1 + stacked LoRA q|k|v with lora_dropout (lora.py:64-76 x 3 over matcha transformer.py:255-262) and its backward, fused
+    launches against an fp64 restatement under host-replicated masks; also V, U and the dropped copies the adapter gradients use."""
+    from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    from cosyvoice_lora_finetune_framework_amd.hipops.blockpack import BlockQkvPack
+    import ctypes as C
+    w, x, dY, dres = _qkv_case(M, p, seed=M)
+    scale = 2.0
+    d = lambda t: t.to(DEV)
+    pack = BlockQkvPack(d(w["wqkv"]), d(w["bias"]), d(w["gamma"]), d(w["beta"]), 1e-5)
+    A = torch.cat(w["A"], 0).to(torch.bfloat16)                        # [48, 256]
+    Bb = torch.zeros(1536, 48)
+    for t in range(3):
+        Bb[512 * t:512 * (t + 1), 16 * t:16 * (t + 1)] = w["B"][t]
+    Bb = Bb.to(torch.bfloat16)
+    ops = (d(A), d(A.t().contiguous()), d(Bb), d(Bb.t().contiguous()))
+    seed_val, sites = 123456789, [5, 9, 11]
+    HF._DROPOUT["seed"] = torch.full((1,), seed_val, dtype=torch.int64, device=DEV)
+    xd_ = d(x.to(torch.bfloat16))
+    Y = torch.empty((M, 1536), dtype=torch.bfloat16, device=DEV)
+    U = torch.empty((M, 48), dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    outs = [torch.empty((M, 256), dtype=torch.bfloat16, device=DEV) for _ in range(3)]
+    a = cb.BlockQkvArgs()
+    a.M, a.x, a.gamma, a.beta, a.eps, a.mean, a.rstd = M, cb.ptr(xd_), cb.ptr(pack.gamma), cb.ptr(pack.beta), 1e-5, cb.ptr(mean), cb.ptr(rstd)
+    a.W_fwd, a.bias, a.N3 = cb.ptr(pack.W_fwd), cb.ptr(pack.bias), 1536
+    a.A, a.lda, a.Bb, a.ldb = cb.ptr(ops[0]), 256, cb.ptr(ops[2]), 48
+    a.alpha, a.p = scale, p
+    if p > 0:
+        a.seed = cb.ptr(HF._DROPOUT["seed"])
+        for i in range(3):
+            a.sites[i] = sites[i]
+            a.xd[i] = outs[i].data_ptr()
+    else:
+        a.y_out = cb.ptr(outs[0])
+    a.U, a.ldu, a.Y, a.ldy = cb.ptr(U), 48, cb.ptr(Y), 1536
+    cb.check(cb.lib().cvft_block_qkv_fwd(C.byref(a), cb.stream()), "fwd")
+    # ---- fp64 reference (y rounded to bf16 where the kernel rounds it; U rounded where it is stored)
+    xr = x.double()
+    y = F.layer_norm(xr, (256,), w["gamma"].double(), w["beta"].double(), 1e-5).to(torch.bfloat16).double()
+    keep = [(_keep_mask(M, 256, p, seed_val, sites[t]).double() if p > 0 else torch.ones(M, 256, dtype=torch.float64)) for t in range(3)]
+    inv = 1.0 / (1.0 - p)
+    Uref = torch.cat([scale * inv * ((keep[t] * y) @ w["A"][t].double().t()) for t in range(3)], 1)
+    Yref = y @ w["wqkv"].double().t() + w["bias"].double() + Uref.to(torch.bfloat16).double() @ Bb.double().t()
+    assert rel(U, Uref) < 1e-2 and rel(Y, Yref) < 1e-2, (rel(U, Uref), rel(Y, Yref))
+    assert rel(mean, xr.mean(1)) < 1e-5
+    if p > 0:
+        for t in range(3):
+            assert rel(outs[t], keep[t] * y * inv) < 5e-3
+    else:
+        assert rel(outs[0], y) < 5e-3
+    # ---- backward
+    V = torch.empty((M, 48), dtype=torch.bfloat16, device=DEV)
+    dx = torch.empty((M, 256), dtype=torch.bfloat16, device=DEV)
+    dYd, dresd = d(dY.to(torch.bfloat16)), d(dres.to(torch.bfloat16))
+    b = cb.BlockQkvBwdArgs()
+    b.M, b.dY, b.lddy, b.dres, b.x = M, cb.ptr(dYd), 1536, cb.ptr(dresd), cb.ptr(xd_)
+    b.gamma, b.mean, b.rstd, b.W_bwd, b.N3 = cb.ptr(pack.gamma), cb.ptr(mean), cb.ptr(rstd), cb.ptr(pack.W_bwd), 1536
+    b.At, b.ldat, b.Bbt, b.ldbt = cb.ptr(ops[1]), 48, cb.ptr(ops[3]), 1536
+    b.alpha, b.p = scale, p
+    if p > 0:
+        b.seed = cb.ptr(HF._DROPOUT["seed"])
+        for i in range(3):
+            b.sites[i] = sites[i]
+    b.V, b.ldv, b.dx = cb.ptr(V), 48, cb.ptr(dx)
+    cb.check(cb.lib().cvft_block_qkv_bwd(C.byref(b), cb.stream()), "bwd")
+    Vref = scale * dY.double() @ Bb.double()
+    dy = dY.double() @ w["wqkv"].double()
+    Vb = Vref.to(torch.bfloat16).double()
+    for t in range(3):
+        dy = dy + keep[t] * inv * (Vb[:, 16 * t:16 * (t + 1)] @ w["A"][t].double())
+    xq = xr.clone().requires_grad_(True)
+    yq = F.layer_norm(xq, (256,), w["gamma"].double(), w["beta"].double(), 1e-5)
+    (yq * dy).sum().backward()
+    dxref = dres.double() + xq.grad
+    assert rel(V, Vref) < 1e-2, rel(V, Vref)
+    assert rel(dx, dxref) < 1.5e-2, rel(dx, dxref)
+    HF._DROPOUT["seed"] = None
