@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 extern "C" void cvft_set_error(const char* fmt, ...);
 extern "C" void cvft_set_kernel_label(const char* fmt, ...);
+extern "C" int cvft_concurrent_chains(void);
 
 #define CVFT_CHECK_ARG(cond, ...)                      \
     do {                                               \

@@ -560,7 +560,11 @@ int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
     // 25 % less L2 -> LDS traffic per FLOP, two k-tiles in flight.  Measured cold (tools/bench_cfg.py), 128x128 -> 128x256 ->
     // 96x256: 5328x1024x4096 631 -> 696 -> 709 TFLOP/s, x1024x3072 584 -> 638 -> 652, x1024x1024 485 -> 507 -> 501; on the
     // multi-round shapes (N = 3072 / 4096) 128x256 is equal and 96x256 10-15 % slower, so they keep two 128x128 blocks per CU.
-    static const int wide_on = getenv("CVFT_GLDS_WIDE") ? atoi(getenv("CVFT_GLDS_WIDE")) : 1;
+    // ... when this chain has the chip to itself: the 96x256 tile owns its CU (12 waves, 135 KB of LDS), so with other chains in
+    // flight (joint mode: LLM + 2 x Flow) their workgroups wait for whole CUs to drain; two co-residing 128x128 blocks per CU are
+    // slower alone and faster in the step (same-box A/B, joint B = 16: 23.62 -> 23.16 ms, 22.70 on a second box).  CVFT_GLDS_WIDE=0/1 forces.
+    static const int wide_env = getenv("CVFT_GLDS_WIDE") ? atoi(getenv("CVFT_GLDS_WIDE")) : -1;
+    const int wide_on = wide_env >= 0 ? wide_env : (cvft_concurrent_chains() >= 3 ? 0 : 1);
     if (big && wide_on && nk >= 8 && t64 >= 1000 && p.N >= 256 && (long)((p.M + 95) / 96) * ((p.N + 255) / 256) <= 256)
         return glds_launch_cfg<96, 256, 3, 4, 0, 3>(p, st);
     if (big && (nk >= 8 || big_env == 12) && t64 >= 1000) return glds_launch_cfg<128, 128, 4, 2, 0, 2>(p, st);

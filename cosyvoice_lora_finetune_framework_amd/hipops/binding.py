@@ -95,6 +95,8 @@ _i, _f, _p, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_int64
 # name -> argtypes (restype is int unless noted).  Must list every symbol of include/cvft.h.
 SIGNATURES = {
     "cvft_version": [],
+    "cvft_set_concurrent_chains": [_i],
+    "cvft_concurrent_chains": [],
     "cvft_last_error": [],
     "cvft_gemm": [C.POINTER(GemmArgs), _p],
     "cvft_gemm_last_kernel": [],

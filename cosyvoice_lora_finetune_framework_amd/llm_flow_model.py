@@ -76,6 +76,8 @@ class JointLLMFlowModel(nn.Module):
         do_flow = self.training_mode in ('joint', 'flow_only')
         chains = [('llm', k) for k in range(len(parts['llm']))] * do_llm + [('flow', k) for k in range(len(parts['flow']))] * do_flow
         use_streams = BRANCH_STREAMS and torch.cuda.is_available() and len(chains) > 1
+        if torch.cuda.is_available():      # tile-shape hint for the kernels that would own a whole CU (cvft.h)
+            HF.lib().cvft_set_concurrent_chains(len(chains) if use_streams else 1)
         HF.LoraGradSink.uses_hint = max(len(v) for v in parts.values())      # chains that will run the same adapters
         cur = torch.cuda.current_stream() if use_streams else None
         results = {}

@@ -37,6 +37,11 @@ enum { CVFT_ACT_NONE = 0, CVFT_ACT_RELU = 1, CVFT_ACT_SILU = 2, CVFT_ACT_GELU_ER
 
 int cvft_version(void);
 const char* cvft_last_error(void);
+/* Execution hint (performance only, never results): the number of independent kernel chains the caller keeps in flight on
+ * separate streams (llm_flow_model.JointLLMFlowModel: LLM + Flow sub-batches).  With >= 3, kernels that would own a whole CU
+ * give way to tile shapes that share it.  Returns the previous value. */
+int cvft_set_concurrent_chains(int n);
+int cvft_concurrent_chains(void);
 
 /* ---------------------------------------------------------------------------------
  * Tap-GEMM with fused rank-r LoRA side path and epilogue.
