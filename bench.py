@@ -209,9 +209,10 @@ def trainer_run(a, jm, workload, dev, dtype, rank, world, steps, warmup):
     from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, SyntheticLoader, Trainer
     module = JointLightningModule(workload, learning_rate=2e-4, min_lr=1e-6, warmup_steps=10, weight_decay=0.01,
                                   model=jm, numerics=Numerics(dtype=dtype))
-    # per-rank host budget: the replay thread and the prefetch thread need a core each; torch's intra-op pool gets the rest
-    # of this rank's share of the host (cores // world), so eight ranks do not oversubscribe one host
-    torch.set_num_threads(max(1, min(host_cores() // max(world, 1), 16)))
+    # per-rank host budget (dp.host_budget, applied by Trainer.fit when world > 1): cores // world per rank, the replay thread and
+    # the prefetch thread on cores of their own, torch's intra-op pool on the rest -- eight ranks do not oversubscribe one host
+    if world == 1:
+        torch.set_num_threads(max(1, min(host_cores(), 16)))
     B, T = a.batch, a.frames
     loader = SyntheticLoader(warmup + steps, B, T, seed=1234, ragged=a.ragged, rank=rank, cache=True)
     marks = {}
@@ -388,6 +389,7 @@ def main():
         # launches by 1.2-1.5x, which is a property of the step, not of the kernel the roofline is about.
         from cosyvoice_lora_finetune_framework_amd import llm_flow_model as J
         branch_streams, J.BRANCH_STREAMS = J.BRANCH_STREAMS, False
+        J.CHAINS_HINT = HF.lib().cvft_concurrent_chains()      # same tile choices as the timed (multi-chain) step
         HF.PROFILE = []
         torch.cuda.synchronize()
         from cosyvoice_lora_finetune_framework_amd.hipops import binding as _cb
@@ -410,6 +412,7 @@ def main():
         opt.zero_grad()
         torch.cuda.synchronize()
         J.BRANCH_STREAMS = branch_streams
+        J.CHAINS_HINT = 0
         groups = {}
         for rec in HF.PROFILE:
             # the masked-extension instantiation (",xdrop": lora_dropout dgrad) is the same kernel with a different rank tail

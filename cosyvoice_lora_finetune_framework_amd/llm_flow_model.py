@@ -33,6 +33,7 @@ SPLIT_MIN_PART = int(os.environ.get("CVFT_SPLIT_MIN_PART", "4"))      # utteranc
 # flow_only has no LLM chain to overlap with: two Flow chains of 4 utterances are SLOWER than one of 8 (BASELINE configs[1], B = 8:
 # 13.89 vs 13.56 ms/step, same-box A/B), two of 8 faster than one of 16 (18.1 vs 18.6)
 SPLIT_MIN_PART_FLOW_ONLY = int(os.environ.get("CVFT_SPLIT_MIN_PART_FLOW_ONLY", "8"))
+CHAINS_HINT = 0        # > 0: pin the concurrent-chains hint (bench.py's single-stream roofline leg times the kernels of the three-chain step)
 BRANCH_STREAMS = os.environ.get("CVFT_BRANCH_STREAMS", "1") != "0"      # LLM branch on a second stream (joint mode): 35.9 -> 30.1 ms/step
 
 
@@ -77,7 +78,7 @@ class JointLLMFlowModel(nn.Module):
         chains = [('llm', k) for k in range(len(parts['llm']))] * do_llm + [('flow', k) for k in range(len(parts['flow']))] * do_flow
         use_streams = BRANCH_STREAMS and torch.cuda.is_available() and len(chains) > 1
         if torch.cuda.is_available():      # tile-shape hint for the kernels that would own a whole CU (cvft.h)
-            HF.lib().cvft_set_concurrent_chains(len(chains) if use_streams else 1)
+            HF.lib().cvft_set_concurrent_chains(CHAINS_HINT if CHAINS_HINT else (len(chains) if use_streams else 1))
         HF.LoraGradSink.uses_hint = max(len(v) for v in parts.values())      # chains that will run the same adapters
         cur = torch.cuda.current_stream() if use_streams else None
         results = {}
