@@ -393,6 +393,9 @@ static int launch_bwd(const TailBwd& a, hipStream_t st) {
     return 0;
 }
 
+int block_tail_lean_fwd_launch(const cvft_block_tail_args* p, int DI, void* stream);       // block_lean.hip
+int block_tail_lean_bwd_launch(const cvft_block_tail_bwd_args* p, int DI, void* stream);
+
 extern "C" int cvft_block_tail_fwd(const cvft_block_tail_args* p, void* stream) {
     CVFT_CHECK_ARG(p && p->M > 0 && p->F > 0 && p->F % 128 == 0 && p->F <= BF_MAX_F, "cvft_block_tail_fwd: need M > 0, F %% 128 == 0, F <= 2048 (F=%d)", p ? p->F : -1);
     CVFT_CHECK_ARG(p->x1 && p->out && p->W_fwd && p->b1 && p->b2 && p->gamma && p->beta && p->mean && p->rstd, "cvft_block_tail_fwd: null operand");
@@ -402,6 +405,12 @@ extern "C" int cvft_block_tail_fwd(const cvft_block_tail_args* p, void* stream) 
                              "cvft_block_tail_fwd: output projection needs x0, bo, DI in {256, 512}, 16-byte aligned o rows");
     CVFT_CHECK_ARG(al16(p->x1) && al16(p->out) && al16(p->W_fwd) && al16(p->b1) && al16(p->b2) && al16(p->gamma) && al16(p->beta) &&
                    (!p->z || al16(p->z)) && (!p->x0 || al16(p->x0)) && (!p->bo || al16(p->bo)), "cvft_block_tail_fwd: operands must be 16-byte aligned");
+    if (p->lean) {
+        const int rc = block_tail_lean_fwd_launch(p, DI, stream);
+        if (rc) return rc;
+        CVFT_LAUNCH_CHECK("cvft_block_tail_fwd (lean)");
+        return 0;
+    }
     TailFwd a;
     a.M = p->M; a.o = (const bf16_t*)p->o; a.ldo = p->ldo; a.x0 = (const bf16_t*)p->x0;
     a.Wst = (const bf16x8*)p->W_fwd; a.wave_frags = DI / 8 + p->F / 4; a.bo = p->bo; a.x1 = (bf16_t*)p->x1;
@@ -425,6 +434,12 @@ extern "C" int cvft_block_tail_bwd(const cvft_block_tail_bwd_args* p, void* stre
     const int DI = p->dout ? p->DI : 0;
     if (p->dout) CVFT_CHECK_ARG((DI == 256 || DI == 512) && p->lddo % 4 == 0 && al16(p->dout), "cvft_block_tail_bwd: output-projection dgrad needs DI in {256, 512}, aligned dout");
     CVFT_CHECK_ARG(al16(p->x1) && al16(p->dy) && al16(p->gamma) && al16(p->z) && al16(p->W_bwd) && al16(p->dx1), "cvft_block_tail_bwd: operands must be 16-byte aligned");
+    if (p->lean) {
+        const int rc = block_tail_lean_bwd_launch(p, DI, stream);
+        if (rc) return rc;
+        CVFT_LAUNCH_CHECK("cvft_block_tail_bwd (lean)");
+        return 0;
+    }
     TailBwd a;
     a.M = p->M; a.x1 = (const bf16_t*)p->x1; a.dy = (const bf16_t*)p->dy; a.gamma = p->gamma; a.mean = p->mean; a.rstd = p->rstd;
     a.z = (const bf16_t*)p->z; a.Wst = (const bf16x8*)p->W_bwd; a.wave_frags = p->F / 4 + p->DI / 8; a.F = p->F;

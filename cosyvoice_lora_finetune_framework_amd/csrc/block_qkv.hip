@@ -41,8 +41,12 @@ __device__ __forceinline__ bf16x8 bq_mask8(bf16x8 v, unsigned long long key, uns
     return *reinterpret_cast<bf16x8*>(&u);
 }
 
-// DROP: lora_dropout masks on (p > 0); otherwise the adapters see y itself
-template <bool DROP>
+// DROP: lora_dropout masks on (p > 0); otherwise the adapters see y itself.
+// NS (1 | 2): output-column split over gridDim.y workgroups per row tile -- the projection's columns are independent, so half
+// (blockIdx.y) streams half of the weight (its waves' n-tiles 24 half + 6 wave + i of the same packed stream) and repeats the
+// cheap part (LayerNorm, rank-side product); only half 0 writes mean / rstd / U / the dropped copies.  At M = 2000 a launch is
+// 63 row tiles on 256 CUs and stream-bound per CU: two workgroups per tile halve the bytes per CU.
+template <bool DROP, int NS>
 __global__ __launch_bounds__(256, 1) void block_qkv_fwd_kernel(QkvFwd a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -51,6 +55,8 @@ __global__ __launch_bounds__(256, 1) void block_qkv_fwd_kernel(QkvFwd a) {
     const int row = min(m0 + m, a.M - 1);
     const bool rvalid = m0 + m < a.M;
     const unsigned touched = BF_TOUCH ? bf_touch_stream(a.Wst, 4 * a.wave_frags) : 0u;
+    const int half = NS > 1 ? blockIdx.y : 0;
+    const bool writer = half == 0;
 
     // ---- loads in the order they are needed: x, small parameters (-> LDS), adapter operands, then the ring
     bf16x4 xb[2][4];
@@ -77,18 +83,20 @@ __global__ __launch_bounds__(256, 1) void block_qkv_fwd_kernel(QkvFwd a) {
         afv[k] = *reinterpret_cast<const bf16x8*>(a.A + (size_t)(32 + (m & 15)) * a.lda + 16 * ks + 8 * h);
     }
     // B_blk fragments of the wave's n-tiles (chained k order: element j = rank 8 (j>>2) + 4 h + (j&3) of the tile's adapter)
-    constexpr int ntw = 12;                            // n-tiles per wave (3N = 1536)
+    constexpr int ntw = 12 / NS;                       // n-tiles per wave (3N = 1536)
     constexpr int tiles_per_adapter = 16;              // (3N / 3) / 32
-    bf16x8 bext[12];
+    const int nt0 = (48 / NS) * half + ntw * wave;     // this wave's first n-tile
+    bf16x8 bext[ntw];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int nt = wave * ntw + i;
+    for (int i = 0; i < ntw; ++i) {
+        const int nt = nt0 + i;
         const int t = nt / tiles_per_adapter;
         const bf16_t* bp = a.Bb + (size_t)(32 * nt + m) * a.ldb + 16 * t + 4 * h;
         const bf16x4 lo = *reinterpret_cast<const bf16x4*>(bp), hi = *reinterpret_cast<const bf16x4*>(bp + 8);
         bext[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
-    const bf16x8* nx = a.Wst + (size_t)wave * a.wave_frags * 64 + lane;
+    // (the packed stream is [48 n-tiles][16 k-steps] in tile order: tile nt0 starts at fragment 16 nt0)
+    const bf16x8* nx = a.Wst + (size_t)nt0 * BF_KS * 64 + lane;
     bf16x8 ring[BF_RING];
 #pragma unroll
     for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void block_qkv_fwd_kernel(QkvFwd a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const float d = (float)xb[c2][g][i] - mean; s += d * d; }
     const float rstd = rsqrtf(bf_rowsum(smem, 1, wave, lane, s) * (1.f / BF_D) + a.eps);
-    if (wave == 0 && lane < 32 && rvalid) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    if (writer && wave == 0 && lane < 32 && rvalid) { a.mean[row] = mean; a.rstd[row] = rstd; }
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
@@ -150,14 +158,14 @@ __global__ __launch_bounds__(256, 1) void block_qkv_fwd_kernel(QkvFwd a) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 vm[t] = DROP ? bq_mask8(yk, keys[t], e0, thr) : yk;
-                if (DROP && a.xd[t] != nullptr && rvalid) {
+                if (DROP && writer && a.xd[t] != nullptr && rvalid) {
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)vm[t][e] * inv_keep);
                     *reinterpret_cast<bf16x8*>(a.xd[t] + e0) = o;
                 }
             }
-            if (!DROP && a.y_out != nullptr && rvalid) *reinterpret_cast<bf16x8*>(a.y_out + e0) = yk;
+            if (!DROP && writer && a.y_out != nullptr && rvalid) *reinterpret_cast<bf16x8*>(a.y_out + e0) = yk;
             const bf16x8 aq = m < 16 ? af01[k] : zf, ak = m < 16 ? zf : af01[k], av = m < 16 ? afv[k] : zf;
             u01 = mfma32(aq, vm[0], u01);
             u01 = mfma32(ak, vm[1], u01);
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void block_qkv_fwd_kernel(QkvFwd a) {
     bf16x8 hb01[2], hbv;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { hb01[0][i] = (bf16_t)u01[i]; hb01[1][i] = (bf16_t)u01[8 + i]; hbv[i] = (bf16_t)uv[i]; }
-    if (wave == 0 && rvalid) {
+    if (writer && wave == 0 && rvalid) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const bf16x4 o = {(bf16_t)u01[4 * g], (bf16_t)u01[4 * g + 1], (bf16_t)u01[4 * g + 2], (bf16_t)u01[4 * g + 3]};
@@ -202,14 +210,14 @@ __global__ __launch_bounds__(256, 1) void block_qkv_fwd_kernel(QkvFwd a) {
 #pragma unroll
     for (int i0 = 0; i0 < ntw; i0 += 2) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int i = i0 + half;
-            const int nt = wave * ntw + i;
+        for (int hh = 0; hh < 2; ++hh) {
+            const int i = i0 + hh;
+            const int nt = nt0 + i;
             f32x16 acc = bf_bias_init(bs, nt, h);
 #pragma unroll
             for (int ks = 0; ks < BF_KS; ++ks) {
-                acc = mfma32(ring[16 * half + ks], yf[ks], acc);
-                if (i + 2 < ntw) ring[16 * half + ks] = nx[(16 * half + ks) * 64];
+                acc = mfma32(ring[16 * hh + ks], yf[ks], acc);
+                if (i + 2 < ntw) ring[16 * hh + ks] = nx[(16 * hh + ks) * 64];
             }
             const int t = nt / tiles_per_adapter;
             acc = mfma32(bext[i], t == 0 ? hb01[0] : (t == 1 ? hb01[1] : hbv), acc);
@@ -417,11 +425,11 @@ __global__ __launch_bounds__(256, 1) void block_qkv_bwd_kernel(QkvBwd a) {
     if (touched == 0x7fc07fc1u && a.M < 0) a.dx[0] = (bf16_t)0.f;   // (keeps the prefetch loads alive; never true)
 }
 
-template <bool DROP>
+template <bool DROP, int NS>
 static int launch_qkv_fwd(const QkvFwd& a, hipStream_t st) {
     static int ready = 0;
-    if (!ready) { if (bf_prepare(block_qkv_fwd_kernel<DROP>)) return -2; ready = 1; }
-    hipLaunchKernelGGL((block_qkv_fwd_kernel<DROP>), dim3((a.M + BF_ROWS - 1) / BF_ROWS), dim3(256), BF_LDS_TOTAL, st, a);
+    if (!ready) { if (bf_prepare(block_qkv_fwd_kernel<DROP, NS>)) return -2; ready = 1; }
+    hipLaunchKernelGGL((block_qkv_fwd_kernel<DROP, NS>), dim3((a.M + BF_ROWS - 1) / BF_ROWS, NS), dim3(256), BF_LDS_TOTAL, st, a);
     return 0;
 }
 template <bool DROP>
@@ -447,7 +455,14 @@ extern "C" int cvft_block_qkv_fwd(const cvft_block_qkv_args* p, void* stream) {
     a.alpha = p->alpha; a.p = p->p; a.seed = (const long long*)p->seed;
     for (int i = 0; i < 3; ++i) { a.sites[i] = p->sites[i]; a.xd[i] = (bf16_t*)p->xd[i]; }
     a.U = (bf16_t*)p->U; a.ldu = p->ldu; a.y_out = (bf16_t*)p->y_out; a.Y = (bf16_t*)p->Y; a.ldy = p->ldy;
-    const int rc = p->p > 0.f ? launch_qkv_fwd<true>(a, (hipStream_t)stream) : launch_qkv_fwd<false>(a, (hipStream_t)stream);
+    // two workgroups per row tile while the launch cannot fill the chip with one AND this chain is not competing with two others:
+    // same-box A/B, flow_only (2 chains) 14.95 -> 14.71 ms, joint (3 chains) 23.37 -> 23.53 -- what shortens a chain on an idle chip
+    // costs the step when the chip is shared.  CVFT_QKV_NSPLIT=1/2 forces.
+    static const int ns_env = getenv("CVFT_QKV_NSPLIT") ? atoi(getenv("CVFT_QKV_NSPLIT")) : 0;
+    const int ns = ns_env ? ns_env : (((p->M + BF_ROWS - 1) / BF_ROWS <= 128 && cvft_concurrent_chains() < 3) ? 2 : 1);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = p->p > 0.f ? (ns == 2 ? launch_qkv_fwd<true, 2>(a, st) : launch_qkv_fwd<true, 1>(a, st))
+                              : (ns == 2 ? launch_qkv_fwd<false, 2>(a, st) : launch_qkv_fwd<false, 1>(a, st));
     if (rc) return rc;
     CVFT_LAUNCH_CHECK("cvft_block_qkv_fwd");
     return 0;

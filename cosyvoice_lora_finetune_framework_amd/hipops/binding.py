@@ -41,14 +41,15 @@ class BlockTailArgs(C.Structure):
                 ("W_fwd", C.c_void_p), ("bo", C.c_void_p), ("x1", C.c_void_p),
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
                 ("b1", C.c_void_p), ("F", C.c_int), ("b2", C.c_void_p),
-                ("act", C.c_int), ("z", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("out", C.c_void_p)]
+                ("act", C.c_int), ("z", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("out", C.c_void_p),
+                ("lean", C.c_int)]
 
 
 class BlockTailBwdArgs(C.Structure):
     """mirror of cvft_block_tail_bwd_args (include/cvft.h)"""
     _fields_ = [("M", C.c_int), ("x1", C.c_void_p), ("dy", C.c_void_p), ("gamma", C.c_void_p), ("mean", C.c_void_p),
                 ("rstd", C.c_void_p), ("z", C.c_void_p), ("W_bwd", C.c_void_p), ("F", C.c_int), ("DI", C.c_int),
-                ("act", C.c_int), ("dx1", C.c_void_p), ("dout", C.c_void_p), ("lddo", C.c_int)]
+                ("act", C.c_int), ("dx1", C.c_void_p), ("dout", C.c_void_p), ("lddo", C.c_int), ("lean", C.c_int)]
 
 
 class BlockQkvArgs(C.Structure):

@@ -97,6 +97,31 @@ class BlockTailPack:
         self.W_fwd, nf = _streams(fwd)
         self.W_bwd, nb = _streams(bwd)
         assert nf == self.DI // 8 + self.F // 4 and nb == nf
+        # "lean" streams (csrc/block_lean.hip): a wave owns 64 OUTPUT features of every link and hidden tile 4 r + w of round r
+        W2n = pack_a(w2, "natural")                              # [8 ct][F/16 ks]
+        W1Tn = pack_a(w1.detach().t().contiguous(), "natural")   # [8 dt][F/16 ks]
+        nr = self.F // 128
+        fwd, bwd = [], []
+        for w in range(4):
+            cf, cb = [], []
+            if self.DI:
+                cf.append(Won[2 * w:2 * w + 2].permute(1, 0, 2, 3))                   # [ks][c2]
+            cf.append(W1n[w])
+            cb.append(W2Tn[w])
+            for r in range(nr):
+                if r + 1 < nr:
+                    cf.append(W1n[4 * (r + 1) + w])
+                    cb.append(W2Tn[4 * (r + 1) + w])
+                cf.append(W2n[2 * w:2 * w + 2, 8 * r:8 * r + 8].permute(1, 0, 2, 3))     # [k'][c2]
+                cb.append(W1Tn[2 * w:2 * w + 2, 8 * r:8 * r + 8].permute(1, 0, 2, 3))
+            if self.DI:
+                fw = self.DI // 128
+                cb.append(WoTn[fw * w:fw * (w + 1)].permute(1, 0, 2, 3))                # [ks][f]
+            fwd.append(cf)
+            bwd.append(cb)
+        self.W_fwd_lean, nfl = _streams(fwd)
+        self.W_bwd_lean, nbl = _streams(bwd)
+        assert nfl == nf and nbl == nf
 
 
 class BlockQkvPack:

@@ -1350,7 +1350,8 @@ class BlockTailFn(torch.autograd.Function):
         a.M = M
         x1 = x0
         assert (o is not None) == (pack.DI > 0), "BlockTailPack built with / without to_out must match the call"
-        a.DI, a.W_fwd = pack.DI, ptr(pack.W_fwd)
+        ctx.lean = block_tail_lean()
+        a.DI, a.W_fwd, a.lean = pack.DI, ptr(pack.W_fwd_lean if ctx.lean else pack.W_fwd), int(ctx.lean)
         if o is not None:
             assert o.shape == (M, pack.DI) and o.stride(1) == 1
             x1 = torch.empty_like(x0)
@@ -1380,7 +1381,8 @@ class BlockTailFn(torch.autograd.Function):
         dx1 = torch.empty_like(x1)
         do = None
         a.M, a.x1, a.dy, a.gamma, a.mean, a.rstd, a.z = M, ptr(x1), ptr(dy), ptr(pack.gamma), ptr(mean), ptr(rstd), ptr(z)
-        a.W_bwd, a.F, a.DI, a.act, a.dx1 = ptr(pack.W_bwd), pack.F, pack.DI, ACT[ctx.act], ptr(dx1)
+        a.W_bwd, a.F, a.DI, a.act, a.dx1 = ptr(pack.W_bwd_lean if ctx.lean else pack.W_bwd), pack.F, pack.DI, ACT[ctx.act], ptr(dx1)
+        a.lean = int(ctx.lean)
         if ctx.has_o and ctx.needs_input_grad[0]:
             do = torch.empty((M, pack.DI), dtype=x1.dtype, device=x1.device)
             a.dout, a.lddo = ptr(do), do.stride(0)
@@ -1526,6 +1528,15 @@ def can_block_tail(x: torch.Tensor, d_ff: int, d_inner: int) -> bool:
 
 
 BLOCK_FUSE = _os.environ.get("CVFT_BLOCK_FUSE", "1") != "0"
+# CU-sharing form of the block-tail kernels (csrc/block_lean.hip): opt-in (1) or "auto" (when >= 3 chains are in flight).  Measured, same-box
+# A/B: joint 22.85 (CU-owning form) vs 22.99 ms (this form), flow_only 15.01 vs 15.16 -- sharing the CU does not pay, so the default is 0
+BLOCK_LEAN = _os.environ.get("CVFT_BLOCK_LEAN", "0")
+
+
+def block_tail_lean() -> bool:
+    if BLOCK_LEAN in ("0", "1"):
+        return BLOCK_LEAN == "1"
+    return lib().cvft_concurrent_chains() >= 3
 BLOCK_QKV_FUSE = _os.environ.get("CVFT_BLOCK_QKV_FUSE", "1") != "0"      # first half of the block (norm1 + stacked LoRA q|k|v)
 
 

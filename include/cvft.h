@@ -393,6 +393,11 @@ typedef struct {
     void* z;                             /* pre-activation workspace or NULL (inference) */
     float* mean; float* rstd;            /* [M] LayerNorm statistics of x1 (saved for backward) */
     void* out;                           /* [M][256] */
+    int lean;                            /* 0: W_fwd as above, the workgroup owns its CU (512 registers per lane, 155 KB LDS);
+                                            1: the CU-sharing form (block_lean.hip: <= 256 registers, 82 KB) -- W_fwd then holds the
+                                            "lean" streams: wave w = fragments of ITS 64 output features: natural(Wo, 2 w + c2, ks) in
+                                            order [ks][c2]; natural(W1, w, ks); per round r < F / 128: [natural(W1, 4 (r+1) + w, ks)],
+                                            natural(W2, 2 w + c2, 8 r + k') in order [k'][c2]  (same wave_frags) */
 } cvft_block_tail_args;
 int cvft_block_tail_fwd(const cvft_block_tail_args* a, void* stream);
 typedef struct {
@@ -403,6 +408,9 @@ typedef struct {
     const void* W_bwd; int F; int DI; int act;
     void* dx1;                           /* [M][256] gradient at x1 (= gradient of x0 through the residual) */
     void* dout; int lddo;                /* dout [M][DI] = dx1 . to_out.weight, or NULL (not wanted / DI == 0) */
+    int lean;                            /* as in cvft_block_tail_args; lean W_bwd, wave w: natural(W2^T, w, ks); per round r:
+                                            [natural(W2^T, 4 (r+1) + w, ks)], natural(W1^T, 2 w + c2, 8 r + k') in order [k'][c2];
+                                            natural(Wo^T, (DI/128) w + f, ks) in order [ks][f] */
 } cvft_block_tail_bwd_args;
 int cvft_block_tail_bwd(const cvft_block_tail_bwd_args* a, void* stream);
 

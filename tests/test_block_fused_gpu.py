@@ -40,11 +40,15 @@ def _ref(o, x0, w, act, with_o=True):
     return o, x0, x1r, out
 
 
+@pytest.mark.parametrize("lean", [False, True])
 @pytest.mark.parametrize("act", ["gelu_erf", "gelu_tanh"])
 @pytest.mark.parametrize("M,DI,Fh,with_o", [(64, 512, 1024, True), (250, 512, 1024, True), (37, 256, 128, True), (70, 512, 256, True), (96, 512, 1024, False),
                                             (4000, 512, 1024, True)])
-def test_block_tail_matches_fp64_reference(act, M, DI, Fh, with_o):
+def test_block_tail_matches_fp64_reference(act, M, DI, Fh, with_o, lean, monkeypatch):
+    """lean = the CU-sharing form of the kernels (csrc/block_lean.hip: each wave owns 64 output features, hidden tiles exchanged
+    through LDS, <= 256 registers); both forms against the same fp64 restatement."""
     from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    monkeypatch.setattr(HF, "BLOCK_LEAN", "1" if lean else "0")
     from cosyvoice_lora_finetune_framework_amd.hipops.blockpack import BlockTailPack
     w = _weights(DI, Fh, seed=M)
     g = torch.Generator().manual_seed(M + 1)
@@ -129,7 +133,7 @@ def _keep_mask(M, Kd, p, seed, site):
     return torch.from_numpy((fields >= thr).astype("float32"))
 
 
-@pytest.mark.parametrize("M,p", [(64, 0.0), (250, 0.05), (37, 0.3), (2000, 0.05)])
+@pytest.mark.parametrize("M,p", [(64, 0.0), (250, 0.05), (37, 0.3), (2000, 0.05), (4200, 0.05), (4200, 0.0)])      # (> 128 row tiles: one workgroup per tile)
 def test_block_qkv_matches_fp64_reference(M, p):
     """norm1 + stacked LoRA q|k|v with lora_dropout (lora.py:64-76 x 3 over matcha transformer.py:255-262) and its backward, fused
     launches against an fp64 restatement under host-replicated masks; also V, U and the dropped copies the adapter gradients use."""

@@ -21,8 +21,9 @@ def main():
         o = torch.randn(M, 512, device=dev, dtype=dt)
         x0 = torch.randn(M, 256, device=dev, dtype=dt)
         dy = torch.randn(M, 256, device=dev, dtype=dt)
-        for fuse in (False, True):
-            HF.BLOCK_FUSE = fuse
+        for fuse in (False, True, "lean"):
+            HF.BLOCK_FUSE = bool(fuse)
+            HF.BLOCK_LEAN = "1" if fuse == "lean" else "0"
 
             def fwd():
                 with torch.no_grad():
@@ -33,7 +34,7 @@ def main():
                 blk._tail(oo, xx, "gelu_erf").backward(dy)
             tf, tb = timeit(fwd), timeit(fwdbwd)
             fl = 2.0 * M * 256 * (2 * 1024 + 512)
-            print(f"M={M:5d} fused={int(fuse)}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF/s)   fwd+bwd {tb:7.1f} us  -> bwd ~{tb - tf:7.1f} us ({fl * 1.0 / max(tb - tf, 1e-3) / 1e6:6.1f} TF/s dgrad-only)")
+            print(f"M={M:5d} fused={fuse!s:5s}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF/s)   fwd+bwd {tb:7.1f} us  -> bwd ~{tb - tf:7.1f} us ({fl * 1.0 / max(tb - tf, 1e-3) / 1e6:6.1f} TF/s dgrad-only)")
     HF.BLOCK_FUSE = True
 
 
