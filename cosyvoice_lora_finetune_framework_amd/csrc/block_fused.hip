@@ -395,6 +395,8 @@ static int launch_bwd(const TailBwd& a, hipStream_t st) {
 
 int block_tail_lean_fwd_launch(const cvft_block_tail_args* p, int DI, void* stream);       // block_lean.hip
 int block_tail_lean_bwd_launch(const cvft_block_tail_bwd_args* p, int DI, void* stream);
+int block_tail_wide_fwd_launch(const cvft_block_tail_args* p, int DI, void* stream);       // block_wide.hip
+int block_tail_wide_bwd_launch(const cvft_block_tail_bwd_args* p, int DI, void* stream);
 
 extern "C" int cvft_block_tail_fwd(const cvft_block_tail_args* p, void* stream) {
     CVFT_CHECK_ARG(p && p->M > 0 && p->F > 0 && p->F % 128 == 0 && p->F <= BF_MAX_F, "cvft_block_tail_fwd: need M > 0, F %% 128 == 0, F <= 2048 (F=%d)", p ? p->F : -1);
@@ -406,7 +408,8 @@ extern "C" int cvft_block_tail_fwd(const cvft_block_tail_args* p, void* stream) 
     CVFT_CHECK_ARG(al16(p->x1) && al16(p->out) && al16(p->W_fwd) && al16(p->b1) && al16(p->b2) && al16(p->gamma) && al16(p->beta) &&
                    (!p->z || al16(p->z)) && (!p->x0 || al16(p->x0)) && (!p->bo || al16(p->bo)), "cvft_block_tail_fwd: operands must be 16-byte aligned");
     if (p->lean) {
-        const int rc = block_tail_lean_fwd_launch(p, DI, stream);
+        CVFT_CHECK_ARG(p->lean == 1 || (p->lean == 2 && p->z && p->F >= 256), "cvft_block_tail_fwd: lean must be 0, 1 or 2; the wide form (2) needs F >= 256 and always stores z (whole 64-row groups)");
+        const int rc = p->lean == 2 ? block_tail_wide_fwd_launch(p, DI, stream) : block_tail_lean_fwd_launch(p, DI, stream);
         if (rc) return rc;
         CVFT_LAUNCH_CHECK("cvft_block_tail_fwd (lean)");
         return 0;
@@ -435,7 +438,9 @@ extern "C" int cvft_block_tail_bwd(const cvft_block_tail_bwd_args* p, void* stre
     if (p->dout) CVFT_CHECK_ARG((DI == 256 || DI == 512) && p->lddo % 4 == 0 && al16(p->dout), "cvft_block_tail_bwd: output-projection dgrad needs DI in {256, 512}, aligned dout");
     CVFT_CHECK_ARG(al16(p->x1) && al16(p->dy) && al16(p->gamma) && al16(p->z) && al16(p->W_bwd) && al16(p->dx1), "cvft_block_tail_bwd: operands must be 16-byte aligned");
     if (p->lean) {
-        const int rc = block_tail_lean_bwd_launch(p, DI, stream);
+        CVFT_CHECK_ARG(p->lean == 1 || (p->lean == 2 && p->F >= 256), "cvft_block_tail_bwd: lean must be 0, 1 or 2 (2: F >= 256)");
+        CVFT_CHECK_ARG(p->lean == 1 || !p->dout || p->lddo % 8 == 0, "cvft_block_tail_bwd: the wide form stores dout in 16-byte pieces (lddo %% 8 == 0)");
+        const int rc = p->lean == 2 ? block_tail_wide_bwd_launch(p, DI, stream) : block_tail_lean_bwd_launch(p, DI, stream);
         if (rc) return rc;
         CVFT_LAUNCH_CHECK("cvft_block_tail_bwd (lean)");
         return 0;

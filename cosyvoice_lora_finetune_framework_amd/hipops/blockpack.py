@@ -122,6 +122,30 @@ class BlockTailPack:
         self.W_fwd_lean, nfl = _streams(fwd)
         self.W_bwd_lean, nbl = _streams(bwd)
         assert nfl == nf and nbl == nf
+        # "wide" streams (csrc/block_wide.hip): the lean groups with the second product lagging one round:
+        # G1(0), G1(1), { G1(r + 1), G2(r - 1) : r = 1 .. nr - 2 }, G2(nr - 2), G2(nr - 1)      (nr = 1: G1(0), G2(0))
+        order = [("1", 0)] + ([("1", 1)] if nr > 1 else [])
+        for r in range(1, nr - 1):
+            order += [("1", r + 1), ("2", r - 1)]
+        order += ([("2", nr - 2)] if nr > 1 else []) + [("2", nr - 1)]
+        assert sorted(order) == sorted([(k, r) for k in "12" for r in range(nr)])
+        fwd, bwd = [], []
+        for w in range(4):
+            g1f = lambda r: W1n[4 * r + w]
+            g2f = lambda r: W2n[2 * w:2 * w + 2, 8 * r:8 * r + 8].permute(1, 0, 2, 3)          # [k'][c2]
+            g1b = lambda r: W2Tn[4 * r + w]
+            g2b = lambda r: W1Tn[2 * w:2 * w + 2, 8 * r:8 * r + 8].permute(1, 0, 2, 3)
+            cf = [Won[2 * w:2 * w + 2].permute(1, 0, 2, 3)] if self.DI else []
+            cf += [(g1f if k == "1" else g2f)(r) for k, r in order]
+            cb = [(g1b if k == "1" else g2b)(r) for k, r in order]
+            if self.DI:
+                fw = self.DI // 128
+                cb.append(WoTn[fw * w:fw * (w + 1)].permute(1, 0, 2, 3))                        # [ks][f]
+            fwd.append(cf)
+            bwd.append(cb)
+        self.W_fwd_wide, nfw = _streams(fwd)
+        self.W_bwd_wide, nbw = _streams(bwd)
+        assert nfw == nf and nbw == nf
 
 
 class BlockQkvPack:

@@ -1351,7 +1351,9 @@ class BlockTailFn(torch.autograd.Function):
         x1 = x0
         assert (o is not None) == (pack.DI > 0), "BlockTailPack built with / without to_out must match the call"
         ctx.lean = block_tail_lean()
-        a.DI, a.W_fwd, a.lean = pack.DI, ptr(pack.W_fwd_lean if ctx.lean else pack.W_fwd), int(ctx.lean)
+        if ctx.lean == 2 and pack.F < 256:             # (the wide form's rounds lag by one: it needs two of them)
+            ctx.lean = 1
+        a.DI, a.W_fwd, a.lean = pack.DI, ptr((pack.W_fwd, pack.W_fwd_lean, pack.W_fwd_wide)[ctx.lean]), int(ctx.lean)
         if o is not None:
             assert o.shape == (M, pack.DI) and o.stride(1) == 1
             x1 = torch.empty_like(x0)
@@ -1360,7 +1362,8 @@ class BlockTailFn(torch.autograd.Function):
         out = torch.empty_like(x0)
         mean = torch.empty(M, dtype=torch.float32, device=x0.device)
         rstd = torch.empty(M, dtype=torch.float32, device=x0.device)
-        z = torch.empty(-(-M // 32) * 32 * pack.F, dtype=x0.dtype, device=x0.device) if need else None
+        # (the wide form always stores z and works on whole 64-row groups)
+        z = torch.empty(-(-M // 64) * 64 * pack.F, dtype=x0.dtype, device=x0.device) if (need or ctx.lean == 2) else None
         a.x1, a.gamma, a.beta, a.eps = ptr(x1), ptr(pack.gamma), ptr(pack.beta), pack.eps
         a.b1, a.F, a.b2, a.act = ptr(pack.b1), pack.F, ptr(pack.b2), ACT[act]
         a.z, a.mean, a.rstd, a.out = ptr(z), ptr(mean), ptr(rstd), ptr(out)
@@ -1381,7 +1384,7 @@ class BlockTailFn(torch.autograd.Function):
         dx1 = torch.empty_like(x1)
         do = None
         a.M, a.x1, a.dy, a.gamma, a.mean, a.rstd, a.z = M, ptr(x1), ptr(dy), ptr(pack.gamma), ptr(mean), ptr(rstd), ptr(z)
-        a.W_bwd, a.F, a.DI, a.act, a.dx1 = ptr(pack.W_bwd_lean if ctx.lean else pack.W_bwd), pack.F, pack.DI, ACT[ctx.act], ptr(dx1)
+        a.W_bwd, a.F, a.DI, a.act, a.dx1 = ptr((pack.W_bwd, pack.W_bwd_lean, pack.W_bwd_wide)[ctx.lean]), pack.F, pack.DI, ACT[ctx.act], ptr(dx1)
         a.lean = int(ctx.lean)
         if ctx.has_o and ctx.needs_input_grad[0]:
             do = torch.empty((M, pack.DI), dtype=x1.dtype, device=x1.device)
@@ -1533,10 +1536,11 @@ BLOCK_FUSE = _os.environ.get("CVFT_BLOCK_FUSE", "1") != "0"
 BLOCK_LEAN = _os.environ.get("CVFT_BLOCK_LEAN", "0")
 
 
-def block_tail_lean() -> bool:
-    if BLOCK_LEAN in ("0", "1"):
-        return BLOCK_LEAN == "1"
-    return lib().cvft_concurrent_chains() >= 3
+def block_tail_lean() -> int:
+    """0: CU-owning 32-row form (block_fused.hip); 1: CU-sharing 32-row form; 2: wide 64-row form (block_lean.hip)"""
+    if BLOCK_LEAN in ("0", "1", "2"):
+        return int(BLOCK_LEAN)
+    return 1 if lib().cvft_concurrent_chains() >= 3 else 0
 BLOCK_QKV_FUSE = _os.environ.get("CVFT_BLOCK_QKV_FUSE", "1") != "0"      # first half of the block (norm1 + stacked LoRA q|k|v)
 
 
