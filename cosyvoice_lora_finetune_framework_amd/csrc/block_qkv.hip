@@ -440,6 +440,9 @@ static int launch_qkv_bwd(const QkvBwd& a, hipStream_t st) {
     return 0;
 }
 
+int block_qkv_wide_fwd_launch(const cvft_block_qkv_args* p, void* stream);          // block_qkv_wide.hip
+int block_qkv_wide_bwd_launch(const cvft_block_qkv_bwd_args* p, void* stream);
+
 extern "C" int cvft_block_qkv_fwd(const cvft_block_qkv_args* p, void* stream) {
     CVFT_CHECK_ARG(p && p->M > 0 && p->N3 == 1536, "cvft_block_qkv_fwd: need M > 0 and 3N == 1536 (N3=%d)", p ? p->N3 : -1);
     CVFT_CHECK_ARG(p->x && p->gamma && p->beta && p->mean && p->rstd && p->W_fwd && p->A && p->Bb && p->U && p->Y, "cvft_block_qkv_fwd: null operand");
@@ -448,6 +451,13 @@ extern "C" int cvft_block_qkv_fwd(const cvft_block_qkv_args* p, void* stream) {
                    p->lda % 8 == 0 && p->ldb % 4 == 0 && p->ldu % 4 == 0 && p->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(p->U) & 7) == 0 &&
                    (!p->y_out || al16(p->y_out)) && (!p->xd[0] || al16(p->xd[0])) && (!p->xd[1] || al16(p->xd[1])) && (!p->xd[2] || al16(p->xd[2])),
                    "cvft_block_qkv_fwd: operands must be 16-byte aligned (row pitches: lda %% 8, ldb / ldu / ldy %% 4)");
+    if (p->wide) {
+        CVFT_CHECK_ARG(p->ldy % 8 == 0, "cvft_block_qkv_fwd: the wide form stores Y in 16-byte pieces (ldy %% 8 == 0)");
+        const int rc = block_qkv_wide_fwd_launch(p, stream);
+        if (rc) return rc;
+        CVFT_LAUNCH_CHECK("cvft_block_qkv_fwd (wide)");
+        return 0;
+    }
     QkvFwd a;
     a.M = p->M; a.x = (const bf16_t*)p->x; a.gamma = p->gamma; a.beta = p->beta; a.eps = p->eps; a.mean = p->mean; a.rstd = p->rstd;
     a.Wst = (const bf16x8*)p->W_fwd; a.wave_frags = p->N3 / 8; a.bias = p->bias; a.N3 = p->N3;
@@ -475,6 +485,12 @@ extern "C" int cvft_block_qkv_bwd(const cvft_block_qkv_bwd_args* p, void* stream
     CVFT_CHECK_ARG(al16(p->dY) && al16(p->x) && al16(p->gamma) && al16(p->W_bwd) && al16(p->Bbt) && al16(p->dx) && (!p->dres || al16(p->dres)) &&
                    p->lddy % 8 == 0 && p->ldbt % 8 == 0 && p->ldat % 4 == 0 && p->ldv % 4 == 0 && (reinterpret_cast<uintptr_t>(p->At) & 7) == 0 &&
                    (reinterpret_cast<uintptr_t>(p->V) & 7) == 0, "cvft_block_qkv_bwd: operands must be 16-byte aligned (row pitches: lddy / ldbt %% 8, ldat / ldv %% 4)");
+    if (p->wide) {
+        const int rc = block_qkv_wide_bwd_launch(p, stream);
+        if (rc) return rc;
+        CVFT_LAUNCH_CHECK("cvft_block_qkv_bwd (wide)");
+        return 0;
+    }
     QkvBwd a;
     a.M = p->M; a.dY = (const bf16_t*)p->dY; a.lddy = p->lddy; a.dres = (const bf16_t*)p->dres; a.x = (const bf16_t*)p->x;
     a.gamma = p->gamma; a.mean = p->mean; a.rstd = p->rstd; a.Wst = (const bf16x8*)p->W_bwd; a.wave_frags = p->N3 / 8; a.N3 = p->N3;

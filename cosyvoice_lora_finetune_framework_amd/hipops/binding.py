@@ -58,7 +58,8 @@ class BlockQkvArgs(C.Structure):
                 ("mean", C.c_void_p), ("rstd", C.c_void_p), ("W_fwd", C.c_void_p), ("bias", C.c_void_p), ("N3", C.c_int),
                 ("A", C.c_void_p), ("lda", C.c_int), ("Bb", C.c_void_p), ("ldb", C.c_int),
                 ("alpha", C.c_float), ("p", C.c_float), ("seed", C.c_void_p), ("sites", C.c_uint * 3),
-                ("U", C.c_void_p), ("ldu", C.c_int), ("xd", C.c_void_p * 3), ("y_out", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int)]
+                ("U", C.c_void_p), ("ldu", C.c_int), ("xd", C.c_void_p * 3), ("y_out", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int),
+                ("wide", C.c_int)]
 
 
 class BlockQkvBwdArgs(C.Structure):
@@ -67,7 +68,7 @@ class BlockQkvBwdArgs(C.Structure):
                 ("gamma", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("W_bwd", C.c_void_p), ("N3", C.c_int),
                 ("At", C.c_void_p), ("ldat", C.c_int), ("Bbt", C.c_void_p), ("ldbt", C.c_int),
                 ("alpha", C.c_float), ("p", C.c_float), ("seed", C.c_void_p), ("sites", C.c_uint * 3),
-                ("V", C.c_void_p), ("ldv", C.c_int), ("dx", C.c_void_p)]
+                ("V", C.c_void_p), ("ldv", C.c_int), ("dx", C.c_void_p), ("wide", C.c_int)]
 
 
 class GemmArgs(C.Structure):

@@ -1415,6 +1415,8 @@ class BlockQkvFn(torch.autograd.Function):
         a = cb.BlockQkvArgs()
         a.M, a.x, a.gamma, a.beta, a.eps, a.mean, a.rstd = M, ptr(x), ptr(pack.gamma), ptr(pack.beta), pack.eps, ptr(mean), ptr(rstd)
         a.W_fwd, a.bias, a.N3 = ptr(pack.W_fwd), ptr(pack.bias), N3
+        ctx.wide = BLOCK_QKV_WIDE
+        a.wide = int(ctx.wide)
         a.A, a.lda, a.Bb, a.ldb = ptr(A), A.stride(0), ptr(Bb), Bb.stride(0)
         a.alpha, a.p = float(scale), float(drop_p)
         xds, y = [], None
@@ -1458,7 +1460,8 @@ class BlockQkvFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         a = cb.BlockQkvBwdArgs()
         a.M, a.dY, a.lddy, a.dres, a.x = M, ptr(dY), dY.stride(0), ptr(None if dres is None else _c(dres)), ptr(x)
-        a.gamma, a.mean, a.rstd, a.W_bwd, a.N3 = ptr(pack.gamma), ptr(mean), ptr(rstd), ptr(pack.W_bwd), N3
+        a.gamma, a.mean, a.rstd, a.W_bwd, a.N3 = ptr(pack.gamma), ptr(mean), ptr(rstd), ptr(pack.W_bwd_wide if ctx.wide else pack.W_bwd), N3
+        a.wide = int(ctx.wide)
         a.At, a.ldat, a.Bbt, a.ldbt = ptr(At), At.stride(0), ptr(Bbt), Bbt.stride(0)
         a.alpha, a.p = scale, p
         if p > 0:
@@ -1542,6 +1545,7 @@ def block_tail_lean() -> int:
         return int(BLOCK_LEAN)
     return 1 if lib().cvft_concurrent_chains() >= 3 else 0
 BLOCK_QKV_FUSE = _os.environ.get("CVFT_BLOCK_QKV_FUSE", "1") != "0"      # first half of the block (norm1 + stacked LoRA q|k|v)
+BLOCK_QKV_WIDE = _os.environ.get("CVFT_BLOCK_QKV_WIDE", "0") != "0"      # its 64-rows-per-workgroup form (csrc/block_qkv_wide.hip)
 
 
 # ---------------------------------------------------------------------------------

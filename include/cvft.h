@@ -440,6 +440,8 @@ typedef struct {
     void* xd[3];                         /* p > 0: dropped copies [M][256] (entries may be NULL) */
     void* y_out;                         /* p == 0: LN(x) [M][256] or NULL */
     void* Y; int ldy;                    /* [M][3N] out */
+    int wide;                            /* 0: 32 rows per workgroup (block_qkv.hip); 1: 64 rows per workgroup (block_qkv_wide.hip), same
+                                            W_fwd stream, ldy % 8 == 0 */
 } cvft_block_qkv_args;
 int cvft_block_qkv_fwd(const cvft_block_qkv_args* a, void* stream);
 typedef struct {
@@ -452,6 +454,8 @@ typedef struct {
     float alpha; float p; const int64_t* seed; unsigned sites[3];
     void* V; int ldv;                    /* [M][48] out */
     void* dx;                            /* [M][256] out */
+    int wide;                            /* 0: W_bwd = wave w's quarter of 3N, [ks][ct] (block_qkv.hip); 1: 64 rows per workgroup
+                                            (block_qkv_wide.hip), W_bwd = wave w's feature tiles 2 w, 2 w + 1 over all of 3N, [ks][c2] */
 } cvft_block_qkv_bwd_args;
 int cvft_block_qkv_bwd(const cvft_block_qkv_bwd_args* a, void* stream);
 

@@ -133,8 +133,9 @@ def _keep_mask(M, Kd, p, seed, site):
     return torch.from_numpy((fields >= thr).astype("float32"))
 
 
+@pytest.mark.parametrize("wide", [0, 1])                                    # (1: 64 rows per workgroup, csrc/block_qkv_wide.hip)
 @pytest.mark.parametrize("M,p", [(64, 0.0), (250, 0.05), (37, 0.3), (2000, 0.05), (4200, 0.05), (4200, 0.0)])      # (> 128 row tiles: one workgroup per tile)
-def test_block_qkv_matches_fp64_reference(M, p):
+def test_block_qkv_matches_fp64_reference(M, p, wide):
     """norm1 + stacked LoRA q|k|v with lora_dropout (lora.py:64-76 x 3 over matcha transformer.py:255-262) and its backward, fused
     launches against an fp64 restatement under host-replicated masks; also V, U and the dropped copies the adapter gradients use."""
     from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
@@ -160,7 +161,7 @@ def test_block_qkv_matches_fp64_reference(M, p):
     outs = [torch.empty((M, 256), dtype=torch.bfloat16, device=DEV) for _ in range(3)]
     a = cb.BlockQkvArgs()
     a.M, a.x, a.gamma, a.beta, a.eps, a.mean, a.rstd = M, cb.ptr(xd_), cb.ptr(pack.gamma), cb.ptr(pack.beta), 1e-5, cb.ptr(mean), cb.ptr(rstd)
-    a.W_fwd, a.bias, a.N3 = cb.ptr(pack.W_fwd), cb.ptr(pack.bias), 1536
+    a.W_fwd, a.bias, a.N3, a.wide = cb.ptr(pack.W_fwd), cb.ptr(pack.bias), 1536, wide
     a.A, a.lda, a.Bb, a.ldb = cb.ptr(ops[0]), 256, cb.ptr(ops[2]), 48
     a.alpha, a.p = scale, p
     if p > 0:
@@ -192,7 +193,8 @@ def test_block_qkv_matches_fp64_reference(M, p):
     dYd, dresd = d(dY.to(torch.bfloat16)), d(dres.to(torch.bfloat16))
     b = cb.BlockQkvBwdArgs()
     b.M, b.dY, b.lddy, b.dres, b.x = M, cb.ptr(dYd), 1536, cb.ptr(dresd), cb.ptr(xd_)
-    b.gamma, b.mean, b.rstd, b.W_bwd, b.N3 = cb.ptr(pack.gamma), cb.ptr(mean), cb.ptr(rstd), cb.ptr(pack.W_bwd), 1536
+    b.gamma, b.mean, b.rstd, b.W_bwd, b.N3 = cb.ptr(pack.gamma), cb.ptr(mean), cb.ptr(rstd), cb.ptr(pack.W_bwd_wide if wide else pack.W_bwd), 1536
+    b.wide = wide
     b.At, b.ldat, b.Bbt, b.ldbt = cb.ptr(ops[1]), 48, cb.ptr(ops[3]), 1536
     b.alpha, b.p = scale, p
     if p > 0:
