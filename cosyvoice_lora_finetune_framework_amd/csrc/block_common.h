@@ -83,13 +83,25 @@ __device__ __forceinline__ float bf_gelu(float x) {
 // of the whole stream -- the workgroups that share an XCD (equal blockIdx % 8: speed only, never correctness) split it by
 // (blockIdx / 8) % 8 -- which puts all of it in flight towards that XCD's L2 at once; the ring's loads then hit lines that are
 // resident or already on their way.  The touched words are OR-ed into a value nobody reads before the kernel's end.
-__device__ __forceinline__ unsigned bf_touch_stream(const void* stream, int total_frags) {
+// The loads are requested BEHIND the ring fill and nothing reads their values before the kernel's end (bf_touch_fold): a load whose
+// value is used at once makes the wave wait for every load requested before it (vmcnt retires in order), and a run-time loop of
+// loads makes the compiler wait for all outstanding loads at the next use of any of them.
+struct BfTouch { unsigned v[8]; };
+__device__ __forceinline__ BfTouch bf_touch_stream(const void* stream, int total_frags) {
     const int part = (blockIdx.x >> 3) & 7;
-    const int lines = total_frags * 8 / 8;             // 8 lines of 128 B per fragment, one eighth of them per workgroup
+    const int lines = total_frags;                     // 8 lines of 128 B per fragment, one eighth of them per workgroup
     const char* base = reinterpret_cast<const char*>(stream) + (size_t)part * lines * 128;
-    unsigned acc = 0;
-    for (int l = threadIdx.x; l < lines; l += 256) acc |= *reinterpret_cast<const unsigned*>(base + (size_t)l * 128);
-    return acc;
+    BfTouch r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)                        // (total_frags <= 2048; surplus lanes re-touch the last line)
+        r.v[i] = *reinterpret_cast<const unsigned*>(base + (size_t)min(i * 256 + (int)threadIdx.x, lines - 1) * 128);
+    return r;
+}
+__device__ __forceinline__ unsigned bf_touch_fold(const BfTouch& r) {
+    unsigned a = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a |= r.v[i];
+    return a;
 }
 
 // Sum the four waves' partial tiles acc[8] (feature tile ct, rows on the lanes) through LDS; afterwards wave w holds feature

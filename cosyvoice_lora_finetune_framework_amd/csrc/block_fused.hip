@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256, 1) void block_tail_fwd_kernel(TailFwd a) {
     const bool rvalid = m0 + m < a.M;
     BF_STAMP(0);
 
-    const unsigned touched = BF_TOUCH ? bf_touch_stream(a.Wst, 4 * a.wave_frags) : 0u;
     // ---- loads in the order they are needed (vmcnt retires in order): activations, small parameters (-> LDS), then the ring
     bf16x8 of[AR > 0 ? 4 * AR : 1];
     bf16x4 xb[2][4];                                   // this wave's 64 features of x0, later of x1 (as stored: bf16)
@@ -101,6 +100,8 @@ __global__ __launch_bounds__(256, 1) void block_tail_fwd_kernel(TailFwd a) {
 #pragma unroll
     for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
     nx += BF_RING * 64;
+    BfTouch touched;
+    if (BF_TOUCH) touched = bf_touch_stream(a.Wst, 4 * a.wave_frags);
     const float* pbo = reinterpret_cast<const float*>(smem + BF_LDS_PAR), *pgam = pbo + BF_D, *pbet = pbo + 2 * BF_D, *pb2 = pbo + 3 * BF_D;
 
     if (AR > 0) {
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_fwd_kernel(TailFwd a) {
             for (int i = 0; i < 4; ++i) yo[i] = (bf16_t)(v[c2][4 * g + i] + bb[i] + (float)xb[c2][g][i]);
             if (rvalid) *reinterpret_cast<bf16x4*>(a.out + (size_t)row * BF_D + c) = yo;
         }
-    if (touched == 0x7fc07fc1u && a.M < 0) a.mean[0] = 0.f;      // (keeps the prefetch loads alive; never true)
+    if (BF_TOUCH && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.mean[0] = 0.f;      // (keeps the prefetch loads alive; never true)
 }
 
 struct TailBwd {
@@ -258,7 +259,6 @@ __global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
     const int row = min(m0 + m, a.M - 1);
     const bool rvalid = m0 + m < a.M;
 
-    const unsigned touched = BF_TOUCH ? bf_touch_stream(a.Wst, 4 * a.wave_frags) : 0u;
     // ---- loads in the order they are needed (vmcnt retires in order): dy fragments, the first tile's pre-activations, the
     // LayerNorm backward's operands (used at the end: requested now so that they never queue behind the ring), then the ring
     // dy as B fragments (natural k order): lane (m, h) holds dy[row][16 ks + 8 h .. + 7]
@@ -285,6 +285,8 @@ __global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
 #pragma unroll
     for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
     nx += BF_RING * 64;
+    BfTouch touched;
+    if (BF_TOUCH) touched = bf_touch_stream(a.Wst, 4 * a.wave_frags);
 
     // stream: W2^T(0), then per tile t: W2^T(t+1) (slots 16..31), W1^T(t) (slots 0..15); the last tile's W1^T in slots 16..31;
     // then the output projection's dgrad (CR rounds of 32)
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
             if (rvalid) *reinterpret_cast<bf16x4*>(a.dx1 + (size_t)row * BF_D + c) = dx;
             if (CR > 0) *reinterpret_cast<bf16x4*>(smem + BF_LDS_TILE + bf_tile_off(m, c)) = dx;
         }
-    if (touched == 0x7fc07fc1u && a.M < 0) a.dx1[0] = (bf16_t)0.f;  // (keeps the prefetch loads alive; never true)
+    if (BF_TOUCH && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.dx1[0] = (bf16_t)0.f;  // (keeps the prefetch loads alive; never true)
     if (CR == 0) return;
     __syncthreads();
     // ---- do = dx1 Wo: wave w owns output features [w*DI/4, (w+1)*DI/4): 2 feature tiles per round, stream order [ks][f2]

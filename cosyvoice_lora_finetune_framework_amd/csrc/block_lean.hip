@@ -90,7 +90,6 @@ __global__ __launch_bounds__(256, 2) void block_tail_lean_fwd_kernel(LeanFwd a) 
     const int m0 = blockIdx.x * BF_ROWS;
     const int row = min(m0 + m, a.M - 1);
     const bool rvalid = m0 + m < a.M;
-    const unsigned touched = BF_TOUCH ? bf_touch_stream(a.Wst, 4 * a.wave_frags) : 0u;
 
     // ---- loads in the order they are needed: the o tile (-> LDS), this wave's residual features, parameters (-> LDS), the ring
     if (AR > 0) {
@@ -122,6 +121,8 @@ __global__ __launch_bounds__(256, 2) void block_tail_lean_fwd_kernel(LeanFwd a) 
 #pragma unroll
     for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
     nx += BF_RING * 64;
+    BfTouch touched;
+    if (BF_TOUCH) touched = bf_touch_stream(a.Wst, 4 * a.wave_frags);
     const float* pbo = reinterpret_cast<const float*>(smem + BL_PAR), *pgam = pbo + BF_D, *pbet = pbo + 2 * BF_D, *pb2 = pbo + 3 * BF_D;
     __syncthreads();                                   // o tile and parameters are in LDS
 
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void block_tail_lean_fwd_kernel(LeanFwd a) 
             for (int i = 0; i < 4; ++i) yo[i] = (bf16_t)(acc2[c2][4 * g + i] + bb[i] + (float)x1r[i]);
             if (rvalid) *reinterpret_cast<bf16x4*>(a.out + (size_t)row * BF_D + c) = yo;
         }
-    if (touched == 0x7fc07fc1u && a.M < 0) a.mean[0] = 0.f;      // (keeps the prefetch loads alive; never true)
+    if (BF_TOUCH && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.mean[0] = 0.f;      // (keeps the prefetch loads alive; never true)
 }
 
 struct LeanBwd {
@@ -269,7 +270,6 @@ __global__ __launch_bounds__(256, 2) void block_tail_lean_bwd_kernel(LeanBwd a) 
     const int m0 = blockIdx.x * BF_ROWS;
     const int row = min(m0 + m, a.M - 1);
     const bool rvalid = m0 + m < a.M;
-    const unsigned touched = BF_TOUCH ? bf_touch_stream(a.Wst, 4 * a.wave_frags) : 0u;
 
     // this wave's 64 features of dy (-> the shared dy tile) and of x1, the row statistics, gamma (-> LDS), the first z tile, the ring
     {
@@ -294,6 +294,8 @@ __global__ __launch_bounds__(256, 2) void block_tail_lean_bwd_kernel(LeanBwd a) 
 #pragma unroll
     for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
     nx += BF_RING * 64;
+    BfTouch touched;
+    if (BF_TOUCH) touched = bf_touch_stream(a.Wst, 4 * a.wave_frags);
     __syncthreads();
 
     const int nr = a.F / 128;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void block_tail_lean_bwd_kernel(LeanBwd a) 
             if (rvalid) *reinterpret_cast<bf16x4*>(a.dx1 + (size_t)row * BF_D + c) = dx;
             if (CR > 0) *reinterpret_cast<bf16x4*>(smem + BL_YT + bf_tile_off(m, c)) = dx;
         }
-    if (touched == 0x7fc07fc1u && a.M < 0) a.dx1[0] = (bf16_t)0.f;  // (keeps the prefetch loads alive; never true)
+    if (BF_TOUCH && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.dx1[0] = (bf16_t)0.f;  // (keeps the prefetch loads alive; never true)
     if (CR == 0) return;
     __syncthreads();
     // ---- do = dx1 Wo for this wave's DI / 4 output features (2 CR tiles of 32), stream order [ks][f]: ring positions continue

@@ -54,7 +54,6 @@ __global__ __launch_bounds__(256, 1) void block_qkv_fwd_kernel(QkvFwd a) {
     const int m0 = blockIdx.x * BF_ROWS;
     const int row = min(m0 + m, a.M - 1);
     const bool rvalid = m0 + m < a.M;
-    const unsigned touched = BF_TOUCH ? bf_touch_stream(a.Wst, 4 * a.wave_frags) : 0u;
     const int half = NS > 1 ? blockIdx.y : 0;
     const bool writer = half == 0;
 
@@ -101,6 +100,8 @@ __global__ __launch_bounds__(256, 1) void block_qkv_fwd_kernel(QkvFwd a) {
 #pragma unroll
     for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
     nx += BF_RING * 64;
+    BfTouch touched;
+    if (BF_TOUCH) touched = bf_touch_stream(a.Wst, 4 * a.wave_frags);
     const float* pgam = reinterpret_cast<const float*>(smem + BF_LDS_PAR) + BF_D, *pbet = pgam + BF_D;
 
     // ---- LayerNorm -> y tile in LDS -> every wave's B fragments
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void block_qkv_fwd_kernel(QkvFwd a) {
         }
         nx += BF_RING * 64;
     }
-    if (touched == 0x7fc07fc1u && a.M < 0) a.mean[0] = 0.f;      // (keeps the prefetch loads alive; never true)
+    if (BF_TOUCH && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.mean[0] = 0.f;      // (keeps the prefetch loads alive; never true)
 }
 
 struct QkvBwd {
@@ -256,7 +257,6 @@ __global__ __launch_bounds__(256, 1) void block_qkv_bwd_kernel(QkvBwd a) {
     const int m0 = blockIdx.x * BF_ROWS;
     const int row = min(m0 + m, a.M - 1);
     const bool rvalid = m0 + m < a.M;
-    const unsigned touched = BF_TOUCH ? bf_touch_stream(a.Wst, 4 * a.wave_frags) : 0u;
     constexpr int KSW = 24;                            // k-steps per wave: 3N / 16 / 4 (3N = 1536)
     const int ks0 = wave * KSW;
 
@@ -296,6 +296,8 @@ __global__ __launch_bounds__(256, 1) void block_qkv_bwd_kernel(QkvBwd a) {
 #pragma unroll
     for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
     nx += BF_RING * 64;
+    BfTouch touched;
+    if (BF_TOUCH) touched = bf_touch_stream(a.Wst, 4 * a.wave_frags);
     constexpr int VD = 4;                              // V fragments requested ahead (k-steps)
     bf16x8 vf[VD];
     auto vfrag = [&](int k) {
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void block_qkv_bwd_kernel(QkvBwd a) {
             }
             if (rvalid) *reinterpret_cast<bf16x4*>(a.dx + (size_t)row * BF_D + c) = dx;
         }
-    if (touched == 0x7fc07fc1u && a.M < 0) a.dx[0] = (bf16_t)0.f;   // (keeps the prefetch loads alive; never true)
+    if (BF_TOUCH && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.dx[0] = (bf16_t)0.f;   // (keeps the prefetch loads alive; never true)
 }
 
 template <bool DROP, int NS>

@@ -167,8 +167,8 @@ class BlockQkvPack:
         self.W_fwd, nf = _streams(fwd)
         self.W_bwd, nb = _streams(bwd)
         assert nf == nb == self.N3 // 8
-        # 64-row form (csrc/block_qkv_wide.hip): the forward stream is the same; backward, wave w owns feature tiles 2 w, 2 w + 1 over
-        # all of 3N: [ks][c2]
-        bwd = [[WTn[2 * w:2 * w + 2].permute(1, 0, 2, 3)] for w in range(4)]
+        # 64-row form (csrc/block_qkv_wide.hip, 8 waves): the forward stream is the same; backward, wave w owns feature tile w over all
+        # of 3N: [ks]
+        bwd = [[WTn[w]] for w in range(8)]
         self.W_bwd_wide, nbw = _streams(bwd)
-        assert nbw == nf
+        assert nbw == self.N3 // 16

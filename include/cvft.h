@@ -455,7 +455,7 @@ typedef struct {
     void* V; int ldv;                    /* [M][48] out */
     void* dx;                            /* [M][256] out */
     int wide;                            /* 0: W_bwd = wave w's quarter of 3N, [ks][ct] (block_qkv.hip); 1: 64 rows per workgroup
-                                            (block_qkv_wide.hip), W_bwd = wave w's feature tiles 2 w, 2 w + 1 over all of 3N, [ks][c2] */
+                                            (block_qkv_wide.hip, 8 waves), W_bwd = wave w's feature tile w over all of 3N, [ks] */
 } cvft_block_qkv_bwd_args;
 int cvft_block_qkv_bwd(const cvft_block_qkv_bwd_args* a, void* stream);
 
