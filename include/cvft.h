@@ -397,7 +397,12 @@ typedef struct {
                                             1: the CU-sharing form (block_lean.hip: <= 256 registers, 82 KB) -- W_fwd then holds the
                                             "lean" streams: wave w = fragments of ITS 64 output features: natural(Wo, 2 w + c2, ks) in
                                             order [ks][c2]; natural(W1, w, ks); per round r < F / 128: [natural(W1, 4 (r+1) + w, ks)],
-                                            natural(W2, 2 w + c2, 8 r + k') in order [k'][c2]  (same wave_frags) */
+                                            natural(W2, 2 w + c2, 8 r + k') in order [k'][c2]  (same wave_frags);
+                                            2: 64 rows per workgroup (block_wide.hip; F >= 256): the lean groups with the second product
+                                            lagging one round -- G1(0), G1(1), { G1(r + 1), G2(r - 1) : r = 1 .. nr - 2 }, G2(nr - 2),
+                                            G2(nr - 1) with G1(r) = natural(W1, 4 r + w, ks), G2(r) = natural(W2, 2 w + c2, 8 r + k')
+                                            [k'][c2].  In this form z is mandatory, holds whole 64-row groups (ceil(M / 64) * 64 * F
+                                            elements) and stores gelu'(z) instead of z: forward and backward must use the same form */
 } cvft_block_tail_args;
 int cvft_block_tail_fwd(const cvft_block_tail_args* a, void* stream);
 typedef struct {
@@ -410,7 +415,9 @@ typedef struct {
     void* dout; int lddo;                /* dout [M][DI] = dx1 . to_out.weight, or NULL (not wanted / DI == 0) */
     int lean;                            /* as in cvft_block_tail_args; lean W_bwd, wave w: natural(W2^T, w, ks); per round r:
                                             [natural(W2^T, 4 (r+1) + w, ks)], natural(W1^T, 2 w + c2, 8 r + k') in order [k'][c2];
-                                            natural(Wo^T, (DI/128) w + f, ks) in order [ks][f] */
+                                            natural(Wo^T, (DI/128) w + f, ks) in order [ks][f];  2: the same groups in the lagged
+                                            order of the forward's form 2, then the Wo^T groups; z = gelu'(z) as the forward stored it,
+                                            lddo % 8 == 0 */
 } cvft_block_tail_bwd_args;
 int cvft_block_tail_bwd(const cvft_block_tail_bwd_args* a, void* stream);
 
