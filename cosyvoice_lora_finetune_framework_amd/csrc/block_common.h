@@ -77,6 +77,38 @@ __device__ __forceinline__ float bf_gelu(float x) {
     }
 }
 
+// Value AND derivative in one evaluation: the forward kernels save gelu'(z) (bf16) in the workspace the backward reads, so that the
+// backward's activation is one multiplication (with one wave per SIMD every VALU instruction of the activation is added to the
+// wave's MFMA issue time: DESIGN.md section 12).  erf form: Phi(x) = 1/2 + xc P(xc^2), xc = clamp(x, -4, 4), P = degree-8 minimax fit
+// (|error| <= 7e-6 in fp32 Horner; beyond the clamp Phi is 2.6e-5 from 0 / 1), no transcendental;  gelu = x Phi,  gelu' = Phi + x phi(x)
+// with one exp2.  tanh form: as bf_gelu.
+template <int ACT>
+__device__ __forceinline__ void bf_gelu2(float x, float& g, float& dg) {
+    if (ACT == CVFT_ACT_GELU_ERF) {
+        const float xc = __builtin_amdgcn_fmed3f(x, -4.f, 4.f);
+        const float u = xc * xc;
+        float p = fmaf(u, 8.063223411e-11f, -7.003337503e-09f);
+        p = fmaf(p, u, 2.716120992e-07f);
+        p = fmaf(p, u, -6.294948650e-06f);
+        p = fmaf(p, u, 9.890766180e-05f);
+        p = fmaf(p, u, -1.133920192e-03f);
+        p = fmaf(p, u, 9.877472248e-03f);
+        p = fmaf(p, u, -6.641059018e-02f);
+        p = fmaf(p, u, 3.989227081e-01f);
+        const float cdf = fmaf(xc, p, 0.5f);
+        g = x * cdf;
+        const float e2 = __builtin_amdgcn_exp2f(-0.72134752f * x * x);               // exp(-x^2 / 2)
+        dg = fmaf(x * 0.39894228f, e2, cdf);
+    } else {
+        const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
+        const float x2 = x * x;
+        const float w = k0 * x * fmaf(k1, x2, 1.f);
+        const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008f * w));
+        g = x * sg;
+        dg = fmaf(x * 2.f * sg * (1.f - sg), k0 * fmaf(3.f * k1, x2, 1.f), sg);
+    }
+}
+
 // Cold-weight prefetch.  In the training step a block's weight stream was last read a whole step ago: it comes from HBM, and the
 // 32 KB per wave the ring keeps in flight cover an L2 hit (~0.3 us), not an HBM miss (~2 us): the stream ran at half its rate
 // (35 us per launch in the step against 22 us on L2-warm operands).  So every workgroup first TOUCHES one 128-byte line in eight

@@ -43,15 +43,25 @@ struct TailFwd {
 // first fragment + 32)
 template <int ACT, int S0, bool RELOAD>
 __device__ __forceinline__ void bf_ffn_second(bf16x8 (&ring)[BF_RING], const bf16x8* nx, const f32x16& z, f32x16 (&acc2)[BF_CT], bf16x8* zdst) {
-    bf16x8 hb[2], zs[2];
+    bf16x8 hb[2];
+    if (zdst != nullptr) {                             // training: the workspace takes gelu'(z) (block_common.h, bf_gelu2)
+        bf16x8 zs[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        zs[i >> 3][i & 7] = (bf16_t)z[i];
-        hb[i >> 3][i & 7] = (bf16_t)bf_gelu<ACT, false>(z[i]);
-    }
-    if (zdst != nullptr) {
+        for (int i = 0; i < 16; ++i) {
+            float g, dg;
+            bf_gelu2<ACT>(z[i], g, dg);
+            zs[i >> 3][i & 7] = (bf16_t)dg;
+            hb[i >> 3][i & 7] = (bf16_t)g;
+        }
         zdst[0] = zs[0];
         zdst[1] = zs[1];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float g, dg;
+            bf_gelu2<ACT>(z[i], g, dg);
+            hb[i >> 3][i & 7] = (bf16_t)g;
+        }
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
@@ -239,7 +249,7 @@ template <int ACT, int S0, bool RELOAD>
 __device__ __forceinline__ void bf_ffn_second_bwd(bf16x8 (&ring)[BF_RING], const bf16x8* nx, const f32x16& g, const bf16x8 (&zs)[2], f32x16 (&accd)[BF_CT]) {
     bf16x8 hb[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hb[i >> 3][i & 7] = (bf16_t)(g[i] * bf_gelu<ACT, true>((float)zs[i >> 3][i & 7]));
+    for (int i = 0; i < 16; ++i) hb[i >> 3][i & 7] = (bf16_t)(g[i] * (float)zs[i >> 3][i & 7]);      // (the workspace holds gelu'(z))
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll

@@ -199,9 +199,11 @@ __global__ __launch_bounds__(256, 2) void block_tail_lean_fwd_kernel(LeanFwd a) 
     for (int r = 0; r + 1 < nr; ++r) {
         bf16x8 hb[2], zs[2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            zs[i >> 3][i & 7] = (bf16_t)acc1[i];
-            hb[i >> 3][i & 7] = (bf16_t)bf_gelu<ACT, false>(acc1[i]);
+        for (int i = 0; i < 16; ++i) {                  // (the workspace takes gelu'(z): block_common.h, bf_gelu2)
+            float g, dg;
+            bf_gelu2<ACT>(acc1[i], g, dg);
+            zs[i >> 3][i & 7] = (bf16_t)dg;
+            hb[i >> 3][i & 7] = (bf16_t)g;
         }
         acc1 = bf_bias_init(b1s, 4 * (r + 1) + wave, h);
 #pragma unroll
@@ -222,9 +224,11 @@ __global__ __launch_bounds__(256, 2) void block_tail_lean_fwd_kernel(LeanFwd a) 
     {                                                  // last round: its W2 group sits in slots 16..31
         bf16x8 hb[2], zs[2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            zs[i >> 3][i & 7] = (bf16_t)acc1[i];
-            hb[i >> 3][i & 7] = (bf16_t)bf_gelu<ACT, false>(acc1[i]);
+        for (int i = 0; i < 16; ++i) {                  // (the workspace takes gelu'(z): block_common.h, bf_gelu2)
+            float g, dg;
+            bf_gelu2<ACT>(acc1[i], g, dg);
+            zs[i >> 3][i & 7] = (bf16_t)dg;
+            hb[i >> 3][i & 7] = (bf16_t)g;
         }
         if (zp != nullptr) {
             zp[(size_t)(nr - 1) * 4 * 128] = zs[0];
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void block_tail_lean_bwd_kernel(LeanBwd a) 
     for (int r = 0; r + 1 < nr; ++r) {
         bf16x8 hb[2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hb[i >> 3][i & 7] = (bf16_t)(accg[i] * bf_gelu<ACT, true>((float)zs[i >> 3][i & 7]));
+        for (int i = 0; i < 16; ++i) hb[i >> 3][i & 7] = (bf16_t)(accg[i] * (float)zs[i >> 3][i & 7]);
         zs[0] = zp[(size_t)(r + 1) * 4 * 128];
         zs[1] = zp[(size_t)(r + 1) * 4 * 128 + 1];
         accg = zero16();
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void block_tail_lean_bwd_kernel(LeanBwd a) 
     {                                                  // last round: its W1^T group sits in slots 16..31
         bf16x8 hb[2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hb[i >> 3][i & 7] = (bf16_t)(accg[i] * bf_gelu<ACT, true>((float)zs[i >> 3][i & 7]));
+        for (int i = 0; i < 16; ++i) hb[i >> 3][i & 7] = (bf16_t)(accg[i] * (float)zs[i >> 3][i & 7]);
         char* ht = smem + BL_HT + ((nr - 1) & 1) * 4 * BL_HT_TILE;
         bl_put_tile(ht + wave * BL_HT_TILE, m, h, hb);
         __syncthreads();

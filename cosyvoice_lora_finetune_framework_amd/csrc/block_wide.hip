@@ -112,38 +112,6 @@ __device__ __forceinline__ void bw_store_rows256(const char* tiles, bf16_t* dst,
     }
 }
 
-// Activation of the wide kernels: value AND derivative in one evaluation -- the forward kernel saves gelu'(z) (bf16) where the
-// other forms save z, so the backward kernel's activation work is one multiplication per element (with one wave per SIMD the
-// activation's VALU instructions compete with the MFMAs for the wave's issue slots: 75 cycles per element for the exp + rcp form).
-// erf form: Phi(x) = 1/2 + xc P(xc^2), xc = clamp(x, -4, 4), P = degree-8 minimax fit (|error| <= 7e-6 in fp32 Horner; beyond the
-// clamp Phi is 2.6e-5 from 0 / 1), no transcendental;  gelu = x Phi,  gelu' = Phi + x phi(x) with one exp2.
-// tanh form: as bf_gelu.
-template <int ACT>
-__device__ __forceinline__ void bw_gelu2(float x, float& g, float& dg) {
-    if (ACT == CVFT_ACT_GELU_ERF) {
-        const float xc = __builtin_amdgcn_fmed3f(x, -4.f, 4.f);
-        const float u = xc * xc;
-        float p = fmaf(u, 8.063223411e-11f, -7.003337503e-09f);
-        p = fmaf(p, u, 2.716120992e-07f);
-        p = fmaf(p, u, -6.294948650e-06f);
-        p = fmaf(p, u, 9.890766180e-05f);
-        p = fmaf(p, u, -1.133920192e-03f);
-        p = fmaf(p, u, 9.877472248e-03f);
-        p = fmaf(p, u, -6.641059018e-02f);
-        p = fmaf(p, u, 3.989227081e-01f);
-        const float cdf = fmaf(xc, p, 0.5f);
-        g = x * cdf;
-        const float e2 = __builtin_amdgcn_exp2f(-0.72134752f * x * x);               // exp(-x^2 / 2)
-        dg = fmaf(x * 0.39894228f, e2, cdf);
-    } else {
-        const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
-        const float x2 = x * x;
-        const float w = k0 * x * fmaf(k1, x2, 1.f);
-        const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008f * w));
-        g = x * sg;
-        dg = fmaf(x * 2.f * sg * (1.f - sg), k0 * fmaf(3.f * k1, x2, 1.f), sg);
-    }
-}
 // cold-weight touches (bf_touch_stream) with a compile-time trip count: a run-time loop of loads makes the compiler wait for ALL
 // outstanding loads at the next use of any of them (the counter is unknown after the loop)
 struct BwTouch { unsigned v[8]; };
@@ -434,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_fwd_kernel(WideFwd a) 
 #ifdef BW_DBG_NOACT
         g = acc1[t][i]; dg = g;
 #else
-        bw_gelu2<ACT>(acc1[t][i], g, dg);
+        bf_gelu2<ACT>(acc1[t][i], g, dg);
 #endif
         zcur[t][i & 7] = (bf16_t)dg;
         hcur[t][i & 3] = (bf16_t)g;
@@ -561,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
     auto none = [](int) __attribute__((always_inline)) {};
     auto act = [&](int e) __attribute__((always_inline)) {
         const int t = e >> 4, i = e & 15;
-        hcur[t][i & 3] = (bf16_t)(accg[t][i] * (float)zs[t][i >> 3][i & 7]);       // (z holds gelu'(z): see bw_gelu2)
+        hcur[t][i & 3] = (bf16_t)(accg[t][i] * (float)zs[t][i >> 3][i & 7]);       // (z holds gelu'(z): see bf_gelu2)
         if ((i & 3) == 3)
             *reinterpret_cast<bf16x4*>(smem + BW_HT + ((rc & 1) * 8 + wave * 2 + t) * BW_HT_TILE + m * 80 + (8 * (i >> 2) + 4 * h) * 2) = hcur[t];
     };

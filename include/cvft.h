@@ -390,7 +390,8 @@ typedef struct {
     const float* b1; int F;
     const float* b2;
     int act;
-    void* z;                             /* pre-activation workspace or NULL (inference) */
+    void* z;                             /* backward workspace or NULL (inference): gelu'(pre-activation), bf16, in the producing wave's
+                                            accumulator order [row tile][F / 32][64 lanes][16] */
     float* mean; float* rstd;            /* [M] LayerNorm statistics of x1 (saved for backward) */
     void* out;                           /* [M][256] */
     int lean;                            /* 0: W_fwd as above, the workgroup owns its CU (512 registers per lane, 155 KB LDS);
@@ -402,7 +403,7 @@ typedef struct {
                                             lagging one round -- G1(0), G1(1), { G1(r + 1), G2(r - 1) : r = 1 .. nr - 2 }, G2(nr - 2),
                                             G2(nr - 1) with G1(r) = natural(W1, 4 r + w, ks), G2(r) = natural(W2, 2 w + c2, 8 r + k')
                                             [k'][c2].  In this form z is mandatory, holds whole 64-row groups (ceil(M / 64) * 64 * F
-                                            elements) and stores gelu'(z) instead of z: forward and backward must use the same form */
+                                            elements): forward and backward must use the same form */
 } cvft_block_tail_args;
 int cvft_block_tail_fwd(const cvft_block_tail_args* a, void* stream);
 typedef struct {
@@ -416,8 +417,7 @@ typedef struct {
     int lean;                            /* as in cvft_block_tail_args; lean W_bwd, wave w: natural(W2^T, w, ks); per round r:
                                             [natural(W2^T, 4 (r+1) + w, ks)], natural(W1^T, 2 w + c2, 8 r + k') in order [k'][c2];
                                             natural(Wo^T, (DI/128) w + f, ks) in order [ks][f];  2: the same groups in the lagged
-                                            order of the forward's form 2, then the Wo^T groups; z = gelu'(z) as the forward stored it,
-                                            lddo % 8 == 0 */
+                                            order of the forward's form 2, then the Wo^T groups; lddo % 8 == 0 */
 } cvft_block_tail_bwd_args;
 int cvft_block_tail_bwd(const cvft_block_tail_bwd_args* a, void* stream);
 
