@@ -1350,10 +1350,14 @@ class BlockTailFn(torch.autograd.Function):
         a.M = M
         x1 = x0
         assert (o is not None) == (pack.DI > 0), "BlockTailPack built with / without to_out must match the call"
-        ctx.lean = block_tail_lean()
-        if ctx.lean == 2 and pack.F < 256:             # (the wide form's rounds lag by one: it needs two of them)
-            ctx.lean = 1
-        a.DI, a.W_fwd, a.lean = pack.DI, ptr((pack.W_fwd, pack.W_fwd_lean, pack.W_fwd_wide)[ctx.lean]), int(ctx.lean)
+        mode = block_tail_lean()
+        if mode >= 2 and pack.F < 256:                 # (the 64-row forms' rounds lag by one: they need two of them)
+            mode = 1
+        # every form saves gelu'(z) in the same [row tile][hidden tile][64 lanes][16] order, so the two directions may use different
+        # forms: 3 = 32-row forward (the faster forward) + 64-row backward (same latency as the 32-row one on half the CUs)
+        ctx.lean = 2 if mode == 3 else mode
+        fwd_form = 0 if mode == 3 else mode
+        a.DI, a.W_fwd, a.lean = pack.DI, ptr((pack.W_fwd, pack.W_fwd_lean, pack.W_fwd_wide)[fwd_form]), int(fwd_form)
         if o is not None:
             assert o.shape == (M, pack.DI) and o.stride(1) == 1
             x1 = torch.empty_like(x0)
@@ -1363,7 +1367,7 @@ class BlockTailFn(torch.autograd.Function):
         mean = torch.empty(M, dtype=torch.float32, device=x0.device)
         rstd = torch.empty(M, dtype=torch.float32, device=x0.device)
         # (the wide form always stores z and works on whole 64-row groups)
-        z = torch.empty(-(-M // 64) * 64 * pack.F, dtype=x0.dtype, device=x0.device) if (need or ctx.lean == 2) else None
+        z = torch.empty(-(-M // 64) * 64 * pack.F, dtype=x0.dtype, device=x0.device) if (need or fwd_form == 2) else None
         a.x1, a.gamma, a.beta, a.eps = ptr(x1), ptr(pack.gamma), ptr(pack.beta), pack.eps
         a.b1, a.F, a.b2, a.act = ptr(pack.b1), pack.F, ptr(pack.b2), ACT[act]
         a.z, a.mean, a.rstd, a.out = ptr(z), ptr(mean), ptr(rstd), ptr(out)
@@ -1534,16 +1538,19 @@ def can_block_tail(x: torch.Tensor, d_ff: int, d_inner: int) -> bool:
 
 
 BLOCK_FUSE = _os.environ.get("CVFT_BLOCK_FUSE", "1") != "0"
-# CU-sharing form of the block-tail kernels (csrc/block_lean.hip): opt-in (1) or "auto" (when >= 3 chains are in flight).  Measured, same-box
-# A/B: joint 22.85 (CU-owning form) vs 22.99 ms (this form), flow_only 15.01 vs 15.16 -- sharing the CU does not pay, so the default is 0
-BLOCK_LEAN = _os.environ.get("CVFT_BLOCK_LEAN", "0")
+# Form of the block-tail kernels: 0 = CU-owning 32-row form (block_fused.hip), 1 = CU-sharing 32-row form (block_lean.hip), 2 = 64-row form
+# (block_wide.hip), 3 = 32-row forward + 64-row backward, "auto" (default) = 3 while >= 3 chains share the chip, else 0.  Measured, same-box
+# A/Bs (DESIGN sections 11 / 12): joint 22.85 (0) / 22.99 (1) / 22.71 (2) / 23.2 -> 22.8 (3); flow_only 14.66 (0) / 15.0 (3) / 15.7 (2): the 64-row
+# backward has the 32-row one's latency on half the CUs, the 64-row forward is 9 us longer -- fewer CUs only pay when the chip is shared
+BLOCK_LEAN = _os.environ.get("CVFT_BLOCK_LEAN", "auto")
 
 
 def block_tail_lean() -> int:
-    """0: CU-owning 32-row form (block_fused.hip); 1: CU-sharing 32-row form; 2: wide 64-row form (block_lean.hip)"""
-    if BLOCK_LEAN in ("0", "1", "2"):
+    """0: CU-owning 32-row form (block_fused.hip); 1: CU-sharing 32-row form (block_lean.hip); 2: 64-row form (block_wide.hip);
+    3: 32-row forward + 64-row backward"""
+    if BLOCK_LEAN in ("0", "1", "2", "3"):
         return int(BLOCK_LEAN)
-    return 1 if lib().cvft_concurrent_chains() >= 3 else 0
+    return 3 if lib().cvft_concurrent_chains() >= 3 else 0
 BLOCK_QKV_FUSE = _os.environ.get("CVFT_BLOCK_QKV_FUSE", "1") != "0"      # first half of the block (norm1 + stacked LoRA q|k|v)
 BLOCK_QKV_WIDE = _os.environ.get("CVFT_BLOCK_QKV_WIDE", "0") != "0"      # its 64-rows-per-workgroup form (csrc/block_qkv_wide.hip)
 
