@@ -20,6 +20,12 @@ extern "C" int cvft_debug_block_stamps(unsigned long long* host_out) {
 #define BF_STAMP(i)
 #endif
 
+// A value loaded BEFORE a run-time loop that issues loads and first used AFTER it makes the compiler wait for every outstanding load
+// at that use (it cannot count the loop's loads: s_waitcnt vmcnt(0)) -- including the ring's re-requests of the moment.  Pinning
+// the value (an empty asm that "modifies" it) behind the next barrier moves the wait to where the value has long arrived.
+#define BF_PIN(x) asm volatile("" : "+v"(x))
+#define BF_PIN64(x) asm volatile("" : "+v"(reinterpret_cast<unsigned long long&>(x)))     /* an 8-byte vector */
+
 #define BF_ROWS 32
 #define BF_D 256
 #define BF_CT (BF_D / 32)                 // 8 output-feature tiles of the residual stream

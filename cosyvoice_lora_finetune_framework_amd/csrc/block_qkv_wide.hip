@@ -17,6 +17,9 @@
                                                 // other instruction of the same wave comes on top (tools/ub/mfma_valu.hip); with <= 256
                                                 // registers per wave the row tiles' B fragments are read from LDS, one step ahead
 #define QW_RING 16                              // weight fragments in flight per wave (8 x 16 KB per CU)
+#ifndef QW_AHEAD
+#define QW_AHEAD 1                              // B fragments requested this many steps ahead of their MFMAs
+#endif
 // LDS carve
 #define QW_XT 0                                 // x tiles 2 x [32][256] swizzled (backward: x, then dx)
 #define QW_YT 32768                             // forward: LN(x) tiles;  backward: dres tiles
@@ -304,17 +307,19 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_fwd_kernel(QwFwd
         f32x16 acc[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) acc[rt] = bf_bias_init(bs, nt, h);
-        bf16x8 bq[2][2];
+        bf16x8 bq[QW_AHEAD + 1][2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) bq[0][rt] = qw_frag256(smem + QW_YT + rt * 16384, m, h, 0);
+        for (int ks = 0; ks < QW_AHEAD; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) bq[ks][rt] = qw_frag256(smem + QW_YT + rt * 16384, m, h, ks);
 #pragma unroll
         for (int ks = 0; ks < BF_KS; ++ks) {
-            if (ks + 1 < BF_KS) {
+            if (ks + QW_AHEAD < BF_KS) {
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) bq[(ks + 1) & 1][rt] = qw_frag256(smem + QW_YT + rt * 16384, m, h, ks + 1);
+                for (int rt = 0; rt < 2; ++rt) bq[(ks + QW_AHEAD) % (QW_AHEAD + 1)][rt] = qw_frag256(smem + QW_YT + rt * 16384, m, h, ks + QW_AHEAD);
             }
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) acc[rt] = mfma32(ring[ks], bq[ks & 1][rt], acc[rt]);
+            for (int rt = 0; rt < 2; ++rt) acc[rt] = mfma32(ring[ks], bq[ks % (QW_AHEAD + 1)][rt], acc[rt]);
             if (i + 1 < 6) ring[ks] = nx[ks * 64];
         }
         nx += QW_RING * 64;
@@ -371,6 +376,7 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_bwd_kernel(QwBwd
 #pragma unroll
     for (int t = 0; t < 2; ++t) { row[t] = min(m0 + 32 * t + m, a.M - 1); rvalid[t] = m0 + 32 * t + m < a.M; }
 
+    BF_STAMP(20);
     // ---- requests: the first dY chunk, the ring, then x / dres tiles, LayerNorm operands, adapter operands, touches
     bf16x8 dv[4];
     qw_load_rows256(a.dY, a.lddy, 0, m0, a.M, dv);
@@ -405,6 +411,9 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_bwd_kernel(QwBwd
     if (BF_TOUCH) touched = qw_touch_stream(a.Wst, 768);
     qw_rows256_to_lds(smem + QW_STG, dv);              // chunk 0 -> buffer 0
     __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { BF_PIN(mean[t]); BF_PIN(rstd[t]); }
+    BF_STAMP(21);
 
     // B_blk^T fragment of k-step ks for V = s dY B_blk: rows 0..31 (q|k adapters, block-diagonal zeros select) or 32..47 (v)
     auto vfrag = [&](int ks) __attribute__((always_inline)) {
@@ -416,34 +425,39 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_bwd_kernel(QwBwd
     // B fragment picked by address; the adapters change class at k-step 64 = chunk 4: one accumulator, handed over once.
     const int vrt = wave & 1, vk = wave >> 1;
     f32x16 acc[2] = {zero16(), zero16()}, v01 = zero16(), vacc = zero16();
-    bf16x8 vf = vfrag(vk);
 #pragma unroll 1
     for (int q = 0; q < 6; ++q) {
+        BF_STAMP(22 + q);
         const char* buf = smem + QW_STG + (q & 1) * 32768;
-        qw_load_rows256(a.dY, a.lddy, 256 * min(q + 1, 5), m0, a.M, dv);      // (the last round re-requests chunk 5: nobody reads it)
-        bf16x8 bq[2][2];
+        // this chunk's four B_blk^T fragments and the next dY chunk are requested BEFORE the chunk's ring re-requests: vmcnt retires in
+        // order, and a fragment needed in a few steps must not queue behind fragments needed a chunk later
+        bf16x8 vfa[4];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) bq[0][rt] = qw_frag256(buf + rt * 16384, m, h, 0);
+        for (int j = 0; j < 4; ++j) vfa[j] = vfrag(16 * q + 4 * j + vk);
+        qw_load_rows256(a.dY, a.lddy, 256 * min(q + 1, 5), m0, a.M, dv);      // (the last round re-requests chunk 5: nobody reads it)
+        bf16x8 bq[QW_AHEAD + 1][2];
+#pragma unroll
+        for (int k = 0; k < QW_AHEAD; ++k)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) bq[k][rt] = qw_frag256(buf + rt * 16384, m, h, k);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            if (k + 1 < 16) {
+            if (k + QW_AHEAD < 16) {
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) bq[(k + 1) & 1][rt] = qw_frag256(buf + rt * 16384, m, h, k + 1);
+                for (int rt = 0; rt < 2; ++rt) bq[(k + QW_AHEAD) % (QW_AHEAD + 1)][rt] = qw_frag256(buf + rt * 16384, m, h, k + QW_AHEAD);
             }
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) acc[rt] = mfma32(ring[k], bq[k & 1][rt], acc[rt]);
+            for (int rt = 0; rt < 2; ++rt) acc[rt] = mfma32(ring[k], bq[k % (QW_AHEAD + 1)][rt], acc[rt]);
             ring[k] = nx[k * 64];                      // (the last round reads the 16 fragments behind this wave's stream)
-            if ((k & 3) == 3) {                        // this wave's V step of the group: k-step 16 q + (k - 3) + vk, row tile vrt
-                const int kl = k - 3 + vk;
-                vacc = mfma32(vf, qw_frag256(buf + vrt * 16384, m, h, kl), vacc);
-                vf = vfrag(min(16 * q + kl + 4, 95));
-            }
+            if ((k & 3) == 3)                          // this wave's V step of the group: k-step 16 q + (k - 3) + vk, row tile vrt
+                vacc = mfma32(vfa[k >> 2], qw_frag256(buf + vrt * 16384, m, h, k - 3 + vk), vacc);
         }
         nx += QW_RING * 64;
         if (q == 3) { v01 = vacc; vacc = zero16(); }
         qw_rows256_to_lds(smem + QW_STG + ((q + 1) & 1) * 32768, dv);
         __syncthreads();
     }
+    BF_STAMP(28);
     // ---- V partials (rows 0..31 of v01: q|k adapters; rows 0..15 of vacc: v adapter) meet in LDS (the chunk buffers' place); every
     // wave needs V (bf16, as stored) of both row tiles for the side term
     bf16x8 hbV[2][3];
@@ -482,6 +496,7 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_bwd_kernel(QwBwd
             }
         }
     }
+    BF_STAMP(29);
     // ---- masked side term of this wave's features: dy += keep_t / (1-p) (A_t^T V_t^T)
     {
         unsigned long long keys[3] = {0, 0, 0};
@@ -506,6 +521,7 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_bwd_kernel(QwBwd
                 }
             }
     }
+    BF_STAMP(30);
     // ---- LayerNorm backward + residual branch: dx = dres + rstd (g.v - mean_c(g.v) - xhat mean_c(g.v.xhat)); x / dres from the tiles
     float sp[2][2], all[16][2];
     bf16x4 xr[2][4];
@@ -528,7 +544,9 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_bwd_kernel(QwBwd
         sp[0][rt] += __shfl_xor(sp[0][rt], 32, 64);
         sp[1][rt] += __shfl_xor(sp[1][rt], 32, 64);
     }
+    BF_STAMP(12);
     qw_exchange(smem, wave, lane, sp, all);
+    BF_STAMP(13);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         float m1 = 0.f, m2 = 0.f;
@@ -549,8 +567,11 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_bwd_kernel(QwBwd
             *reinterpret_cast<bf16x4*>(smem + QW_XT + rt * 16384 + bf_tile_off(m, c)) = dx;      // (over this lane's own x values)
         }
     }
+    BF_STAMP(14);
     __syncthreads();
+    BF_STAMP(15);
     qw_store_rows256(smem + QW_XT, a.dx, m0, a.M);
+    BF_STAMP(31);
     if (BF_TOUCH && qw_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.dx[0] = (bf16_t)0.f;   // (keeps the prefetch loads alive; never true)
 }
 

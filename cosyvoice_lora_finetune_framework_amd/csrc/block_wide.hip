@@ -521,6 +521,8 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
     bw_rows256_to_lds(XT, xv);
     const float* pgam = reinterpret_cast<const float*>(smem + BW_PAR);
     __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { BF_PIN(mean[t]); BF_PIN(rstd[t]); }
     f32x16 accd[2][2], accg[2], accn[2];
     int rc = 0;
     bf16x4 hcur[2];

@@ -31,6 +31,13 @@ def main():
         nxt = t[5 + 2 * (i + 1)] if i < 5 else t[17]
         builtins.print(f"  tile {i}: MFMAs {t[6 + 2 * i] - t[5 + 2 * i]:6d}   ext + staging/store {nxt - t[6 + 2 * i]:6d}")
     builtins.print(f"total {t[17] - t[0]}")
+    builtins.print("backward:")
+    builtins.print(f"dY chunk 0, x, dres in LDS   +{t[21] - t[20]:7d}")
+    for q in range(6):
+        builtins.print(f"  chunk {q}: {t[23 + q] - t[22 + q]:6d}")
+    builtins.print(f"V exchange                   +{t[29] - t[28]:7d}")
+    builtins.print(f"side term                    +{t[30] - t[29]:7d}")
+    builtins.print(f"LN backward: sums {t[12] - t[30]}, exchange {t[13] - t[12]}, dx -> tile {t[14] - t[13]}, barrier {t[15] - t[14]}, store {t[31] - t[15]}  (total {t[31] - t[20]})")
 
 
 if __name__ == "__main__":
