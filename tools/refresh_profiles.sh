@@ -6,12 +6,14 @@ set -e -o pipefail
 OUT=gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
-python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.log 2>&1
-tail -1 $OUT/bench_n1.log > $OUT/bench_n1.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/prof.log 2>&1
 cp "$(find $OUT/prof -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
 python tools/step_summary.py "$(find $OUT/prof -name '*kernel_trace.csv' | head -1)" $OUT/step_summary.json joint 16 500
 rm -rf $OUT/prof
+# (the bench line takes launches / kernel time per step from the newest profiles/*step_summary*.json: this build's trace first)
+cp $OUT/step_summary.json profiles/r3_step_summary.json
+python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.log 2>&1
+tail -1 $OUT/bench_n1.log > $OUT/bench_n1.json
 python tools/counters.py collect $OUT/counters > $OUT/counters.log 2>&1
 python tools/counters.py summarise $OUT/counters $OUT/counters.json > $OUT/counters.txt
 F=$(find $OUT/counters/fetch -name '*counter_collection.csv' | head -1)
@@ -21,6 +23,7 @@ python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi128ELi128ELi4ELi2ELi0ELi2E
 python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi96ELi256ELi3ELi4ELi0ELi3ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,96,256,3,4,ns3,regepi>' $OUT/pmc_traffic_96x256.json || true
 python tools/pmc_traffic.py $F $W 'block_tail_fwd_kernel' 'block_tail_fwd' $OUT/pmc_traffic_block_tail_fwd.json || true
 python tools/pmc_traffic.py $F $W 'block_qkv_fwd_kernel' 'block_qkv_fwd' $OUT/pmc_traffic_block_qkv_fwd.json || true
+python tools/pmc_traffic.py $F $W 'block_tail_wide_bwd_kernel' 'block_tail_wide_bwd' $OUT/pmc_traffic_block_tail_wide_bwd.json || true
 rm -rf $OUT/counters
 python bench.py --workload flow_only --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_flow_only_b8.json
 python bench.py --workload flow_only --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_flow_only_b16.json
