@@ -435,6 +435,7 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_bwd_kernel(QwBwd
 #pragma unroll
         for (int j = 0; j < 4; ++j) vfa[j] = vfrag(16 * q + 4 * j + vk);
         qw_load_rows256(a.dY, a.lddy, 256 * min(q + 1, 5), m0, a.M, dv);      // (the last round re-requests chunk 5: nobody reads it)
+        __builtin_amdgcn_sched_barrier(0);             // (at 256 registers the compiler otherwise sinks these requests to their uses)
         bf16x8 bq[QW_AHEAD + 1][2];
 #pragma unroll
         for (int k = 0; k < QW_AHEAD; ++k)

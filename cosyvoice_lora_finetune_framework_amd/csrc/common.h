@@ -173,11 +173,20 @@ __device__ __forceinline__ unsigned long long cvft_mix64(unsigned long long z) {
 __device__ __forceinline__ unsigned long long cvft_drop_key(const long long* seed, unsigned site) {
     return cvft_mix64((unsigned long long)seed[0] ^ ((unsigned long long)site << 32));
 }
-// 16 random bits per element: ONE SplitMix64 draw serves a group of 4 consecutive elements (its four 16-bit fields).  The
-// draw costs two 64-bit multiplies -- quarter-rate integer work, ~35 issue slots -- and these masks are re-derived inside
-// GEMM epilogues, rank-side products and the dropout passes of every train-mode step; at 32 bits per element (two draws
-// per group) the masked-extension GEMM launches ran 1.3-1.8x their plain twins on mask arithmetic alone.  p is quantised
-// to 1/65536 (0.05 -> 0.050003), the keep scale stays 1 / (1 - p).
+// 16 random bits per element: ONE draw of 64 bits serves a group of 4 consecutive elements (its four 16-bit fields).  The draw is
+// two 32-bit murmur3 finalisers of the group index under the two halves of the site key: four 32-bit multiplies (quarter-rate
+// integer work) against the 64-bit SplitMix finaliser's two 64 x 64 multiplies (four 32-bit multiplies EACH plus carries) --
+// measured in the q|k|v chain kernels, where three masks per element are re-derived each way: the mask phases were 6.9 k (forward)
+// and 5.4 k (backward) ticks of a ~50 k-tick launch.  These masks are re-derived inside GEMM epilogues,
+// rank-side products and the dropout passes of every train-mode step.  p is quantised to 1/65536 (0.05 -> 0.050003), the keep
+// scale stays 1 / (1 - p).  The group index is taken modulo 2^32 (tensors of up to 2^34 elements have distinct groups).
+__device__ __forceinline__ unsigned cvft_fmix32(unsigned h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    return h ^ (h >> 16);
+}
 // Rates the 16-bit fields represent without bias: p == 0 (off) or 2^-16 <= p <= 1 - 2^-16.  Below 2^-16 the threshold rounds to
 // 0 (nothing dropped, everything still scaled by 1 / (1 - p)); above 1 - 2^-16 it clamps (1 in 65536 kept, scaled by a huge
 // factor): every C entry that takes a dropout rate rejects those (CVFT_CHECK_ARG), see include/cvft.h "Dropout masks".
@@ -185,8 +194,8 @@ static inline bool cvft_drop_rate_ok(float p) { return p == 0.f || (p >= 1.f / 6
 __device__ __forceinline__ unsigned cvft_drop_thr(float p) { return (unsigned)fminf(65535.f, rintf(p * 65536.f)); }
 // keep flags of elements 4g .. 4g+3: field e of the draw >= thr
 __device__ __forceinline__ void cvft_keep4(unsigned long long key, unsigned long long g, unsigned thr, bool (&k)[4]) {
-    const unsigned long long r = cvft_mix64(key + g);
-    const unsigned lo = (unsigned)r, hi = (unsigned)(r >> 32);
+    const unsigned gl = (unsigned)g;
+    const unsigned lo = cvft_fmix32(gl ^ (unsigned)key), hi = cvft_fmix32(gl ^ (unsigned)(key >> 32));
     k[0] = (lo & 0xffffu) >= thr; k[1] = (lo >> 16) >= thr; k[2] = (hi & 0xffffu) >= thr; k[3] = (hi >> 16) >= thr;
 }
 

@@ -280,7 +280,7 @@ int cvft_act_dropout(int dtype, int64_t n, int act, const void* z, const void* d
  *                         stacked q|k|v adapters); xd (NULL or 3 pointers, one per DISTINCT site, entries may be NULL): also
  *                         writes drop_t(X) = keep_t X / (1-p), [M][K] each, for the backward's dA_t = V_t^T drop_t(X)
  *   cvft_lora_side_dgrad: out[m,k] = dx[m,k] + sum_t keep_t(m,k)/(1-p) * sum_j V[m,16t+j] A[16t+j][k] */
-/* Dropout masks: keep(i) is a pure function of (*seed, site, element index i) -- one SplitMix64 draw per group of 4 consecutive
+/* Dropout masks: keep(i) is a pure function of (*seed, site, element index i) -- one 64-bit draw (two 32-bit murmur3 finalisers of the group index under the halves of the SplitMix64 site key) per group of 4 consecutive
  * elements, a 16-bit field each, kept when field >= rint(p * 65536); kept values are scaled by the nominal 1 / (1 - p).  The
  * rate is therefore quantised to 1/65536 (0.05 -> 0.050003); every entry point that takes a rate accepts p == 0 (off, where the
  * entry allows it) or 2^-16 <= p <= 1 - 2^-16 and rejects anything else (a smaller p would drop nothing yet still scale, a

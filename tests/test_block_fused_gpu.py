@@ -115,7 +115,8 @@ def _qkv_case(M, p, seed):
 
 
 def _keep_mask(M, Kd, p, seed, site):
-    """host replica of the counter-based mask (csrc/common.h): SplitMix64 finaliser, one draw per 4 elements, 16-bit fields"""
+    """host replica of the counter-based mask (csrc/common.h): site key = SplitMix64 finaliser of (seed, site); one draw per 4 elements =
+    two murmur3 32-bit finalisers of the group index under the key's halves, 16-bit fields"""
     import numpy as np
     M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -124,12 +125,20 @@ def _keep_mask(M, Kd, p, seed, site):
         z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & M64
         z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & M64
         return z ^ (z >> np.uint64(31))
+
+    def fmix32(h):
+        h = h ^ (h >> np.uint32(16))
+        h = (h.astype(np.uint64) * np.uint64(0x85ebca6b)).astype(np.uint32)
+        h = h ^ (h >> np.uint32(13))
+        h = (h.astype(np.uint64) * np.uint64(0xc2b2ae35)).astype(np.uint32)
+        return h ^ (h >> np.uint32(16))
     with np.errstate(over="ignore"):
         key = mix(np.uint64(seed) ^ (np.uint64(site) << np.uint64(32)))
-        grp = np.arange(M * Kd // 4, dtype=np.uint64)
-        rnd = mix((key + grp) & M64)
+        grp = np.arange(M * Kd // 4, dtype=np.uint32)
+        lo = fmix32(grp ^ np.uint32(int(key) & 0xFFFFFFFF))
+        hi = fmix32(grp ^ np.uint32(int(key) >> 32))
     thr = min(65535, int(round(p * 65536)))
-    fields = np.stack([(rnd >> np.uint64(16 * e)) & np.uint64(0xffff) for e in range(4)], 1).reshape(M, Kd)
+    fields = np.stack([lo & np.uint32(0xffff), lo >> np.uint32(16), hi & np.uint32(0xffff), hi >> np.uint32(16)], 1).reshape(M, Kd)
     return torch.from_numpy((fields >= thr).astype("float32"))
 
 

@@ -971,12 +971,19 @@ def _keep_scale_host(seed: int, site: int, n: int, p: float) -> torch.Tensor:
         z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & M
         z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & M
         return z ^ (z >> np.uint64(31))
+    def fmix32(h):
+        h = h ^ (h >> np.uint32(16))
+        h = (h.astype(np.uint64) * np.uint64(0x85ebca6b)).astype(np.uint32)
+        h = h ^ (h >> np.uint32(13))
+        h = (h.astype(np.uint64) * np.uint64(0xc2b2ae35)).astype(np.uint32)
+        return h ^ (h >> np.uint32(16))
     with np.errstate(over="ignore"):
-        key = mix(np.uint64(seed) ^ (np.uint64(site) << np.uint64(32)))
-        g = np.arange((n + 3) // 4, dtype=np.uint64)
-        r = mix(key + g)                                        # one draw per 4 elements, 16-bit fields
-    f = np.uint64(0xFFFF)
-    u = np.stack([r & f, (r >> np.uint64(16)) & f, (r >> np.uint64(32)) & f, r >> np.uint64(48)], 1).reshape(-1)[:n]
+        key = int(mix(np.uint64(seed) ^ (np.uint64(site) << np.uint64(32))))
+        g = np.arange((n + 3) // 4, dtype=np.uint32)
+        lo = fmix32(g ^ np.uint32(key & 0xFFFFFFFF))            # one draw per 4 elements: two 32-bit finalisers, 16-bit fields
+        hi = fmix32(g ^ np.uint32(key >> 32))
+    f = np.uint32(0xFFFF)
+    u = np.stack([lo & f, lo >> np.uint32(16), hi & f, hi >> np.uint32(16)], 1).reshape(-1)[:n].astype(np.uint64)
     thr = int(min(65535.0, float(np.rint(np.float32(p) * np.float32(65536.0)))))
     return torch.from_numpy((u >= np.uint64(thr)).astype(np.float64)) / (1.0 - float(np.float32(p)))
 
