@@ -17,9 +17,8 @@
                                                 // other instruction of the same wave comes on top (tools/ub/mfma_valu.hip); with <= 256
                                                 // registers per wave the row tiles' B fragments are read from LDS, one step ahead
 #define QW_RING 16                              // weight fragments in flight per wave (8 x 16 KB per CU)
-#ifndef QW_AHEAD
-#define QW_AHEAD 1                              // B fragments requested this many steps ahead of their MFMAs
-#endif
+#define QW_AHEAD 2                              // B fragments requested this many steps ahead of their MFMAs (forward)
+#define QW_AHEAD_BWD 1                          // (backward: 256 registers are full)
 // LDS carve
 #define QW_XT 0                                 // x tiles 2 x [32][256] swizzled (backward: x, then dx)
 #define QW_YT 32768                             // forward: LN(x) tiles;  backward: dres tiles
@@ -321,6 +320,7 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_fwd_kernel(QwFwd
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) acc[rt] = mfma32(ring[ks], bq[ks % (QW_AHEAD + 1)][rt], acc[rt]);
             if (i + 1 < 6) ring[ks] = nx[ks * 64];
+            __builtin_amdgcn_sched_barrier(0);
         }
         nx += QW_RING * 64;
         BF_STAMP(6 + 2 * i);
@@ -436,19 +436,19 @@ __global__ __launch_bounds__(QW_THREADS, 1) void block_qkv_wide_bwd_kernel(QwBwd
         for (int j = 0; j < 4; ++j) vfa[j] = vfrag(16 * q + 4 * j + vk);
         qw_load_rows256(a.dY, a.lddy, 256 * min(q + 1, 5), m0, a.M, dv);      // (the last round re-requests chunk 5: nobody reads it)
         __builtin_amdgcn_sched_barrier(0);             // (at 256 registers the compiler otherwise sinks these requests to their uses)
-        bf16x8 bq[QW_AHEAD + 1][2];
+        bf16x8 bq[QW_AHEAD_BWD + 1][2];
 #pragma unroll
-        for (int k = 0; k < QW_AHEAD; ++k)
+        for (int k = 0; k < QW_AHEAD_BWD; ++k)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) bq[k][rt] = qw_frag256(buf + rt * 16384, m, h, k);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            if (k + QW_AHEAD < 16) {
+            if (k + QW_AHEAD_BWD < 16) {
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) bq[(k + QW_AHEAD) % (QW_AHEAD + 1)][rt] = qw_frag256(buf + rt * 16384, m, h, k + QW_AHEAD);
+                for (int rt = 0; rt < 2; ++rt) bq[(k + QW_AHEAD_BWD) % (QW_AHEAD_BWD + 1)][rt] = qw_frag256(buf + rt * 16384, m, h, k + QW_AHEAD_BWD);
             }
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) acc[rt] = mfma32(ring[k], bq[k % (QW_AHEAD + 1)][rt], acc[rt]);
+            for (int rt = 0; rt < 2; ++rt) acc[rt] = mfma32(ring[k], bq[k % (QW_AHEAD_BWD + 1)][rt], acc[rt]);
             ring[k] = nx[k * 64];                      // (the last round reads the 16 fragments behind this wave's stream)
             if ((k & 3) == 3)                          // this wave's V step of the group: k-step 16 q + (k - 3) + vk, row tile vrt
                 vacc = mfma32(vfa[k >> 2], qw_frag256(buf + vrt * 16384, m, h, k - 3 + vk), vacc);

@@ -1419,8 +1419,9 @@ class BlockQkvFn(torch.autograd.Function):
         a = cb.BlockQkvArgs()
         a.M, a.x, a.gamma, a.beta, a.eps, a.mean, a.rstd = M, ptr(x), ptr(pack.gamma), ptr(pack.beta), pack.eps, ptr(mean), ptr(rstd)
         a.W_fwd, a.bias, a.N3 = ptr(pack.W_fwd), ptr(pack.bias), N3
-        ctx.wide = BLOCK_QKV_WIDE
-        a.wide = int(ctx.wide)
+        mode = block_qkv_wide()
+        ctx.wide = mode in ("1", "both")                    # (backward form)
+        a.wide = int(mode in ("1", "both", "fwd"))
         a.A, a.lda, a.Bb, a.ldb = ptr(A), A.stride(0), ptr(Bb), Bb.stride(0)
         a.alpha, a.p = float(scale), float(drop_p)
         xds, y = [], None
@@ -1552,7 +1553,16 @@ def block_tail_lean() -> int:
         return int(BLOCK_LEAN)
     return 3 if lib().cvft_concurrent_chains() >= 3 else 0
 BLOCK_QKV_FUSE = _os.environ.get("CVFT_BLOCK_QKV_FUSE", "1") != "0"      # first half of the block (norm1 + stacked LoRA q|k|v)
-BLOCK_QKV_WIDE = _os.environ.get("CVFT_BLOCK_QKV_WIDE", "0") != "0"      # its 64-rows-per-workgroup form (csrc/block_qkv_wide.hip)
+# its 64-rows-per-workgroup form (csrc/block_qkv_wide.hip): "0" off, "fwd" forward only (the two directions exchange only standard tensors),
+# "1" / "both" forward and backward, "auto" (default) = both while >= 3 chains share the chip.  Same-box A/B, three pairs of 60 steps:
+# joint 22.78 / 22.81 / 22.82 (off) against 22.59 / 22.58 / 22.45 (both); flow_only 14.7 -> 15.2 (fwd) / 17.2 (both, with the 64-row tail)
+BLOCK_QKV_WIDE = _os.environ.get("CVFT_BLOCK_QKV_WIDE", "auto")
+
+
+def block_qkv_wide() -> str:
+    if BLOCK_QKV_WIDE != "auto":
+        return BLOCK_QKV_WIDE
+    return "both" if lib().cvft_concurrent_chains() >= 3 else "0"
 
 
 # ---------------------------------------------------------------------------------
