@@ -22,7 +22,7 @@ python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi64ELi64ELi2ELi2ELi0ELi4ELb
 python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi128ELi128ELi4ELi2ELi0ELi2ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,128,128,4,2,ns2,regepi>' $OUT/pmc_traffic_128x128.json
 python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi96ELi256ELi3ELi4ELi0ELi3ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,96,256,3,4,ns3,regepi>' $OUT/pmc_traffic_96x256.json || true
 python tools/pmc_traffic.py $F $W 'block_tail_fwd_kernel' 'block_tail_fwd' $OUT/pmc_traffic_block_tail_fwd.json || true
-python tools/pmc_traffic.py $F $W 'block_qkv_fwd_kernel' 'block_qkv_fwd' $OUT/pmc_traffic_block_qkv_fwd.json || true
+python tools/pmc_traffic.py $F $W 'block_qkv_wide_fwd_kernel' 'block_qkv_wide_fwd' $OUT/pmc_traffic_block_qkv_fwd.json || true
 python tools/pmc_traffic.py $F $W 'block_tail_wide_bwd_kernel' 'block_tail_wide_bwd' $OUT/pmc_traffic_block_tail_wide_bwd.json || true
 rm -rf $OUT/counters
 python bench.py --workload flow_only --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_flow_only_b8.json
