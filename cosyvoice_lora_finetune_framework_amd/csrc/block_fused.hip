@@ -409,6 +409,7 @@ int block_tail_lean_fwd_launch(const cvft_block_tail_args* p, int DI, void* stre
 int block_tail_lean_bwd_launch(const cvft_block_tail_bwd_args* p, int DI, void* stream);
 int block_tail_wide_fwd_launch(const cvft_block_tail_args* p, int DI, void* stream);       // block_wide.hip
 int block_tail_wide_bwd_launch(const cvft_block_tail_bwd_args* p, int DI, void* stream);
+int block_tail_wide8_fwd_launch(const cvft_block_tail_args* p, int DI, void* stream);      // block_wide8.hip
 
 extern "C" int cvft_block_tail_fwd(const cvft_block_tail_args* p, void* stream) {
     CVFT_CHECK_ARG(p && p->M > 0 && p->F > 0 && p->F % 128 == 0 && p->F <= BF_MAX_F, "cvft_block_tail_fwd: need M > 0, F %% 128 == 0, F <= 2048 (F=%d)", p ? p->F : -1);
@@ -420,8 +421,11 @@ extern "C" int cvft_block_tail_fwd(const cvft_block_tail_args* p, void* stream) 
     CVFT_CHECK_ARG(al16(p->x1) && al16(p->out) && al16(p->W_fwd) && al16(p->b1) && al16(p->b2) && al16(p->gamma) && al16(p->beta) &&
                    (!p->z || al16(p->z)) && (!p->x0 || al16(p->x0)) && (!p->bo || al16(p->bo)), "cvft_block_tail_fwd: operands must be 16-byte aligned");
     if (p->lean) {
-        CVFT_CHECK_ARG(p->lean == 1 || (p->lean == 2 && p->z && p->F >= 256), "cvft_block_tail_fwd: lean must be 0, 1 or 2; the wide form (2) needs F >= 256 and always stores z (whole 64-row groups)");
-        const int rc = p->lean == 2 ? block_tail_wide_fwd_launch(p, DI, stream) : block_tail_lean_fwd_launch(p, DI, stream);
+        CVFT_CHECK_ARG(p->lean == 1 || ((p->lean == 2 || p->lean == 4) && p->z && p->F >= 256),
+                       "cvft_block_tail_fwd: lean must be 0, 1, 2 or 4; the 64-row forms (2, 4) need F >= 256 and always store z (whole 64-row groups)");
+        CVFT_CHECK_ARG(p->lean != 4 || (p->F % 256 == 0 && p->F >= 512 && p->F <= 1024), "cvft_block_tail_fwd: the eight-wave form (4) needs F %% 256 == 0, 512 <= F <= 1024");
+        const int rc = p->lean == 4 ? block_tail_wide8_fwd_launch(p, DI, stream)
+                     : p->lean == 2 ? block_tail_wide_fwd_launch(p, DI, stream) : block_tail_lean_fwd_launch(p, DI, stream);
         if (rc) return rc;
         CVFT_LAUNCH_CHECK("cvft_block_tail_fwd (lean)");
         return 0;

@@ -146,6 +146,23 @@ class BlockTailPack:
         self.W_fwd_wide, nfw = _streams(fwd)
         self.W_bwd_wide, nbw = _streams(bwd)
         assert nfw == nf and nbw == nf
+        # eight-wave 64-row forward (csrc/block_wide8.hip): wave w of 8 owns feature tile w of every link and hidden tile 8 r + w of round r
+        # (rounds of 256 hidden units), groups of 16 fragments in the same lagged order
+        self.W_fwd_wide8 = None
+        if self.F % 256 == 0 and 512 <= self.F <= 1024:
+            nr8 = self.F // 256
+            order8 = [("1", 0), ("1", 1)]
+            for r in range(1, nr8 - 1):
+                order8 += [("1", r + 1), ("2", r - 1)]
+            order8 += [("2", nr8 - 2), ("2", nr8 - 1)]
+            assert sorted(order8) == sorted([(k, r) for k in "12" for r in range(nr8)])
+            fwd = []
+            for w in range(8):
+                cf = [Won[w]] if self.DI else []                                             # [ks]
+                cf += [(W1n[8 * r + w] if k == "1" else W2n[w, 16 * r:16 * r + 16]) for k, r in order8]
+                fwd.append(cf)
+            self.W_fwd_wide8, nf8 = _streams(fwd)
+            assert nf8 == self.DI // 16 + self.F // 8
 
 
 class BlockQkvPack:

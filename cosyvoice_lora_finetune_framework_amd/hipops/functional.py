@@ -1355,9 +1355,11 @@ class BlockTailFn(torch.autograd.Function):
             mode = 1
         # every form saves gelu'(z) in the same [row tile][hidden tile][64 lanes][16] order, so the two directions may use different
         # forms: 3 = 32-row forward (the faster forward) + 64-row backward (same latency as the 32-row one on half the CUs)
-        ctx.lean = 2 if mode == 3 else mode
+        if mode == 4 and pack.W_fwd_wide8 is None:     # (the eight-wave forward: F % 256 == 0, 512 <= F <= 1024)
+            mode = 3
+        ctx.lean = 2 if mode >= 3 else mode            # (backward form)
         fwd_form = 0 if mode == 3 else mode
-        a.DI, a.W_fwd, a.lean = pack.DI, ptr((pack.W_fwd, pack.W_fwd_lean, pack.W_fwd_wide)[fwd_form]), int(fwd_form)
+        a.DI, a.W_fwd, a.lean = pack.DI, ptr({0: pack.W_fwd, 1: pack.W_fwd_lean, 2: pack.W_fwd_wide, 4: pack.W_fwd_wide8}[fwd_form]), int(fwd_form)
         if o is not None:
             assert o.shape == (M, pack.DI) and o.stride(1) == 1
             x1 = torch.empty_like(x0)
@@ -1367,7 +1369,7 @@ class BlockTailFn(torch.autograd.Function):
         mean = torch.empty(M, dtype=torch.float32, device=x0.device)
         rstd = torch.empty(M, dtype=torch.float32, device=x0.device)
         # (the wide form always stores z and works on whole 64-row groups)
-        z = torch.empty(-(-M // 64) * 64 * pack.F, dtype=x0.dtype, device=x0.device) if (need or fwd_form == 2) else None
+        z = torch.empty(-(-M // 64) * 64 * pack.F, dtype=x0.dtype, device=x0.device) if (need or fwd_form in (2, 4)) else None
         a.x1, a.gamma, a.beta, a.eps = ptr(x1), ptr(pack.gamma), ptr(pack.beta), pack.eps
         a.b1, a.F, a.b2, a.act = ptr(pack.b1), pack.F, ptr(pack.b2), ACT[act]
         a.z, a.mean, a.rstd, a.out = ptr(z), ptr(mean), ptr(rstd), ptr(out)
@@ -1540,7 +1542,8 @@ def can_block_tail(x: torch.Tensor, d_ff: int, d_inner: int) -> bool:
 
 BLOCK_FUSE = _os.environ.get("CVFT_BLOCK_FUSE", "1") != "0"
 # Form of the block-tail kernels: 0 = CU-owning 32-row form (block_fused.hip), 1 = CU-sharing 32-row form (block_lean.hip), 2 = 64-row form
-# (block_wide.hip), 3 = 32-row forward + 64-row backward, "auto" (default) = 3 while >= 3 chains share the chip, else 0.  Measured, same-box
+# (block_wide.hip), 3 = 32-row forward + 64-row backward, 4 = eight-wave 64-row forward (block_wide8.hip) + 64-row backward, "auto" (default) = 3
+# while >= 3 chains share the chip, else 0.  Measured, same-box
 # A/Bs (DESIGN sections 11 / 12): joint 22.85 (0) / 22.99 (1) / 22.71 (2) / 23.2 -> 22.8 (3); flow_only 14.66 (0) / 15.0 (3) / 15.7 (2): the 64-row
 # backward has the 32-row one's latency on half the CUs, the 64-row forward is 9 us longer -- fewer CUs only pay when the chip is shared
 BLOCK_LEAN = _os.environ.get("CVFT_BLOCK_LEAN", "auto")
@@ -1548,8 +1551,8 @@ BLOCK_LEAN = _os.environ.get("CVFT_BLOCK_LEAN", "auto")
 
 def block_tail_lean() -> int:
     """0: CU-owning 32-row form (block_fused.hip); 1: CU-sharing 32-row form (block_lean.hip); 2: 64-row form (block_wide.hip);
-    3: 32-row forward + 64-row backward"""
-    if BLOCK_LEAN in ("0", "1", "2", "3"):
+    3: 32-row forward + 64-row backward; 4: eight-wave 64-row forward (block_wide8.hip) + 64-row backward"""
+    if BLOCK_LEAN in ("0", "1", "2", "3", "4"):
         return int(BLOCK_LEAN)
     return 3 if lib().cvft_concurrent_chains() >= 3 else 0
 BLOCK_QKV_FUSE = _os.environ.get("CVFT_BLOCK_QKV_FUSE", "1") != "0"      # first half of the block (norm1 + stacked LoRA q|k|v)

@@ -403,7 +403,10 @@ typedef struct {
                                             lagging one round -- G1(0), G1(1), { G1(r + 1), G2(r - 1) : r = 1 .. nr - 2 }, G2(nr - 2),
                                             G2(nr - 1) with G1(r) = natural(W1, 4 r + w, ks), G2(r) = natural(W2, 2 w + c2, 8 r + k')
                                             [k'][c2].  In this form z is mandatory, holds whole 64-row groups (ceil(M / 64) * 64 * F
-                                            elements): forward and backward must use the same form */
+                                            elements);
+                                            4: the eight-wave 64-row forward (block_wide8.hip; F % 256 == 0, 512 <= F <= 1024; W_fwd = wave w of 8:
+                                            natural(Wo, w, ks), then G1(r) = natural(W1, 8 r + w, ks), G2(r) = natural(W2, w, 16 r + k') in the same
+                                            lagged order).  Every form stores the same z, so the directions may use different forms */
 } cvft_block_tail_args;
 int cvft_block_tail_fwd(const cvft_block_tail_args* a, void* stream);
 typedef struct {

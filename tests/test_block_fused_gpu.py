@@ -40,7 +40,7 @@ def _ref(o, x0, w, act, with_o=True):
     return o, x0, x1r, out
 
 
-@pytest.mark.parametrize("lean", [0, 1, 2, 3])
+@pytest.mark.parametrize("lean", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("act", ["gelu_erf", "gelu_tanh"])
 @pytest.mark.parametrize("M,DI,Fh,with_o", [(64, 512, 1024, True), (250, 512, 1024, True), (37, 256, 128, True), (70, 512, 256, True), (96, 512, 1024, False),
                                             (4000, 512, 1024, True)])

@@ -21,9 +21,9 @@ def main():
         o = torch.randn(M, 512, device=dev, dtype=dt)
         x0 = torch.randn(M, 256, device=dev, dtype=dt)
         dy = torch.randn(M, 256, device=dev, dtype=dt)
-        for fuse in (False, True, "lean", "wide"):
+        for fuse in (False, True, "lean", "wide", "wide8"):
             HF.BLOCK_FUSE = bool(fuse)
-            HF.BLOCK_LEAN = {"lean": "1", "wide": "2"}.get(fuse, "0")
+            HF.BLOCK_LEAN = {"lean": "1", "wide": "2", "wide8": "4"}.get(fuse, "0")
 
             def fwd():
                 with torch.no_grad():

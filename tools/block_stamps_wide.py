@@ -31,6 +31,13 @@ base = t[0]
 for i, name in ((1, "o, x0 tiles + params in LDS"), (2, "out-proj MFMAs"), (3, "x1 into the x tile"), (4, "LN, x1 store, y tiles"), (5, "G1(0)")):
     print(f"{name:28s} +{t[i] - t[i - 1]:7d}  (at {t[i] - base})")
 print(f"round 0 (act beside G1(1))   +{t[8] - t[5]:7d}")
+if HF.BLOCK_LEAN == "4":                                # eight waves: rounds of 256 hidden units, nr = 4
+    for r in (1, 2):
+        a, b, c = (t[8] if r == 1 else t[10]), t[9 + 2 * (r - 1)], t[10 + 2 * (r - 1)]
+        print(f"  round {r}: G1(r+1) + half act {b - a:6d}   G2(r-1) + half act + barrier + keep {c - b:6d}")
+    print(f"last round + G2(nr-1)        +{t[7] - t[6]:7d}  (at {t[7] - base})")
+    print(f"epilogue                     +{t[26] - t[7]:7d}  (total {t[26] - base})")
+    sys.exit(0)
 for r in range(1, 7):
     a, b = t[8 + 2 * (r - 1)], t[9 + 2 * (r - 1)]
     nxt = t[8 + 2 * r] if r < 6 else t[6]
