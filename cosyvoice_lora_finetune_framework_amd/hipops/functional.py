@@ -765,7 +765,7 @@ STACKED_DROP_DEFER = _os.environ.get('CVFT_STACKED_DROP_DEFER', '1') != '0'
 KEEP_DROPPED = _os.environ.get('CVFT_KEEP_DROPPED', '1') != '0'   # forward writes drop(x) for the backward's dA (no re-derivation launch)
 LN_SKINNY = _os.environ.get('CVFT_LN_SKINNY', '1') != '0'    # LayerNorm launch also emits the dropped rank-side product of the adapter it feeds
 XDROP_ON = _os.environ.get('CVFT_XDROP', '1') != '0'        # lora_dropout dgrad: masked rank extension inside the GEMM launch
-SINK_PLAN_BLOCKS = int(_os.environ.get('CVFT_SINK_PLAN_BLOCKS', 256))     # measured 512 / 256 / 128: 26.38 / 26.11 / 26.29 ms/step (slab traffic vs blocks)
+SINK_PLAN_BLOCKS = int(_os.environ.get('CVFT_SINK_PLAN_BLOCKS', 512))     # wave stripes per launch; round 3, same-box: 256 -> 22.75 / 22.69 / 22.79, 512 -> 22.45 / 22.52 / 22.50, 1024 -> 22.33-22.38 vs 22.29-22.34 (round 2 had 256 best by 0.2 ms)
 SINK_DEFER = _os.environ.get('CVFT_SINK_DEFER', '1') != '0'
 SINK_DEFER_MAX = int(_os.environ.get('CVFT_SINK_DEFER_MAX', 12_000_000))      # x.numel() + dY.numel(): the flow branch's layers
 SINK_DEFER_RPB = int(_os.environ.get('CVFT_SINK_DEFER_RPB', 256))
