@@ -493,6 +493,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
     char* const XT = smem + 32768;                      // x1 tiles, then dx1 tiles
     const int nr = a.F / 128;
 
+    BF_STAMP(16);
     // dy and x1 tiles, gamma, the row statistics, the first z tiles, the ring, the cold-weight touches
     bf16x8 dv[8], xv[8];
     bw_load_rows256(a.dy, m0, a.M, dv);
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) { BF_PIN(mean[t]); BF_PIN(rstd[t]); }
+    BF_STAMP(17);
     f32x16 accd[2][2], accg[2], accn[2];
     int rc = 0;
     bf16x4 hcur[2];
@@ -547,6 +549,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
     };
     bw_first<0>(ring, nx, DT, m, h, accg, none);              // H1(0)
     nx += 16 * 64;
+    BF_STAMP(18);
     {                                                   // (nr >= 2: checked by the entry point)
         zload(1);
 #pragma unroll
@@ -554,6 +557,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
         bw_first<16>(ring, nx, DT, m, h, accn, [&](int ks) __attribute__((always_inline)) { act(2 * ks); act(2 * ks + 1); });
         nx += 16 * 64;
         finish(0, true);
+        BF_STAMP(19);
         for (int r = 1; r + 1 < nr; ++r) {
             rc = r;
             zload(r + 1);
@@ -565,6 +569,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
             nx += BF_RING * 64;
             finish(r, true);
         }
+        BF_STAMP(20);
         rc = nr - 1;
         bw_second<0, (CR > 0)>(ring, nx, smem + BW_HT + ((nr - 2) & 1) * 8 * BW_HT_TILE, m, h, accd,
                                [&](int k) __attribute__((always_inline)) { act(4 * k); act(4 * k + 1); act(4 * k + 2); act(4 * k + 3); });
@@ -574,6 +579,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
     bw_second<16, (CR > 0)>(ring, nx, smem + BW_HT + ((nr - 1) & 1) * 8 * BW_HT_TILE, m, h, accd, none);      // H2(nr - 1)
     nx += 16 * 64;
 
+    BF_STAMP(21);
     // ---- LayerNorm backward + residual branch for this wave's 64 features; x1 and dy from the tiles in accumulator layout
     float sp[2][2], sm[2][2];
     bf16x4 xr[2][2][4];
@@ -596,7 +602,9 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
                 }
             }
     }
+    BF_STAMP(22);
     bw_rowsum<2>(smem, 0, wave, lane, sp, sm);
+    BF_STAMP(23);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const float m1 = sm[0][t] * (1.f / BF_D), m2 = sm[1][t] * (1.f / BF_D);
@@ -616,6 +624,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
             }
     }
     __syncthreads();
+    BF_STAMP(24);
     bw_store_rows256(XT, a.dx1, m0, a.M);
     if (BF_TOUCH && bw_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.dx1[0] = (bf16_t)0.f;  // (keeps the prefetch loads alive; never true)
     if (CR == 0) return;
@@ -645,6 +654,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        BF_STAMP(25);
         __syncthreads();                               // every wave has read its dx1 fragments and stored dx1: the tiles are free
         char* OUT = smem;                              // 2 x [32][DI] tiles, row pitch 2 DI bytes, 16-byte chunks swizzled by (row & 15)
         constexpr int PITCH = CR > 0 ? 512 * CR : 512;
@@ -667,6 +677,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(OUT + (r >> 5) * 32 * PITCH + (r & 31) * PITCH + ((ch ^ (r & 15)) << 4));
             if (m0 + r < a.M) *reinterpret_cast<bf16x8*>(a.dout + (size_t)(m0 + r) * a.lddo + 8 * ch) = v;
         }
+        BF_STAMP(27);
     }
 }
 

@@ -92,3 +92,71 @@ def test_block_tail_streams_hold_every_fragment_once_in_consumption_order():
             for ks in range(16):
                 for f2 in range(2):
                     assert torch.equal(ws[base + 32 * r + 2 * ks + f2], WoTn[fw * w + 2 * r + f2, ks])
+
+
+def _lagged(nr):
+    """consumption order of the 64-row forms: G1(0), G1(1), { G1(r + 1), G2(r - 1) : r = 1 .. nr - 2 }, G2(nr - 2), G2(nr - 1)"""
+    order = [("1", 0), ("1", 1)]
+    for r in range(1, nr - 1):
+        order += [("1", r + 1), ("2", r - 1)]
+    return order + [("2", nr - 2), ("2", nr - 1)]
+
+
+def test_64_row_streams_follow_the_lagged_order():
+    """W_fwd_wide / W_bwd_wide (four waves, csrc/block_wide.hip) and W_fwd_wide8 (eight waves, csrc/block_wide8.hip): every group of 16
+    fragments restated from the natural images, in the order the kernels' comments give"""
+    g = torch.Generator().manual_seed(3)
+    Fh, DI = 1024, 512
+    w1, w2, wo = torch.randn(Fh, 256, generator=g), torch.randn(256, Fh, generator=g), torch.randn(256, DI, generator=g)
+    pk = bp.BlockTailPack(wo, None, None, None, 1e-5, w1, None, w2, None)
+    W1n, W2n, Won = bp.pack_a(w1, "natural").float(), bp.pack_a(w2, "natural").float(), bp.pack_a(wo, "natural").float()
+    W2Tn, W1Tn = bp.pack_a(w2.t().contiguous(), "natural").float(), bp.pack_a(w1.t().contiguous(), "natural").float()
+    WoTn = bp.pack_a(wo.t().contiguous(), "natural").float()
+    # four waves: wave w owns feature tiles 2 w, 2 w + 1 and hidden tile 4 r + w of round r (128 hidden units per round)
+    nf, nr = DI // 8 + Fh // 4, Fh // 128
+    sf, sb = pk.W_fwd_wide.float().view(-1, 64, 8), pk.W_bwd_wide.float().view(-1, 64, 8)
+    assert sf.shape[0] == sb.shape[0] == 4 * nf + 32
+    for w in range(4):
+        ws, wb = sf[w * nf:(w + 1) * nf], sb[w * nf:(w + 1) * nf]
+        for ks in range(DI // 16):
+            for c2 in range(2):
+                assert torch.equal(ws[2 * ks + c2], Won[2 * w + c2, ks])
+        pos = DI // 8
+        for i, (kind, r) in enumerate(_lagged(nr)):
+            a = ws[pos + 16 * i:pos + 16 * i + 16]
+            b = wb[16 * i:16 * i + 16]
+            if kind == "1":
+                assert torch.equal(a, W1n[4 * r + w]) and torch.equal(b, W2Tn[4 * r + w])
+            else:
+                for k in range(8):
+                    for c2 in range(2):
+                        assert torch.equal(a[2 * k + c2], W2n[2 * w + c2, 8 * r + k]) and torch.equal(b[2 * k + c2], W1Tn[2 * w + c2, 8 * r + k])
+        fw = DI // 128
+        for ks in range(16):
+            for f in range(fw):
+                assert torch.equal(wb[32 * nr + ks * fw + f], WoTn[fw * w + f, ks])
+    # eight waves: wave w owns feature tile w and hidden tile 8 r + w of round r (256 hidden units per round)
+    nf8, nr8 = DI // 16 + Fh // 8, Fh // 256
+    s8 = pk.W_fwd_wide8.float().view(-1, 64, 8)
+    assert s8.shape[0] == 8 * nf8 + 32
+    for w in range(8):
+        ws = s8[w * nf8:(w + 1) * nf8]
+        assert torch.equal(ws[:DI // 16], Won[w])
+        for i, (kind, r) in enumerate(_lagged(nr8)):
+            a = ws[DI // 16 + 16 * i:DI // 16 + 16 * i + 16]
+            assert torch.equal(a, W1n[8 * r + w] if kind == "1" else W2n[w, 16 * r:16 * r + 16])
+    # F = 128 has a single round: no 64-row streams for the eight-wave form, the four-wave one degenerates to G1(0), G2(0)
+    small = bp.BlockTailPack(wo, None, None, None, 1e-5, w1[:128], None, w2[:, :128], None)
+    assert small.W_fwd_wide8 is None
+
+
+def test_qkv_streams_of_the_64_row_backward():
+    """BlockQkvPack.W_bwd_wide (csrc/block_qkv_wide.hip): wave w of eight = Wqkv^T fragments of feature tile w over all of 3N, [ks]"""
+    g = torch.Generator().manual_seed(4)
+    wqkv = torch.randn(1536, 256, generator=g)
+    pk = bp.BlockQkvPack(wqkv, None, None, None, 1e-5)
+    WTn = bp.pack_a(wqkv.t().contiguous(), "natural").float()                  # [8 ct][96 ks]
+    st = pk.W_bwd_wide.float().view(-1, 64, 8)
+    assert st.shape[0] == 8 * 96 + 32 and float(st[8 * 96:].abs().sum()) == 0.0
+    for w in range(8):
+        assert torch.equal(st[96 * w:96 * (w + 1)], WTn[w])

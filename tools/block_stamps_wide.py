@@ -19,14 +19,27 @@ for p in blk.parameters():
 M = int(os.environ.get("M", 4000))
 o = torch.randn(M, 512, device=dev, dtype=dt)
 x0 = torch.randn(M, 256, device=dev, dtype=dt)
+dy = torch.randn(M, 256, device=dev, dtype=dt)
 for _ in range(50):
-    with torch.no_grad():
-        blk._tail(o, x0, "gelu_erf")
+    if os.environ.get("BWD"):
+        oo, xx = o.detach().requires_grad_(True), x0.detach().requires_grad_(True)
+        blk._tail(oo, xx, "gelu_erf").backward(dy)
+    else:
+        with torch.no_grad():
+            blk._tail(o, x0, "gelu_erf")
 torch.cuda.synchronize()
 lib = C.CDLL(cb.LIB_PATH)
 buf = (C.c_ulonglong * 32)()
 assert lib.cvft_debug_block_stamps(buf) == 0
 t = list(buf)
+if os.environ.get("BWD"):                               # stamps 16.. of block_tail_wide_bwd_kernel
+    names = ["dy / x1 tiles in LDS", "H1(0)", "round 0", "rounds 1 .. nr-2", "last round + H2(nr-1)", "LN backward sums", "exchange", "dx1 -> tile + barrier",
+             "dx1 store + Wo^T product", "barrier + do tile + store"]
+    idx = [16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27]
+    for n, a, b in zip(names, idx[:-1], idx[1:]):
+        print(f"{n:28s} +{t[b] - t[a]:7d}")
+    print("total", t[27] - t[16])
+    sys.exit(0)
 base = t[0]
 for i, name in ((1, "o, x0 tiles + params in LDS"), (2, "out-proj MFMAs"), (3, "x1 into the x tile"), (4, "LN, x1 store, y tiles"), (5, "G1(0)")):
     print(f"{name:28s} +{t[i] - t[i - 1]:7d}  (at {t[i] - base})")
