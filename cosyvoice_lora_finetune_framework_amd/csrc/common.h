@@ -104,8 +104,8 @@ __device__ __forceinline__ float act_apply(int act, float x) {
         case CVFT_ACT_MISH: {
             // x * tanh(softplus(x)) with tanh(log(1+e)) = ((1+e)^2 - 1) / ((1+e)^2 + 1) = n / (n + 2), n = e*(e + 2):
             // one v_exp_f32 instead of expf + log1pf + tanhf (the GroupNorm kernels were VALU-bound on those)
-            if (x > 20.f) return x;
-            const float e = __expf(x), n = e * (e + 2.f);
+            // (x > 20: n / (n + 2) is exactly 1 in fp32 -- the clamp only keeps e finite, no branch per element)
+            const float e = __expf(fminf(x, 20.f)), n = e * (e + 2.f);
             return x * (n / (n + 2.f));
         }
         default: return x;
@@ -130,8 +130,7 @@ __device__ __forceinline__ float act_grad(int act, float x) {
             return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x2);
         }
         case CVFT_ACT_MISH: {
-            if (x > 20.f) return 1.f;
-            const float e = __expf(x), n = e * (e + 2.f);
+            const float e = __expf(fminf(x, 20.f)), n = e * (e + 2.f);      // x > 20: th == 1 exactly, the second term vanishes
             const float th = n / (n + 2.f), sg = e / (1.f + e);
             return th + x * (1.f - th * th) * sg;
         }

@@ -85,19 +85,20 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(int rows, int C, const T* _
 // MK (vector path only): also writes dxm = keep(site) / (1 - p) * dx, the gradient that the dropout in front of x's producer
 // (x = residual + dropout(linear(.)), encoder_layer.py:95 / 104) hands to that linear -- its backward then needs no pass of its
 // own over dx (cvft_layernorm_bwd_mask).  The mask is cvft_dropout_add's: flat element index row * C + c, groups of 4.
-template <typename T, bool VP, bool MK = false>
-__global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* __restrict__ x,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      int relu, float post, const T* __restrict__ dy,
-                                                      const T* __restrict__ dres, T* __restrict__ dx,
-                                                      float mp = 0.f, const long long* __restrict__ mseed = nullptr,
-                                                      unsigned msite = 0, T* __restrict__ dxm = nullptr) {
+// SD (with MK): the linear in front carries a rank-16 adapter -- its backward starts with V = s * dxm B ([rows][16], lora.py:71-76),
+// a latency-bound launch of its own on the backward chain.  The wave that writes a row of dxm holds it in registers: it forms the
+// 16 dot products with B^T ([16][C], L2-resident) and reduces them with a halving butterfly (17 cross-lane moves for 16 sums).
+template <typename T, bool VP, bool MK = false, bool SD = false, int NCH = 4>
+__device__ __forceinline__ void ln_bwd_row(const int row, int C, const T* __restrict__ x,
+                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                           int relu, float post, const T* __restrict__ dy,
+                                           const T* __restrict__ dres, T* __restrict__ dx,
+                                           float mp = 0.f, const long long* __restrict__ mseed = nullptr,
+                                           unsigned msite = 0, T* __restrict__ dxm = nullptr,
+                                           const T* sB = nullptr, float salpha = 0.f, T* __restrict__ sV = nullptr) {
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int NCH = 4;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
     const T* xr = x + (size_t)row * C;
     const T* dr = dy + (size_t)row * C;
     T* ox = dx + (size_t)row * C;
@@ -131,6 +132,11 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
         }
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
+        float sacc[16];
+        if (SD) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sacc[j] = 0.f;
+        }
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             const int ch = lane + q * 64;
@@ -162,8 +168,42 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
                         for (int e = 0; e < 4; ++e) om[4 * gq + e] = kp[e] ? from_f32<T>(to_f32(o[4 * gq + e]) * inv) : from_f32<T>(0.f);
                     }
                     *reinterpret_cast<uint4*>(dxm + (size_t)row * C + ch * VEC) = *reinterpret_cast<uint4*>(om);
+                    if constexpr (SD) {      // bf16 pairs straight into v_dot2_f32_bf16 (no conversions): 4 per 16-byte chunk and rank
+                        typedef __attribute__((ext_vector_type(2))) __bf16 bfp_t;
+                        bfp_t op[4];
+                        __builtin_memcpy(op, om, 16);
+#pragma unroll
+                        for (int jh = 0; jh < 16; jh += 8) {
+                            uint4 rb[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) rb[j] = *reinterpret_cast<const uint4*>(sB + (size_t)(jh + j) * C + ch * VEC);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                bfp_t bp[4];
+                                __builtin_memcpy(bp, &rb[j], 16);
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) sacc[jh + j] = __builtin_amdgcn_fdot2_f32_bf16(op[k], bp[k], sacc[jh + j], false);
+                            }
+                        }
+                    }
                 }
             }
+        }
+        if (SD) {
+            // 16 sums over 64 lanes: each exchange halves the sums a lane carries; lane l ends with sum number
+            // 8 b5 + 4 b4 + 2 b3 + b2 (bits of l) over its group of four, folded by the last two exchanges
+            const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+            float v8[8], v4[4], v2[2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v8[j] = (b5 ? sacc[j + 8] : sacc[j]) + __shfl_xor(b5 ? sacc[j] : sacc[j + 8], 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v4[j] = (b4 ? v8[j + 4] : v8[j]) + __shfl_xor(b4 ? v8[j] : v8[j + 4], 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) v2[j] = (b3 ? v4[j + 2] : v4[j]) + __shfl_xor(b3 ? v4[j] : v4[j + 2], 8);
+            float v1 = (b2 ? v2[1] : v2[0]) + __shfl_xor(b2 ? v2[0] : v2[1], 4);
+            v1 += __shfl_xor(v1, 1);
+            v1 += __shfl_xor(v1, 2);
+            if ((lane & 3) == 0) sV[(size_t)row * 16 + (b5 ? 8 : 0) + (b4 ? 4 : 0) + (b3 ? 2 : 0) + (b2 ? 1 : 0)] = from_f32<T>(v1 * salpha);
         }
         return;
     }
@@ -185,6 +225,43 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
         g *= gamma[c];
         ox[c] = from_f32<T>(rs * (g - s1 - xh * s2) + (rr ? to_f32(rr[c]) : 0.f));
     }
+}
+
+// NCH = 16-byte chunks per lane the vector path is unrolled for (2 cover C <= 128 chunks -- the 1024-wide LLM rows -- with half the
+// registers of 4: 11.4 -> ~9.7 us at 2 664 x 1 024 on the mask form, tools/bench_ln_side.py)
+// RL = false: the caller passes relu == 0 (every LayerNorm of the two models but the length regulator's); as a compile-time fact
+// it removes the beta loads and the y <= 0 test from the per-element work (11.3 -> 9.7 us at 2 664 x 1 024)
+template <typename T, bool VP, bool MK = false, int NCH = 4, bool RL = true>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      int relu, float post, const T* __restrict__ dy,
+                                                      const T* __restrict__ dres, T* __restrict__ dx,
+                                                      float mp = 0.f, const long long* __restrict__ mseed = nullptr,
+                                                      unsigned msite = 0, T* __restrict__ dxm = nullptr) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    ln_bwd_row<T, VP, MK, false, NCH>(row, C, x, gamma, beta, mean, rstd, RL ? relu : 0, post, dy, dres, dx, mp, mseed, msite, dxm);
+}
+
+// The side-product form: B^T ([16][C] bf16, 32 KB at C = 1024) is staged in LDS once per block and every wave walks rows
+// blockIdx.x * 4 + w, + 4 * gridDim.x, ...: read straight from L2 it was 32 KB per ROW (170 MB per launch at 5 328 rows, as much
+// as the launch's own HBM traffic three times over, +7 us).
+template <int NCH>
+__global__ void __launch_bounds__(256) ln_bwd_side_kernel(int rows, int C, const bf16_t* __restrict__ x,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres,
+                                                           bf16_t* __restrict__ dx, float mp, const long long* __restrict__ mseed,
+                                                           unsigned msite, bf16_t* __restrict__ dxm, const bf16_t* __restrict__ sB,
+                                                           float salpha, bf16_t* __restrict__ sV) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ln_smem[];
+    uint4* bl = reinterpret_cast<uint4*>(ln_smem);
+    for (int i = threadIdx.x; i < 2 * C; i += 256) bl[i] = reinterpret_cast<const uint4*>(sB)[i];      // 16 * C / 8 chunks
+    __syncthreads();
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4)
+        ln_bwd_row<bf16_t, true, true, true, NCH>(row, C, x, gamma, beta, mean, rstd, 0, 1.f, dy, dres, dx, mp, mseed, msite, dxm,
+                                             reinterpret_cast<const bf16_t*>(ln_smem), salpha, sV);
 }
 
 template <typename T>
@@ -219,11 +296,15 @@ extern "C" int cvft_layernorm_bwd(int dtype, int rows, int C, const void* x, con
     if (rows == 0) return 0;
     dim3 grid((rows + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-#define LN_BWD(TT, VPv) hipLaunchKernelGGL((ln_bwd_kernel<TT, VPv>), grid, dim3(256), 0, st, rows, C, (const TT*)x, gamma, beta, mean, \
-                                           rstd, relu, post_scale, (const TT*)dy, (const TT*)dres, (TT*)dx)
+#define LN_BWD(TT, VPv, NCHv, RLv) hipLaunchKernelGGL((ln_bwd_kernel<TT, VPv, false, NCHv, RLv>), grid, dim3(256), 0, st, rows, C, (const TT*)x, \
+                                                      gamma, beta, mean, rstd, relu, post_scale, (const TT*)dy, (const TT*)dres, (TT*)dx)
     const bool ra = (reinterpret_cast<uintptr_t>(dres) & 15) == 0;
-    if (dtype == CVFT_F32) { if (ra && ln_vec_ok<float>(C, x, dy, dx)) LN_BWD(float, true); else LN_BWD(float, false); }
-    else { if (ra && ln_vec_ok<bf16_t>(C, x, dy, dx)) LN_BWD(bf16_t, true); else LN_BWD(bf16_t, false); }
+    if (dtype == CVFT_F32) { if (ra && ln_vec_ok<float>(C, x, dy, dx)) LN_BWD(float, true, 4, true); else LN_BWD(float, false, 4, true); }
+    else if (ra && ln_vec_ok<bf16_t>(C, x, dy, dx)) {
+        if (relu) LN_BWD(bf16_t, true, 4, true);
+        else if (C <= 1024) LN_BWD(bf16_t, true, 2, false);
+        else LN_BWD(bf16_t, true, 4, false);
+    } else LN_BWD(bf16_t, false, 4, true);
 #undef LN_BWD
     CVFT_LAUNCH_CHECK("cvft_layernorm_bwd");
     return 0;
@@ -244,10 +325,36 @@ extern "C" int cvft_layernorm_bwd_mask(int dtype, int rows, int C, const void* x
     if (dtype == CVFT_F32)
         hipLaunchKernelGGL((ln_bwd_kernel<float, true, true>), grid, dim3(256), 0, st, rows, C, (const float*)x, gamma, beta, mean, rstd, 0, 1.f,
                            (const float*)dy, (const float*)dres, (float*)dx, p, (const long long*)seed, site, (float*)dxm);
+    else if (C <= 1024)
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, true, true, 2, false>), grid, dim3(256), 0, st, rows, C, (const bf16_t*)x, gamma, beta, mean, rstd, 0, 1.f,
+                           (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, p, (const long long*)seed, site, (bf16_t*)dxm);
     else
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, true, true>), grid, dim3(256), 0, st, rows, C, (const bf16_t*)x, gamma, beta, mean, rstd, 0, 1.f,
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, true, true, 4, false>), grid, dim3(256), 0, st, rows, C, (const bf16_t*)x, gamma, beta, mean, rstd, 0, 1.f,
                            (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, p, (const long long*)seed, site, (bf16_t*)dxm);
     CVFT_LAUNCH_CHECK("cvft_layernorm_bwd_mask");
+    return 0;
+}
+
+extern "C" int cvft_layernorm_bwd_mask_side(int rows, int C, const void* x, const float* gamma, const float* beta,
+                                            const float* mean, const float* rstd, const void* dy, const void* dres, void* dx,
+                                            float p, const int64_t* seed, unsigned site, void* dxm,
+                                            const void* Bt, int R, float alpha, void* V, void* stream) {
+    CVFT_CHECK_ARG(rows >= 0 && C > 0 && x && gamma && beta && mean && rstd && dy && dx && dxm && seed && Bt && V,
+                   "cvft_layernorm_bwd_mask_side: bad args");
+    CVFT_CHECK_ARG(R == 16, "cvft_layernorm_bwd_mask_side: rank 16 only");
+    CVFT_CHECK_ARG(p > 0.f && cvft_drop_rate_ok(p), "cvft_layernorm_bwd_mask_side: p outside [2^-16, 1 - 2^-16]");
+    const bool ra = ((reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(dxm) | reinterpret_cast<uintptr_t>(Bt)) & 15) == 0;
+    CVFT_CHECK_ARG(ra && ln_vec_ok<bf16_t>(C, x, dy, dx),
+                   "cvft_layernorm_bwd_mask_side: needs the vector path (bf16, C % 8 == 0, C <= 2048, 16-byte aligned pointers)");
+    if (rows == 0) return 0;
+    const int groups = (rows + 3) / 4, per = (groups + 1023) / 1024;          // equal shares: no block walks one group more than another needs to
+#define LN_SIDE(NCHv) hipLaunchKernelGGL(ln_bwd_side_kernel<NCHv>, dim3((groups + per - 1) / per), dim3(256), (size_t)32 * C,            \
+                                         (hipStream_t)stream, rows, C, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dy,    \
+                                         (const bf16_t*)dres, (bf16_t*)dx, p, (const long long*)seed, site, (bf16_t*)dxm,              \
+                                         (const bf16_t*)Bt, alpha, (bf16_t*)V)
+    if (C <= 1024) LN_SIDE(2); else LN_SIDE(4);          // chunks of 8 columns per lane: 2 cover C <= 1024 with half the registers
+#undef LN_SIDE
+    CVFT_LAUNCH_CHECK("cvft_layernorm_bwd_mask_side");
     return 0;
 }
 
@@ -458,11 +565,14 @@ __global__ void __launch_bounds__(256) gn_apply_bwd_kernel(int B, int T_, int C,
 // (t_eff < T) gives every thread the same valid chunks as the exact-shape launch: bit-identical on the valid frames.
 constexpr int GN_NCH = 8;
 
-template <typename T>
+// MISH as a template flag and gamma / beta fetched per chunk BEFORE the element loop: with the run-time flag around them the
+// compiler kept one 4-byte load and one branch per element (128 / 368 scalar loads and 100-300 branches per thread in the
+// forward / backward kernels; a block is one of only B * G = 64 per launch, so its own instruction stream is the launch time).
+template <typename T, bool MISH, int NCH>
 __global__ void __launch_bounds__(512) gn_fused_fwd_kernel(int T_, int C, int G, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float eps, const int* __restrict__ len, const T* __restrict__ add,
-                                                            int apply_mish, T* __restrict__ y, float* __restrict__ mean,
+                                                            T* __restrict__ y, float* __restrict__ mean,
                                                             float* __restrict__ rstd, const int* __restrict__ t_eff) {
     constexpr int VEC = 16 / sizeof(T);
     __shared__ float sm[16];
@@ -472,10 +582,10 @@ __global__ void __launch_bounds__(512) gn_fused_fwd_kernel(int T_, int C, int G,
     const int Te = t_eff ? min(*t_eff, T_) : T_;
     const int nst = Te * CgV, nall = T_ * CgV;
     const float n = (float)Te * (float)Cg;
-    uint4 xr[GN_NCH];
+    uint4 xr[NCH];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < GN_NCH; ++k) {
+    for (int k = 0; k < NCH; ++k) {
         const int e = threadIdx.x + k * 512;
         xr[k] = make_uint4(0, 0, 0, 0);
         if (e < nall) xr[k] = *reinterpret_cast<const uint4*>(x + off + (size_t)(e / CgV) * C + (e % CgV) * VEC);
@@ -488,7 +598,7 @@ __global__ void __launch_bounds__(512) gn_fused_fwd_kernel(int T_, int C, int G,
     const float mu = block_sum(s, sm) / n;
     float v2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < GN_NCH; ++k) {
+    for (int k = 0; k < NCH; ++k) {
         const int e = threadIdx.x + k * 512;
         if (e < nst) {
             const T* ve = reinterpret_cast<const T*>(&xr[k]);
@@ -502,8 +612,16 @@ __global__ void __launch_bounds__(512) gn_fused_fwd_kernel(int T_, int C, int G,
         rstd[blockIdx.x] = rs;
     }
     const int lb = len ? len[b] : T_;
+    // 512 % CgV == 0 (the estimator: CgV = 4): a thread's chunks all sit on the same 8 channels -- one gamma / beta fetch
+    const bool same_c = (512 % CgV) == 0;
+    float gm[VEC], bt[VEC];
+    {
+        const int c0 = g * Cg + (threadIdx.x % CgV) * VEC;
 #pragma unroll
-    for (int k = 0; k < GN_NCH; ++k) {
+        for (int q = 0; q < VEC; ++q) { gm[q] = gamma[c0 + q]; bt[q] = beta[c0 + q]; }
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
         const int e = threadIdx.x + k * 512;
         if (e >= nall) continue;
         const int t = e / CgV, cc = (e % CgV) * VEC, c0 = g * Cg + cc;
@@ -511,24 +629,28 @@ __global__ void __launch_bounds__(512) gn_fused_fwd_kernel(int T_, int C, int G,
         const bool dead = t >= lb || pad;
         const T* ve = reinterpret_cast<const T*>(&xr[k]);
         T av[VEC], ov[VEC];
-        if (add) *reinterpret_cast<uint4*>(av) = *reinterpret_cast<const uint4*>(add + (size_t)b * C + c0);
+        *reinterpret_cast<uint4*>(av) = add ? *reinterpret_cast<const uint4*>(add + (size_t)b * C + c0) : make_uint4(0, 0, 0, 0);
+        if (!same_c) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) { gm[q] = gamma[c0 + q]; bt[q] = beta[c0 + q]; }
+        }
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            const float z = (to_f32(ve[q]) - mu) * rs * gamma[c0 + q] + beta[c0 + q];
-            float o = apply_mish ? act_apply(CVFT_ACT_MISH, z) : z;
-            if (dead) o = 0.f;
-            if (add && !pad) o += to_f32(av[q]);
+            const float z = (to_f32(ve[q]) - mu) * rs * gm[q] + bt[q];
+            float o = MISH ? act_apply(CVFT_ACT_MISH, z) : z;
+            o = dead ? 0.f : o;
+            o += pad ? 0.f : to_f32(av[q]);
             ov[q] = from_f32<T>(o);
         }
         *reinterpret_cast<uint4*>(y + off + (size_t)t * C + cc) = *reinterpret_cast<const uint4*>(ov);
     }
 }
 
-template <typename T>
+template <typename T, bool MISH, int NCH>
 __global__ void __launch_bounds__(512) gn_fused_bwd_kernel(int T_, int C, int G, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const int* __restrict__ len, int apply_mish,
+                                                            const int* __restrict__ len,
                                                             const T* __restrict__ dy, T* __restrict__ dx,
                                                             const int* __restrict__ t_eff) {
     constexpr int VEC = 16 / sizeof(T);
@@ -542,10 +664,19 @@ __global__ void __launch_bounds__(512) gn_fused_bwd_kernel(int T_, int C, int G,
     const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
     const int lb = len ? min(len[b], Te) : Te;                     // frames t >= len (or in the bucket padding) contribute nothing
     const int nlive = lb * CgV;
-    uint4 xr[GN_NCH], dr[GN_NCH];
+    // dz = dy * mish'(z) * gamma is formed ONCE and kept (fp32, in place of the dy chunk) for the second pass
+    uint4 xr[NCH], dr[NCH];
+    float dzr[NCH][VEC];
     float s1 = 0.f, s2 = 0.f;
+    const bool same_c = (512 % CgV) == 0;          // a thread's chunks all sit on the same channels: one gamma / beta fetch
+    float gm[VEC], bt[VEC];
+    {
+        const int c0 = g * Cg + (threadIdx.x % CgV) * VEC;
 #pragma unroll
-    for (int k = 0; k < GN_NCH; ++k) {
+        for (int q = 0; q < VEC; ++q) { gm[q] = gamma[c0 + q]; bt[q] = MISH ? beta[c0 + q] : 0.f; }
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
         const int e = threadIdx.x + k * 512;
         xr[k] = make_uint4(0, 0, 0, 0);
         dr[k] = make_uint4(0, 0, 0, 0);
@@ -554,43 +685,44 @@ __global__ void __launch_bounds__(512) gn_fused_bwd_kernel(int T_, int C, int G,
             xr[k] = *reinterpret_cast<const uint4*>(x + i);
             dr[k] = *reinterpret_cast<const uint4*>(dy + i);
         }
-        if (e < nlive) {
-            const int c0 = g * Cg + (e % CgV) * VEC;
-            const T* ve = reinterpret_cast<const T*>(&xr[k]);
-            const T* de = reinterpret_cast<const T*>(&dr[k]);
+    }
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                const float xh = (to_f32(ve[q]) - mu) * rs;
-                float dz = to_f32(de[q]);
-                if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c0 + q] + beta[c0 + q]);
-                dz *= gamma[c0 + q];
-                s1 += dz;
-                s2 += dz * xh;
-            }
+    for (int k = 0; k < NCH; ++k) {
+        const int e = threadIdx.x + k * 512;
+        const bool live = e < nlive;
+        if (!same_c) {
+            const int c0 = g * Cg + (e % CgV) * VEC;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) { gm[q] = gamma[c0 + q]; bt[q] = MISH ? beta[c0 + q] : 0.f; }
         }
+        const T* ve = reinterpret_cast<const T*>(&xr[k]);
+        const T* de = reinterpret_cast<const T*>(&dr[k]);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const float xh = (to_f32(ve[q]) - mu) * rs;
+            float dz = to_f32(de[q]);
+            if (MISH) dz *= act_grad(CVFT_ACT_MISH, xh * gm[q] + bt[q]);
+            dz = live ? dz * gm[q] : 0.f;
+            dzr[k][q] = dz;
+            s1 += dz;
+            s2 += dz * xh;          // (dz == 0 outside the live frames)
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one chunk's temporaries at a time (interleaved, the 8-chunk form spilled)
     }
     const float w1 = block_sum(s1, sm) / n;
     const float w2 = block_sum(s2, sm) / n;
 #pragma unroll
-    for (int k = 0; k < GN_NCH; ++k) {
+    for (int k = 0; k < NCH; ++k) {
         const int e = threadIdx.x + k * 512;
         if (e >= nall) continue;
-        const int t = e / CgV, cc = (e % CgV) * VEC, c0 = g * Cg + cc;
+        const int t = e / CgV, cc = (e % CgV) * VEC;
         const bool pad = t_eff && t >= Te;
-        const bool live = t < lb;
         const T* ve = reinterpret_cast<const T*>(&xr[k]);
-        const T* de = reinterpret_cast<const T*>(&dr[k]);
         T ov[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             const float xh = (to_f32(ve[q]) - mu) * rs;
-            float dz = 0.f;
-            if (live) {
-                dz = to_f32(de[q]);
-                if (apply_mish) dz *= act_grad(CVFT_ACT_MISH, xh * gamma[c0 + q] + beta[c0 + q]);
-                dz *= gamma[c0 + q];
-            }
-            ov[q] = from_f32<T>(pad ? 0.f : rs * (dz - w1 - xh * w2));
+            ov[q] = from_f32<T>(pad ? 0.f : rs * (dzr[k][q] - w1 - xh * w2));
         }
         *reinterpret_cast<uint4*>(dx + off + (size_t)t * C + cc) = *reinterpret_cast<const uint4*>(ov);
     }
@@ -619,10 +751,15 @@ extern "C" int cvft_groupnorm_mish_fwd(int dtype, int B, int T, int C, int G, co
     const bool vp = ((C / G) % vec == 0) && (C % vec == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const bool vpa = vp && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (!add || ((reinterpret_cast<uintptr_t>(add) & 15) == 0));
     if (gn_fused_ok(T, C / G, vec, vpa)) {
-        if (dtype == CVFT_F32) hipLaunchKernelGGL((gn_fused_fwd_kernel<float>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, gamma, beta, eps,
-                                                  len, (const float*)add, apply_mish, (float*)y, mean, rstd, t_eff);
-        else hipLaunchKernelGGL((gn_fused_fwd_kernel<bf16_t>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, gamma, beta, eps,
-                                len, (const bf16_t*)add, apply_mish, (bf16_t*)y, mean, rstd, t_eff);
+        // chunks per thread the kernel is unrolled for: 4 cover the estimator's slabs (500 frames x 4 chunks) with half the registers
+        const bool half = (long)T * (C / G / vec) <= 512L * (GN_NCH / 2);
+#define GN_FF(TT, MI) do { if (half) hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, MI, GN_NCH / 2>), dim3(B * G), dim3(512), 0, st, T, C, G, (const TT*)x, gamma, beta, eps, \
+                                         len, (const TT*)add, (TT*)y, mean, rstd, t_eff);                                                   \
+                           else hipLaunchKernelGGL((gn_fused_fwd_kernel<TT, MI, GN_NCH>), dim3(B * G), dim3(512), 0, st, T, C, G, (const TT*)x, gamma, beta, eps, \
+                                         len, (const TT*)add, (TT*)y, mean, rstd, t_eff); } while (0)
+        if (dtype == CVFT_F32) { if (apply_mish) GN_FF(float, true); else GN_FF(float, false); }
+        else { if (apply_mish) GN_FF(bf16_t, true); else GN_FF(bf16_t, false); }
+#undef GN_FF
         CVFT_LAUNCH_CHECK("cvft_groupnorm_mish_fwd");
         return 0;
     }
@@ -657,10 +794,14 @@ extern "C" int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, co
     const bool vp = ((C / G) % vec == 0) && (C % vec == 0) &&
                     (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
     if (gn_fused_ok(T, C / G, vec, vp)) {
-        if (dtype == CVFT_F32) hipLaunchKernelGGL((gn_fused_bwd_kernel<float>), dim3(B * G), dim3(512), 0, st, T, C, G, (const float*)x, gamma, beta, mean,
-                                                  rstd, len, apply_mish, (const float*)dy, (float*)dx, t_eff);
-        else hipLaunchKernelGGL((gn_fused_bwd_kernel<bf16_t>), dim3(B * G), dim3(512), 0, st, T, C, G, (const bf16_t*)x, gamma, beta, mean,
-                                rstd, len, apply_mish, (const bf16_t*)dy, (bf16_t*)dx, t_eff);
+        const bool half = (long)T * (C / G / vec) <= 512L * (GN_NCH / 2);
+#define GN_FB(TT, MI) do { if (half) hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, MI, GN_NCH / 2>), dim3(B * G), dim3(512), 0, st, T, C, G, (const TT*)x, gamma, beta, mean, \
+                                         rstd, len, (const TT*)dy, (TT*)dx, t_eff);                                                         \
+                           else hipLaunchKernelGGL((gn_fused_bwd_kernel<TT, MI, GN_NCH>), dim3(B * G), dim3(512), 0, st, T, C, G, (const TT*)x, gamma, beta, mean, \
+                                         rstd, len, (const TT*)dy, (TT*)dx, t_eff); } while (0)
+        if (dtype == CVFT_F32) { if (apply_mish) GN_FB(float, true); else GN_FB(float, false); }
+        else { if (apply_mish) GN_FB(bf16_t, true); else GN_FB(bf16_t, false); }
+#undef GN_FB
         CVFT_LAUNCH_CHECK("cvft_groupnorm_mish_bwd");
         return 0;
     }

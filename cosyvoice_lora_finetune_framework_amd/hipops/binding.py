@@ -117,6 +117,7 @@ SIGNATURES = {
     "cvft_layernorm_fwd": [_i, _i, _i, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p],
     "cvft_layernorm_bwd": [_i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p],
     "cvft_layernorm_bwd_mask": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, C.c_uint, _p, _p],
+    "cvft_layernorm_bwd_mask_side": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, C.c_uint, _p, _p, _i, _f, _p, _p],
     "cvft_groupnorm_mish_fwd": [_i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _p],
     "cvft_groupnorm_mish_bwd": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p],
     "cvft_attn_bias_fwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _f, _i, _p, _i, _p, _p],

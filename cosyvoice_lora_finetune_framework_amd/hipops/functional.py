@@ -278,6 +278,7 @@ def dropout_begin_step() -> None:
     _DROPPED.clear()              # dropped inputs a previous forward wrote and no backward consumed
     _ODROP_OUT.clear()
     _PRE_MASKED.clear()
+    _PRE_V.clear()
     _PRE_U.clear()                # a LayerNorm hand-off no adapter took (with the dropped copies it keeps alive)
 
 
@@ -373,23 +374,52 @@ _PRE_U = {}        # LN output data_ptr -> (U, A data_ptr, alpha, p, sites): the
 # The residual-branch dropout of an encoder sublayer, y = residual + dropout(linear(.)), has its mask applied in the GEMM epilogue;
 # in backward the linear needs keep / (1 - p) * dy.  dy is written by the LayerNormForkFn that consumed y (its one consumer), so
 # that launch writes the masked copy too (cvft_layernorm_bwd_mask) and the linear's own mask pass over dy disappears.
-_ODROP_OUT = {}     # data_ptr of y -> (p, site), noted by the producing Function, read by the LayerNormForkFn that takes y
-_PRE_MASKED = {}    # data_ptr of the dx a LayerNormForkFn backward wrote -> (dxm, p, site)
+_ODROP_OUT = {}     # data_ptr of y -> (p, site, side), noted by the producing Function, read by the LayerNormForkFn that takes y
+_PRE_MASKED = {}    # data_ptr of the dx a LayerNormForkFn backward wrote -> (dxm, p, site, side product or None)
+# When that linear carries a rank-16 adapter, side = (Bt, scale) and the same LayerNorm-backward launch can also form
+# V = scale * dxm Bt^T (cvft_layernorm_bwd_mask_side), the product the adapter's backward would open with as a launch of its own
+# (40 launches per LLM step and chain): parked under dxm's address until _lin_bwd asks for exactly (dxm, Bt, scale).
+# Opt-in (CVFT_LN_BWD_SIDE=1): per launch 9.7 / 17.4 us against 7.2 + 4.9 / 12.4 + 4.9 us for the two launches (2 664 / 5 328 rows,
+# tools/bench_ln_side.py) -- the 32 KB of B^T each row re-reads from LDS costs what the second launch did; same-box steps:
+# joint 21.94 / 22.01 (off) vs 22.02 / 21.99 (on), llm_only 13.14 vs 13.25 ms.
+_PRE_V = {}         # data_ptr of dxm -> (V, Bt data_ptr, scale)
 import os as _os  # noqa: E402
 LN_BWD_MASK = _os.environ.get("CVFT_LN_BWD_MASK", "1") != "0"
+LN_BWD_SIDE = _os.environ.get("CVFT_LN_BWD_SIDE", "0") != "0"
 
 
-def _note_out_drop(y: torch.Tensor, od) -> None:
+def _note_out_drop(y: torch.Tensor, od, side=None) -> None:
+    """side = (Bt [16, N] compute dtype, scale) of the producing linear's adapter, or None."""
     if LN_BWD_MASK and od is not None:
-        _ODROP_OUT[y.data_ptr()] = (float(od[0]), int(od[1]))
+        if not (LN_BWD_SIDE and side is not None and side[0] is not None and side[0].dtype == torch.bfloat16 and y.dtype == torch.bfloat16
+                and side[0].dim() == 2 and side[0].shape[0] == 16 and side[0].shape[1] == y.shape[1] and side[0].is_contiguous()
+                and side[0].data_ptr() % 16 == 0):
+            side = None
+        _ODROP_OUT[y.data_ptr()] = (float(od[0]), int(od[1]), side)
 
 
 def _masked_dy(dy: torch.Tensor, od) -> torch.Tensor:
     """keep(site) / (1 - p) * dy: the copy the LayerNorm backward already wrote for exactly this (p, site), else one mask pass."""
     ent = _PRE_MASKED.pop(dy.data_ptr(), None)
     if ent is not None and ent[1] == float(od[0]) and ent[2] == int(od[1]) and ent[0].shape == dy.shape and ent[0].dtype == dy.dtype:
+        if ent[3] is not None:
+            _PRE_V[ent[0].data_ptr()] = ent[3]
         return ent[0]
     return dropout_raw(dy, od[0], od[1])
+
+
+def _take_side_v(dz: torch.Tensor, Bt: torch.Tensor, scale: float):
+    """The V = scale * dz Bt^T the LayerNorm backward that wrote dz made for exactly this (Bt, scale), else None."""
+    ent = _PRE_V.pop(dz.data_ptr(), None)
+    if ent is not None and ent[1] == Bt.data_ptr() and ent[2] == float(scale) and ent[0].shape == (dz.shape[0], Bt.shape[0]):
+        return ent[0]
+    return None
+
+
+def _side_v(dz: torch.Tensor, Bt: torch.Tensor, scale: float) -> torch.Tensor:
+    """V = scale * dz Bt^T [M, r]"""
+    V = _take_side_v(dz, Bt, scale)
+    return V if V is not None else gemm(dz, Bt, alpha=scale)
 
 
 def take_pre_u(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, nsites: int):
@@ -926,7 +956,7 @@ def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_d
         # accumulators BEFORE the epilogue, so act'(z) / the producer's mask still ride there) or by the side-dgrad kernel
         # (then the producer chain runs as a pass of its own); the adapter gradients see drop(x), re-materialised from the site
         Ac, At, Bc, Bt = ops
-        V = gemm(dz, Bt, alpha=scale)
+        V = _side_v(dz, Bt, scale)
         if need_dx:
             if _can_xdrop(dz, pack.Wb, V, At, dx_residual):
                 dx = gemm(dz, pack.Wb, U=V, Bl=At, residual=dx_residual, xdrop=(drop[0], [drop[1]] * (V.shape[1] // 16)),
@@ -940,7 +970,10 @@ def _lin_bwd(x, U, ops, A_ref, B_ref, pack: LinearPack, scale: float, dz, need_d
         return dx, dA, dB
     if has_lora:
         Ac, At, Bc, Bt = ops
-        if need_dx and _can_fuse(dz, Bt, At, pack.K, pack.N):
+        V = _take_side_v(dz, Bt, scale)
+        if V is not None:
+            pass
+        elif need_dx and _can_fuse(dz, Bt, At, pack.K, pack.N):
             # dgrad with the side path fused: V = s * dz B is produced by the same launch
             V = torch.empty((dz.shape[0], Bt.shape[0]), dtype=dz.dtype, device=dz.device)
             dx = gemm(dz, pack.Wb, La=Bt, lora_scale=scale, Uout=V, Bl=At, dact_src=dact_src, dact=dact, residual=dx_residual,
@@ -978,7 +1011,7 @@ class LinearFn(torch.autograd.Function):
             ctx.save_for_backward(x, None, None)
             return y[:, :pack.N]
         y, U, z, ops = _lin_fwd(x, A, B, pack, scale, act, residual, need_grad, ctx.drop, ctx.odrop)
-        _note_out_drop(y, ctx.odrop)
+        _note_out_drop(y, ctx.odrop, None if (ops is None or act) else (ops[3], scale))
         ctx.pack, ctx.scale, ctx.act = pack, scale, act
         ctx.ops, ctx.A_ref, ctx.B_ref = ops, A, B
         ctx.save_for_backward(x, U, z)
@@ -1206,7 +1239,7 @@ class FeedForwardFn(torch.autograd.Function):
         ctx.relu_h = RELU_FROM_H and act == "relu" and A2 is not None
         h, U1, z, ops1 = _lin_fwd(x, A1, B1, pack1, s1, act, None, need_grad and not ctx.relu_h, d1, od_in)
         y, U2, _, ops2 = _lin_fwd(h, A2, B2, pack2, s2, None, residual, False, d2, od_out)
-        _note_out_drop(y, od_out)
+        _note_out_drop(y, od_out, None if ops2 is None else (ops2[3], s2))
         ctx.cfg = (pack1, pack2, s1, s2, act, ops1, ops2, (A1, B1), (A2, B2))
         ctx.save_for_backward(x, U1, z, h if A2 is not None else None, U2)      # (h: dA2 = V2^T h, or drop(h) re-derived)
         return y
@@ -1724,10 +1757,20 @@ class LayerNormForkFn(torch.autograd.Function):
         if (od is not None and x.shape[1] % vec == 0 and x.shape[1] <= 256 * vec and
                 all(t is None or (t.data_ptr() & 15) == 0 for t in (x, dy, dres, dx))):
             dxm = torch.empty_like(x)          # dx under the mask of x's producer, parked for that Function's backward
+            side = od[2] if len(od) > 2 else None
+            if side is not None and x.dtype == torch.bfloat16:
+                Bt, sc = side
+                V = torch.empty((x.shape[0], 16), dtype=x.dtype, device=x.device)
+                check(lib().cvft_layernorm_bwd_mask_side(x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                                         ptr(dy), ptr(dres), ptr(dx), od[0], ptr(_DROPOUT["seed"]), od[1], ptr(dxm),
+                                                         ptr(Bt), 16, float(sc), ptr(V), stream()), "cvft_layernorm_bwd_mask_side")
+                _PRE_MASKED[dx.data_ptr()] = (dxm, od[0], od[1], (V, Bt.data_ptr(), float(sc)))
+                ctx.side_keep = Bt             # the parked address stays this tensor's until the adapter's backward has asked
+                return dx, None, None, None, None
             check(lib().cvft_layernorm_bwd_mask(dt(x), x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                                 ptr(dy), ptr(dres), ptr(dx), od[0], ptr(_DROPOUT["seed"]), od[1], ptr(dxm), stream()),
                   "cvft_layernorm_bwd_mask")
-            _PRE_MASKED[dx.data_ptr()] = (dxm, od[0], od[1])
+            _PRE_MASKED[dx.data_ptr()] = (dxm, od[0], od[1], None)
             return dx, None, None, None, None
         check(lib().cvft_layernorm_bwd(dt(x), x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                        0, 1.0, ptr(dy), ptr(dres), ptr(dx), stream()), "cvft_layernorm_bwd")

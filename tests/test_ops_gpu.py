@@ -838,6 +838,70 @@ def test_layernorm_backward_writes_the_producer_mask_copy(dtype):
     assert rel(h.grad, a[1]) > 5e-2
 
 
+@pytest.mark.parametrize("lora_p", [0.0, 0.1])
+def test_layernorm_backward_writes_the_adapter_side_product(lora_p):
+    """The linear in front of the LayerNorm carries a rank-16 adapter (lora.py:64-76): the LayerNorm backward that writes its
+    masked incoming gradient dxm also forms V = s * dxm B (cvft_layernorm_bwd_mask_side) and the adapter's backward takes it
+    instead of launching the product.  Checked against fp32 torch on the same dxm (bf16 output: 2^-8 relative per entry), and the
+    whole chain against the same chain with the hand-over off (same masks; V differs by summation order only)."""
+    HF = HFmod()
+    dtype = torch.bfloat16
+    torch.manual_seed(11)
+    M, d, hid, r = 333, 1024, 512, 16
+    lin = torch.nn.Linear(hid, d).to(DEV)
+    pack = HF.LinearPack(lin.weight, lin.bias, dtype)
+    A = (torch.randn(r, hid, device=DEV) * 0.05).requires_grad_(True)
+    Bm = (torch.randn(d, r, device=DEV) * 0.05).requires_grad_(True)
+    gamma, beta = (torch.rand(d, device=DEV) + 0.5), torch.randn(d, device=DEV) * 0.1
+    h = torch.randn(M, hid, device=DEV).to(dtype).requires_grad_(True)
+    res = torch.randn(M, d, device=DEV).to(dtype).requires_grad_(True)
+    g1, g2 = torch.randn(M, d, device=DEV).to(dtype), torch.randn(M, d, device=DEV).to(dtype)
+    HF.dropout_begin_step()
+    taken = []
+    orig_take = HF._take_side_v
+
+    def spy(dz, Bt, scale):
+        V = orig_take(dz, Bt, scale)
+        if V is not None:
+            taken.append((dz.detach().clone(), Bt.detach().clone(), float(scale), V.detach().clone()))
+        return V
+
+    def run(side: bool):
+        HF.LN_BWD_SIDE = side
+        HF._DROPOUT["site"] = 7
+        HF._ODROP_OUT.clear()
+        HF._PRE_MASKED.clear()
+        HF._PRE_V.clear()
+        h.grad = res.grad = None
+        gA = torch.zeros_like(A)
+        gB = torch.zeros_like(Bm)
+        A.grad, Bm.grad = gA, gB
+        x = HF.lora_linear(h, pack, A, Bm, 2.0, residual=res, drop_p=lora_p, out_drop_p=0.1)
+        xr, xn = HF.layernorm_fork(x, gamma, beta, 1e-5)
+        torch.autograd.backward([xr, xn], [g1, g2])
+        torch.cuda.synchronize()
+        assert len(HF._PRE_MASKED) == 0 and len(HF._PRE_V) == 0
+        return h.grad.clone(), res.grad.clone(), A.grad.clone(), Bm.grad.clone()
+    HF._take_side_v = spy
+    side_default = HF.LN_BWD_SIDE
+    try:
+        a = run(True)
+        assert len(taken) == 1                               # the adapter's backward took the parked product
+        n_on = len(taken)
+        b = run(False)
+        assert len(taken) == n_on                            # ... and none when the hand-over is off
+    finally:
+        HF._take_side_v = orig_take
+        HF.LN_BWD_SIDE = side_default
+    dz, Bt, sc, V = taken[0]
+    ref = sc * (dz.float() @ Bt.float().t())
+    assert V.shape == (M, r)
+    assert (V.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    assert torch.equal(a[1], b[1])                           # the residual gradient does not pass through the adapter
+    for u, w in zip(a, b):
+        assert rel(u, w) < 4e-3
+
+
 def test_encoder_train_mode_applies_dropout(tiny_meta=None):
     """RelPosEncoder in .train(): output differs from eval, differs between steps, p = 0 reproduces eval exactly."""
     HF = HFmod()

@@ -32,9 +32,10 @@ def timeit(call):
 
 def main():
     HF.dropout_begin_step()
+    ML = int(os.environ.get("LLM_ROWS", "2664"))      # 8 x 333: the LLM runs as two half-batch chains (5328 = whole batch)
     shapes = [("flow qkv (half batch)", 4000, 256, 48, 1536, 3), ("flow qkv (whole)", 8000, 256, 48, 1536, 3),
-              ("LLM out", 5376, 1024, 16, 1024, 1), ("LLM qkv", 5376, 1024, 48, 3072, 3), ("LLM w_1", 5376, 1024, 16, 4096, 1),
-              ("LLM w_2", 5376, 4096, 16, 1024, 1)]
+              ("LLM out", ML, 1024, 16, 1024, 1), ("LLM qkv", ML, 1024, 48, 3072, 3), ("LLM w_1", ML, 1024, 16, 4096, 1),
+              ("LLM w_2", ML, 4096, 16, 1024, 1)]
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     for name, M, K, R, N, nsite in shapes:
         xs = [torch.randn(M, K, device=dev, dtype=dt) for _ in range(NSETS)]
