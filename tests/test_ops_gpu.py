@@ -395,6 +395,44 @@ def test_cross_entropy(dtype):
     assert rel(ld.grad, 3.0 * lr.grad) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("V,pitch", [(4097, 4160), (4097, 4104), (515, 520), (9000, 9008)])
+def test_cross_entropy_padded_pitch_rows(dtype, V, pitch):
+    """The LLM's logits arrive as a [n, V] view of a zero-padded [n, pitch] buffer (16-byte aligned rows): cvft_ce_fwd takes a wave
+    per row with 16-byte loads -- the row held in registers up to 64 * 16 chunks, the two-pass loop beyond (V = 9000 in bf16 stays in
+    registers, in fp32 it does not) -- and more rows than 4 x 512 waves so that waves walk several rows; cvft_ce_bwd writes 16-byte
+    chunks.  Against torch in fp64 on the same (rounded) logits: loss, accuracy with torch.argmax's first-index tie rule, gradient;
+    the pad columns of the gradient stay zero."""
+    HF = HFmod()
+    n = 2100 if V < 5000 else 300
+    g = torch.Generator().manual_seed(3)
+    lg = q(torch.randn(n, V, generator=g) * 2, dtype)
+    tg = torch.randint(0, V, (n,), generator=g)
+    tg[::7] = -1
+    # ties: the maximum twice in a row; the target is the first of the two (counts as correct) or the second (does not)
+    for r, (i, j, t) in {1: (10, 200, 10), 2: (10, 200, 200), 5: (V - 9, V - 1, V - 9), 6: (V - 9, V - 1, V - 1)}.items():
+        lg[r, i] = lg[r, j] = 30.0
+        tg[r] = t
+    base = torch.zeros(n, pitch, device=DEV, dtype=dtype)
+    base[:, :V] = lg.to(DEV, dtype)
+    ld = base[:, :V].detach().requires_grad_(True)
+    assert ld.stride(0) == pitch
+    loss, acc = HF.cross_entropy(ld, tg.to(DEV, torch.int32), 0.0)
+    (loss * 2.0).backward()
+    lr = lg.double().requires_grad_(True)
+    valid = tg >= 0
+    loss_r = torch.nn.functional.cross_entropy(lr[valid], tg[valid])
+    (loss_r * 2.0).backward()
+    acc_r = (lr.detach().argmax(1)[valid] == tg[valid]).double().mean()
+    assert abs(float(loss) - float(loss_r)) / abs(float(loss_r)) < 2e-5
+    assert abs(float(acc) - float(acc_r)) < 1e-6
+    assert rel(ld.grad, lr.grad) < TOL[dtype]
+    assert float(ld.grad[~valid.to(DEV)].abs().max()) == 0.0
+    gbase = ld.grad.as_strided((n, pitch), (ld.grad.stride(0), 1)) if ld.grad.stride(0) == pitch else None
+    if gbase is not None:
+        assert float(gbase[:, V:].abs().max()) == 0.0
+
+
 def test_cross_entropy_label_smoothing_matches_reference():
     """cvft_ce_fwd/bwd with smoothing > 0 against the REFERENCE's LabelSmoothingLoss outputs (tests/golden/lsm.npz: loss and
     autograd gradient, fp32 1e-5) and, at the LLM's vocabulary size in both dtypes, against the oracle restatement."""
