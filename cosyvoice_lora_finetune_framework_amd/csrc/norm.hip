@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(int rows, int C, const T* _
 // SD (with MK): the linear in front carries a rank-16 adapter -- its backward starts with V = s * dxm B ([rows][16], lora.py:71-76),
 // a latency-bound launch of its own on the backward chain.  The wave that writes a row of dxm holds it in registers: it forms the
 // 16 dot products with B^T ([16][C], L2-resident) and reduces them with a halving butterfly (17 cross-lane moves for 16 sums).
-template <typename T, bool VP, bool MK = false, bool SD = false, int NCH = 4>
+template <typename T, bool VP, bool MK = false, bool SD = false, int NCH = 4, bool RLT = true>
 __device__ __forceinline__ void ln_bwd_row(const int row, int C, const T* __restrict__ x,
                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -121,8 +121,10 @@ __device__ __forceinline__ void ln_bwd_row(const int row, int C, const T* __rest
                     const int c = ch * VEC + k;
                     float h = (to_f32(ex[k]) - mu) * rs;
                     float gg = to_f32(ed[k]) * post;
-                    if (relu && (h * gamma[c] + beta[c]) <= 0.f) gg = 0.f;
-                    gg *= gamma[c];
+                    // (gamma / beta fetched unconditionally: behind the run-time relu test they were one load and one branch per element)
+                    const float gmv = gamma[c], btv = RLT ? beta[c] : 0.f;
+                    if (RLT) gg = ((relu != 0) & ((h * gmv + btv) <= 0.f)) ? 0.f : gg;
+                    gg *= gmv;
                     xh[q][k] = h;
                     g[q][k] = gg;
                     s1 += gg;
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
                                                       unsigned msite = 0, T* __restrict__ dxm = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    ln_bwd_row<T, VP, MK, false, NCH>(row, C, x, gamma, beta, mean, rstd, RL ? relu : 0, post, dy, dres, dx, mp, mseed, msite, dxm);
+    ln_bwd_row<T, VP, MK, false, NCH, RL>(row, C, x, gamma, beta, mean, rstd, RL ? relu : 0, post, dy, dres, dx, mp, mseed, msite, dxm);
 }
 
 // The side-product form: B^T ([16][C] bf16, 32 KB at C = 1024) is staged in LDS once per block and every wave walks rows
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(256) ln_bwd_side_kernel(int rows, int C, const
     for (int i = threadIdx.x; i < 2 * C; i += 256) bl[i] = reinterpret_cast<const uint4*>(sB)[i];      // 16 * C / 8 chunks
     __syncthreads();
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4)
-        ln_bwd_row<bf16_t, true, true, true, NCH>(row, C, x, gamma, beta, mean, rstd, 0, 1.f, dy, dres, dx, mp, mseed, msite, dxm,
+        ln_bwd_row<bf16_t, true, true, true, NCH, false>(row, C, x, gamma, beta, mean, rstd, 0, 1.f, dy, dres, dx, mp, mseed, msite, dxm,
                                              reinterpret_cast<const bf16_t*>(ln_smem), salpha, sV);
 }
 

@@ -662,25 +662,50 @@ class LoraGradSink:
         for C, Wd, Rk, ws, tr, rp in ((K, x, V, wsA, 0, rpa), (N, dY, U, wsB, 1, rpb)):
             assert (C % 8 == 0 and Wd.stride(0) % 8 == 0 and Rk.stride(0) % 8 == 0 and Wd.data_ptr() % 16 == 0 and Rk.data_ptr() % 16 == 0
                     and ws.data_ptr() % 16 == 0 and rp % 32 == 0 and Wd.dtype == Rk.dtype == torch.bfloat16 and Rk.shape[1] == r)
-            self.deferred.setdefault(r, []).append((M, C, Wd.data_ptr(), Wd.stride(0), Rk.data_ptr(), Rk.stride(0), ws.data_ptr(), tr, rp, 0))
+            self.deferred.setdefault(r, []).append((M, C, Wd.data_ptr(), Wd.stride(0), Rk.data_ptr(), Rk.stride(0), ws.data_ptr(), tr, rp,
+                                                    torch.cuda.current_stream().cuda_stream))
         self.keep.append((x, V, dY, U))
         self._note_stream()
+        self._deferred_added(r)
 
     def defer_one(self, M: int, r: int, C_: int, Wd, Rk, ws, transpose_out: int, rpb: int, keep=()):
         """Postpone ONE slab product (slabs of Rk^T Wd, [r, C] or [C, r] when transpose_out) to flush()."""
         assert (C_ % 8 == 0 and Wd.stride(0) % 8 == 0 and Rk.stride(0) % 8 == 0 and Wd.data_ptr() % 16 == 0 and Rk.data_ptr() % 16 == 0
                 and ws.data_ptr() % 16 == 0 and rpb % 32 == 0 and Wd.dtype == Rk.dtype == torch.bfloat16 and Rk.shape[1] == r)
-        self.deferred.setdefault(r, []).append((M, C_, Wd.data_ptr(), Wd.stride(0), Rk.data_ptr(), Rk.stride(0), ws.data_ptr(), transpose_out, rpb, 0))
+        self.deferred.setdefault(r, []).append((M, C_, Wd.data_ptr(), Wd.stride(0), Rk.data_ptr(), Rk.stride(0), ws.data_ptr(), transpose_out, rpb,
+                                                torch.cuda.current_stream().cuda_stream))
         self.keep.append((Wd, Rk, ws) + tuple(keep))
         self._note_stream()
+        self._deferred_added(r)
+
+    @staticmethod
+    def _launch_rows(r: int, rows):
+        arr = (cb.RankProbM * len(rows))()
+        for e, (M, Cn, Wd, ldw, Rk, ldr, ws, tr, rp, _) in zip(arr, rows):
+            e.M, e.C, e.Wd, e.ldw, e.Rk, e.ldr, e.part, e.transpose_out, e.rows_per_block = M, Cn, Wd, ldw, Rk, ldr, ws, tr, rp
+        check(lib().cvft_lora_rank_partial_batch(r, len(rows), arr, stream()), "cvft_lora_rank_partial_batch")
 
     def _launch_deferred(self):
         for r, rows in self.deferred.items():
-            arr = (cb.RankProbM * len(rows))()
-            for e, (M, Cn, Wd, ldw, Rk, ldr, ws, tr, rp, _) in zip(arr, rows):
-                e.M, e.C, e.Wd, e.ldw, e.Rk, e.ldr, e.part, e.transpose_out, e.rows_per_block = M, Cn, Wd, ldw, Rk, ldr, ws, tr, rp
-            check(lib().cvft_lora_rank_partial_batch(r, len(rows), arr, stream()), "cvft_lora_rank_partial_batch")
+            if rows:
+                LoraGradSink._launch_rows(r, rows)
         self.deferred = {}
+
+    def _deferred_added(self, r: int):
+        """CVFT_SINK_DEFER_EARLY=1 (experiment, off): once a chain has postponed SINK_EARLY_BATCH products of one rank, that batch goes
+        out on the chain's own stream instead of after the last chain (the batch launches are ~0.9 ms of kernel time between the end
+        of backward and the reduce).  Measured, joint B = 16: a stream of their own for them 22.2 -> 33.5 ms (a fifth stream in the
+        captured graph shares a hardware queue with a chain); see DESIGN section 12 for the in-chain form."""
+        if not SINK_DEFER_EARLY:
+            return
+        cur = torch.cuda.current_stream()
+        rows = self.deferred[r]
+        mine = [i for i, e in enumerate(rows) if e[9] == cur.cuda_stream]
+        if len(mine) < SINK_EARLY_BATCH:
+            return
+        LoraGradSink._launch_rows(r, [rows[i] for i in mine])
+        keep = set(mine)
+        self.deferred[r] = [e for i, e in enumerate(rows) if i not in keep]
 
     def workspace(self, P: torch.Tensor, nsplit: int) -> torch.Tensor:
         """Slab workspace (nsplit x P.numel() floats) for the next product on parameter P inside this sink.  Several
@@ -799,6 +824,8 @@ SINK_PLAN_BLOCKS = int(_os.environ.get('CVFT_SINK_PLAN_BLOCKS', 512))     # wave
 SINK_DEFER = _os.environ.get('CVFT_SINK_DEFER', '1') != '0'
 SINK_DEFER_MAX = int(_os.environ.get('CVFT_SINK_DEFER_MAX', 12_000_000))      # x.numel() + dY.numel(): the flow branch's layers
 SINK_DEFER_RPB = int(_os.environ.get('CVFT_SINK_DEFER_RPB', 256))
+SINK_DEFER_EARLY = _os.environ.get('CVFT_SINK_DEFER_EARLY', '1') != '0'     # full batches leave during backward on their chain's stream
+SINK_EARLY_BATCH = int(_os.environ.get('CVFT_SINK_EARLY_BATCH', 24))       # (= CVFT_RANK_BATCH, one launch)
 FUSE_MAX_MN = int(_os.environ.get('CVFT_FUSE_MAX_MN', 3_000_000))   # measured (tools/bench_fused.py): the in-launch side path wins for the small estimator GEMMs only
 
 
