@@ -279,6 +279,8 @@ def dropout_begin_step() -> None:
     _ODROP_OUT.clear()
     _PRE_MASKED.clear()
     _PRE_V.clear()
+    _FORK_OPEN.clear()
+    _PRE_DX.clear()
     _PRE_U.clear()                # a LayerNorm hand-off no adapter took (with the dropped copies it keeps alive)
 
 
@@ -1667,10 +1669,26 @@ class ConvPack:
         return Tin if self.stride == 1 else (Tin - 1) // 2 + 1
 
 
+# Two stride-1 convolutions reading the SAME x (ResnetBlock1D: block1's conv and res_conv, matcha decoder.py:76-94): autograd would
+# add their two input gradients with a launch of its own (14 per Flow chain and step).  The later conv in forward order ("park")
+# runs FIRST in backward: it parks its dx and reports a zero gradient; the earlier one ("take") adds the parked tensor in its
+# dgrad epilogue.  The pair is armed in forward only when both saw the same buffer.
+_FORK_OPEN = {}     # data_ptr of x -> True, set by the "take" conv's forward, consumed by the "park" conv's forward
+_PRE_DX = {}        # data_ptr of x -> dx parked by the "park" conv's backward
+CONV_FORK = _os.environ.get("CVFT_CONV_FORK", "1") != "0"
+
+
 class ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, pack: ConvPack, B: int, Tin: int, Tout: int, in_len, out_len):
+    def forward(ctx, x, residual, pack: ConvPack, B: int, Tin: int, Tout: int, in_len, out_len, fork=None):
         x = _c(x)
+        ctx.fork, ctx.xkey = None, x.data_ptr()
+        if CONV_FORK and fork is not None and not pack.transposed and pack.stride == 1 and ctx.needs_input_grad[0]:
+            if fork == "take":
+                _FORK_OPEN[ctx.xkey] = True
+                ctx.fork = "take"
+            elif fork == "park" and _FORK_OPEN.pop(ctx.xkey, None):
+                ctx.fork = "park"
         pad = (pack.k - 1) // 2
         if not pack.transposed:
             taps = tuple(range(-pad, pad + 1))
@@ -1693,12 +1711,17 @@ class ConvFn(torch.autograd.Function):
         pack, B, Tin, Tout = ctx.pack, ctx.B, ctx.Tin, ctx.Tout
         dy = _c(dy)
         if not ctx.needs_input_grad[0]:
-            return None, (dy if ctx.needs_input_grad[1] else None), None, None, None, None, None, None
+            return None, (dy if ctx.needs_input_grad[1] else None), None, None, None, None, None, None, None
         # forward's output mask zeroes dy rows >= out_len; forward's input mask zeroes dx rows >= in_len
         kw = dict(nb=B, in_len=ctx.out_len, out_len=ctx.in_len)
         if not pack.transposed and pack.stride == 1:
             pad = (pack.k - 1) // 2
-            dx = gemm(dy, pack.Wb[0], geo=Geo(Tm=Tin, Tin=Tout, Tout=Tin, taps=tuple(range(-pad, pad + 1))), **kw)
+            # (the parked tensor carries the same row mask, so mask(dgrad + parked) == mask(dgrad) + parked)
+            parked = _PRE_DX.pop(ctx.xkey, None) if ctx.fork == "take" else None
+            dx = gemm(dy, pack.Wb[0], geo=Geo(Tm=Tin, Tin=Tout, Tout=Tin, taps=tuple(range(-pad, pad + 1))), residual=parked, **kw)
+            if ctx.fork == "park":
+                _PRE_DX[ctx.xkey] = dx
+                return None, (dy if ctx.needs_input_grad[1] else None), None, None, None, None, None, None, None
         elif not pack.transposed:
             dx = torch.empty((B * Tin, pack.Cin), dtype=dy.dtype, device=dy.device)
             gemm(dy, pack.Wb[0], geo=Geo(Tm=(Tin + 1) // 2, Tin=Tout, Tout=Tin, out_stride=2, out_off=0, taps=(0,)), out=dx, **kw)
@@ -1708,15 +1731,17 @@ class ConvFn(torch.autograd.Function):
             dx = gemm(dy, pack.Wb[0], geo=Geo(Tm=Tin, Tin=Tout, Tout=Tin, in_stride=2, taps=(-1, 0, 1, 2)), **kw)
         # residual is added after the output mask only when out_len is None (the only use: ResnetBlock1D)
         dres = dy if ctx.needs_input_grad[1] else None
-        return dx, dres, None, None, None, None, None, None
+        return dx, dres, None, None, None, None, None, None, None
 
 
-def conv1d(x, pack: ConvPack, B: int, Tin: int, Tout: Optional[int] = None, in_len=None, out_len=None, residual=None):
+def conv1d(x, pack: ConvPack, B: int, Tin: int, Tout: Optional[int] = None, in_len=None, out_len=None, residual=None, fork=None):
     """x [B*Tin, Cin] -> [B*Tout, Cout]; in_len masks input frames (x*mask), out_len zeroes output frames;
-    `residual` [B*Tout, Cout] is added in the GEMM epilogue (stride-1 convs, no out_len)."""
+    `residual` [B*Tout, Cout] is added in the GEMM epilogue (stride-1 convs, no out_len).
+    fork: "take" on the first and "park" on the second of two stride-1 convs of the same x, the second one's output depending on the
+    first's (so its backward runs first): their input gradients are summed inside the first conv's dgrad launch."""
     Tout = pack.out_len(Tin) if Tout is None else Tout
     assert residual is None or out_len is None
-    return ConvFn.apply(x, residual, pack, B, Tin, Tout, in_len, out_len)
+    return ConvFn.apply(x, residual, pack, B, Tin, Tout, in_len, out_len, fork)
 
 
 # ---------------------------------------------------------------------------------

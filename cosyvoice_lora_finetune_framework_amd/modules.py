@@ -247,9 +247,9 @@ class Block1D(nn.Module):
         super().__init__()
         self.block = nn.Sequential(nn.Conv1d(dim, dim_out, 3, padding=1), nn.GroupNorm(groups, dim_out), nn.Mish())
 
-    def forward(self, x, B, T, length, add=None, t_eff=None):
+    def forward(self, x, B, T, length, add=None, t_eff=None, fork=None):
         conv, gn = self.block[0], self.block[1]
-        h = HF.conv1d(x, conv_pack(conv, x.dtype), B, T, in_len=length)
+        h = HF.conv1d(x, conv_pack(conv, x.dtype), B, T, in_len=length, fork=fork)
         return HF.groupnorm_mish(h, _f32(gn.weight), _f32(gn.bias), B, T, gn.num_groups, gn.eps, length, add, True, t_eff)
 
 
@@ -266,10 +266,11 @@ class ResnetBlock1D(nn.Module):
     def forward(self, x, B, T, length, temb_mish, t_eff=None):
         with torch.no_grad():
             add = hip_linear(self.mlp[1], temb_mish)                       # [B, dim_out]; depends on t only
-        h = self.block1(x, B, T, length, add=add, t_eff=t_eff)
+        # x feeds block1's conv and res_conv: the two input gradients meet inside block1's dgrad launch (HF.conv1d `fork`)
+        h = self.block1(x, B, T, length, add=add, t_eff=t_eff, fork="take")
         h = self.block2(h, B, T, length, t_eff=t_eff)
         # h + res_conv(x * mask): 1x1 conv == tap-GEMM with the input-length mask, residual fused
-        return HF.conv1d(x, conv_pack(self.res_conv, x.dtype), B, T, in_len=length, residual=h)
+        return HF.conv1d(x, conv_pack(self.res_conv, x.dtype), B, T, in_len=length, residual=h, fork="park")
 
 
 class Downsample1D(nn.Module):

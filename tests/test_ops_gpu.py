@@ -396,6 +396,59 @@ def test_cross_entropy(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_resnet_block_fork_gradients_meet_in_the_dgrad_launch(dtype):
+    """ResnetBlock1D (matcha decoder.py:76-94): x feeds block1's conv and res_conv.  With HF.CONV_FORK the res_conv backward parks
+    its dx and block1's dgrad launch adds it (no autograd accumulation launch); against the same block with the hand-over off
+    (autograd's own add) and against torch fp64 autograd on the module's own math; ragged lengths; nothing left parked."""
+    HF = HFmod()
+    from cosyvoice_lora_finetune_framework_amd.modules import ResnetBlock1D
+    torch.manual_seed(4)
+    B, T, Cin, Cout, Ct = 3, 50, 320, 256, 64
+    blk = ResnetBlock1D(Cin, Cout, Ct).to(DEV)
+    length = torch.tensor([50, 37, 12], dtype=torch.int32, device=DEV)
+    x0 = torch.randn(B * T, Cin, device=DEV).to(dtype)
+    temb = torch.randn(B, Ct, device=DEV).to(dtype)
+    g = torch.randn(B * T, Cout, device=DEV).to(dtype)
+
+    def run(fork: bool):
+        HF.CONV_FORK = fork
+        HF._FORK_OPEN.clear()
+        HF._PRE_DX.clear()
+        x = x0.clone().requires_grad_(True)
+        y = blk(x, B, T, length, torch.nn.functional.mish(temb.float()).to(dtype))
+        y.backward(g)
+        torch.cuda.synchronize()
+        assert len(HF._FORK_OPEN) == 0 and len(HF._PRE_DX) == 0
+        return y.detach().clone(), x.grad.clone()
+    default = HF.CONV_FORK
+    try:
+        ya, ga = run(True)
+        yb, gb = run(False)
+    finally:
+        HF.CONV_FORK = default
+    assert torch.equal(ya, yb)
+    assert rel(ga, gb) < (1e-6 if dtype == torch.float32 else 4e-3)
+    # fp64 torch on the same weights: mask -> conv -> GroupNorm -> Mish -> mask (+ time term), twice, plus the 1x1 residual conv
+    import torch.nn.functional as F
+    xr = x0.double().reshape(B, T, Cin).transpose(1, 2).clone().requires_grad_(True)
+    mask = (torch.arange(T, device=DEV)[None, :] < length[:, None]).double()[:, None, :]
+    W = lambda m: (m.weight.double(), m.bias.double())
+
+    def block1d(b1d, h):
+        conv, gn = b1d.block[0], b1d.block[1]
+        h = F.conv1d(h * mask, *W(conv), padding=1)
+        h = F.group_norm(h, gn.num_groups, gn.weight.double(), gn.bias.double(), gn.eps)
+        return F.mish(h) * mask
+    h = block1d(blk.block1, xr)
+    h = h + F.linear(F.mish(temb.double()), *W(blk.mlp[1]))[:, :, None]
+    h = block1d(blk.block2, h)
+    yr = h + F.conv1d(xr * mask, *W(blk.res_conv))
+    yr.backward(g.double().reshape(B, T, Cout).transpose(1, 2))
+    gr = xr.grad.transpose(1, 2).reshape(B * T, Cin)
+    assert rel(ga, gr) < (2e-5 if dtype == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("V,pitch", [(4097, 4160), (4097, 4104), (515, 520), (9000, 9008)])
 def test_cross_entropy_padded_pitch_rows(dtype, V, pitch):
     """The LLM's logits arrive as a [n, V] view of a zero-padded [n, pitch] buffer (16-byte aligned rows): cvft_ce_fwd takes a wave
