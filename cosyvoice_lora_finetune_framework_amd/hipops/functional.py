@@ -2119,8 +2119,8 @@ class CrossEntropyFn(torch.autograd.Function):
         check(lib().cvft_ce_fwd(dt(logits), n, V, ptr(logits), logits.stride(0), ptr(target), ptr(out3), ptr(row_lse),
                                 ctx.smoothing, stream()), "cvft_ce_fwd")
         ctx.save_for_backward(logits, target, row_lse, out3)
-        loss = out3[0] / out3[1]
-        acc = out3[2] / out3[1]
+        q = out3 / out3[1]                    # one launch for both quotients (this sits between the LLM's forward and backward)
+        loss, acc = q[0], q[2]
         ctx.mark_non_differentiable(acc)
         return loss, acc
 

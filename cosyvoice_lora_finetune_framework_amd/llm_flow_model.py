@@ -37,6 +37,24 @@ CHAINS_HINT = 0        # > 0: pin the concurrent-chains hint (bench.py's single-
 BRANCH_STREAMS = os.environ.get("CVFT_BRANCH_STREAMS", "1") != "0"      # LLM branch on a second stream (joint mode): 35.9 -> 30.1 ms/step
 
 
+LOSS_FUSE = os.environ.get("CVFT_LOSS_FUSE", "1") != "0"      # 0: the plain op-per-factor recombination (A/B)
+
+
+def _scaled(x, w):
+    """x * w without the launch when w is the Python number 1"""
+    return x if (LOSS_FUSE and isinstance(w, (int, float)) and w == 1) else x * w
+
+
+def _total(xs):
+    """sum of 0-d tensors without `0 + x` (the built-in sum's start value costs a launch)"""
+    if not LOSS_FUSE:
+        return sum(xs)
+    t = xs[0]
+    for x in xs[1:]:
+        t = t + x
+    return t
+
+
 class JointLLMFlowModel(nn.Module):
     _streams: list = []
     def __init__(self, llm: nn.Module, flow: nn.Module, training_mode: str = 'joint', llm_loss_weight: float = 1.0,
@@ -91,13 +109,15 @@ class JointLLMFlowModel(nn.Module):
                 st.wait_stream(cur)
             with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
                 part = parts[kind][k]
+                # (every scalar op here is a launch of its own on the joined stream, with the whole chip waiting between the
+                # last forward chain and the first backward launch -- and another one or two in backward: unit factors are skipped)
                 if kind == 'llm':
                     r = self._forward_llm(part, device)
-                    results[(kind, k)] = (r['loss'] * part['_w_llm'], r['acc'] * part['_w_llm'] if 'acc' in r else None)
+                    results[(kind, k)] = (_scaled(r['loss'], part['_w_llm']), _scaled(r['acc'], part['_w_llm']) if 'acc' in r else None)
                 else:
                     d = None if draws is None else {n_: v[part['_rows']] if '_rows' in part else v for n_, v in draws.items()}
                     r = self._forward_flow(part, device, d)
-                    results[(kind, k)] = (r['loss'] * part['_w_flow'], None)
+                    results[(kind, k)] = (_scaled(r['loss'], part['_w_flow']), None)
             if st is not None:
                 results[(kind, k)] = (results[(kind, k)], st)
         for key, v in list(results.items()):                       # join
@@ -105,11 +125,11 @@ class JointLLMFlowModel(nn.Module):
                 cur.wait_stream(v[1])
                 results[key] = v[0]
         if do_llm:
-            losses['llm_loss'] = sum(results[('llm', k)][0] for k in range(len(parts['llm']))) * self.llm_loss_weight
+            losses['llm_loss'] = _scaled(_total([results[('llm', k)][0] for k in range(len(parts['llm']))]), self.llm_loss_weight)
             if results[('llm', 0)][1] is not None:
-                losses['llm_acc'] = sum(results[('llm', k)][1] for k in range(len(parts['llm'])))
+                losses['llm_acc'] = _total([results[('llm', k)][1] for k in range(len(parts['llm']))])
         if do_flow:
-            losses['flow_loss'] = sum(results[('flow', k)][0] for k in range(len(parts['flow']))) * self.flow_loss_weight
+            losses['flow_loss'] = _scaled(_total([results[('flow', k)][0] for k in range(len(parts['flow']))]), self.flow_loss_weight)
         if self.training_mode == 'joint':
             losses['loss'] = losses['llm_loss'] + losses['flow_loss']
         elif self.training_mode == 'llm_only':

@@ -49,6 +49,19 @@ class LossThresholdCallback:
                 return
 
 
+def _weighted_total(losses, keys, w, accum: int):
+    """sum_k w[k] * losses[k + '_loss'] / accum with as few launches as it takes: these scalar ops sit between the last forward
+    chain and the first backward launch with the whole chip waiting (each is ~5 us, and costs as much again in backward)."""
+    from .llm_flow_model import LOSS_FUSE
+    if not LOSS_FUSE:
+        return sum(losses[f"{k}_loss"] * w[i] for i, k in enumerate(keys)) / accum
+    if len(keys) == 1:
+        t = losses[f"{keys[0]}_loss"] * w[0]
+    else:
+        t = torch.dot(torch.stack([losses[f"{k}_loss"].float() for k in keys]), w[:len(keys)].float())
+    return t if accum == 1 else t / accum
+
+
 class EarlyStopping:
     """Lightning EarlyStopping(monitor='train_loss_epoch', min_delta=1e-3, patience=10, mode='min')
     as configured at train_joint.py:324-331."""
@@ -329,9 +342,9 @@ class _StepGraph:
 
         def run():
             losses = model(self.batch, dev, self.draws)
-            total = sum(losses[f"{k}_loss"] * self.w[i] for i, k in enumerate(keys))
+            total = _weighted_total(losses, keys, self.w, accum)
             with LoraGradSink():
-                (total / accum).backward()
+                total.backward()
             return {k: v.detach() for k, v in losses.items()}
 
         saved = flat_g.clone()
@@ -559,9 +572,9 @@ class Trainer:
             batch = prepared.tree
         self.graph_stats["eager"] += 1
         losses = module.model(batch, dev, draws)
-        total = sum(losses[f"{k}_loss"] * w[i] for i, k in enumerate(keys))
+        total = _weighted_total(losses, keys, w, self.accum)
         with LoraGradSink():
-            (total / self.accum).backward()
+            total.backward()
         return {k: v.detach() for k, v in losses.items()}
 
     # -- fit ------------------------------------------------------------------------------
