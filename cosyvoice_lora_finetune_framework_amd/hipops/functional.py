@@ -1673,8 +1673,11 @@ class ConvPack:
 # add their two input gradients with a launch of its own (14 per Flow chain and step).  The later conv in forward order ("park")
 # runs FIRST in backward: it parks its dx and reports a zero gradient; the earlier one ("take") adds the parked tensor in its
 # dgrad epilogue.  The pair is armed in forward only when both saw the same buffer.
-_FORK_OPEN = {}     # data_ptr of x -> True, set by the "take" conv's forward, consumed by the "park" conv's forward
-_PRE_DX = {}        # data_ptr of x -> dx parked by the "park" conv's backward
+# The pair is matched in forward by x's address (x is alive there); in backward x may be gone and its address reused by another
+# chain's tensor, so the parked gradient travels under a token drawn in forward.
+_FORK_OPEN = {}     # data_ptr of x -> token, set by the "take" conv's forward, consumed by the "park" conv's forward
+_PRE_DX = {}        # token -> dx parked by the "park" conv's backward
+_FORK_TOKEN = [0]
 CONV_FORK = _os.environ.get("CVFT_CONV_FORK", "1") != "0"
 
 
@@ -1682,13 +1685,16 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, pack: ConvPack, B: int, Tin: int, Tout: int, in_len, out_len, fork=None):
         x = _c(x)
-        ctx.fork, ctx.xkey = None, x.data_ptr()
+        ctx.fork, ctx.token = None, None
         if CONV_FORK and fork is not None and not pack.transposed and pack.stride == 1 and ctx.needs_input_grad[0]:
             if fork == "take":
-                _FORK_OPEN[ctx.xkey] = True
-                ctx.fork = "take"
-            elif fork == "park" and _FORK_OPEN.pop(ctx.xkey, None):
-                ctx.fork = "park"
+                _FORK_TOKEN[0] += 1
+                ctx.fork, ctx.token = "take", _FORK_TOKEN[0]
+                _FORK_OPEN[x.data_ptr()] = ctx.token
+            elif fork == "park":
+                ctx.token = _FORK_OPEN.pop(x.data_ptr(), None)
+                if ctx.token is not None:
+                    ctx.fork = "park"
         pad = (pack.k - 1) // 2
         if not pack.transposed:
             taps = tuple(range(-pad, pad + 1))
@@ -1717,10 +1723,10 @@ class ConvFn(torch.autograd.Function):
         if not pack.transposed and pack.stride == 1:
             pad = (pack.k - 1) // 2
             # (the parked tensor carries the same row mask, so mask(dgrad + parked) == mask(dgrad) + parked)
-            parked = _PRE_DX.pop(ctx.xkey, None) if ctx.fork == "take" else None
+            parked = _PRE_DX.pop(ctx.token, None) if ctx.fork == "take" else None
             dx = gemm(dy, pack.Wb[0], geo=Geo(Tm=Tin, Tin=Tout, Tout=Tin, taps=tuple(range(-pad, pad + 1))), residual=parked, **kw)
             if ctx.fork == "park":
-                _PRE_DX[ctx.xkey] = dx
+                _PRE_DX[ctx.token] = dx
                 return None, (dy if ctx.needs_input_grad[1] else None), None, None, None, None, None, None, None
         elif not pack.transposed:
             dx = torch.empty((B * Tin, pack.Cin), dtype=dy.dtype, device=dy.device)
