@@ -86,8 +86,8 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(int rows, int C, const T* _
 // (x = residual + dropout(linear(.)), encoder_layer.py:95 / 104) hands to that linear -- its backward then needs no pass of its
 // own over dx (cvft_layernorm_bwd_mask).  The mask is cvft_dropout_add's: flat element index row * C + c, groups of 4.
 // SD (with MK): the linear in front carries a rank-16 adapter -- its backward starts with V = s * dxm B ([rows][16], lora.py:71-76),
-// a latency-bound launch of its own on the backward chain.  The wave that writes a row of dxm holds it in registers: it forms the
-// 16 dot products with B^T ([16][C], L2-resident) and reduces them with a halving butterfly (17 cross-lane moves for 16 sums).
+// a latency-bound launch of its own on the backward chain.  The wave that writes a row of dxm also leaves it in LDS (somrow) for
+// ln_bwd_side_kernel's matrix-core product.
 template <typename T, bool VP, bool MK = false, bool SD = false, int NCH = 4, bool RLT = true>
 __device__ __forceinline__ void ln_bwd_row(const int row, int C, const T* __restrict__ x,
                                            const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -95,8 +95,7 @@ __device__ __forceinline__ void ln_bwd_row(const int row, int C, const T* __rest
                                            int relu, float post, const T* __restrict__ dy,
                                            const T* __restrict__ dres, T* __restrict__ dx,
                                            float mp = 0.f, const long long* __restrict__ mseed = nullptr,
-                                           unsigned msite = 0, T* __restrict__ dxm = nullptr,
-                                           const T* sB = nullptr, float salpha = 0.f, T* __restrict__ sV = nullptr) {
+                                           unsigned msite = 0, T* __restrict__ dxm = nullptr, T* somrow = nullptr) {
     constexpr int VEC = 16 / sizeof(T);
     const int lane = threadIdx.x & 63;
     const T* xr = x + (size_t)row * C;
@@ -134,11 +133,6 @@ __device__ __forceinline__ void ln_bwd_row(const int row, int C, const T* __rest
         }
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
-        float sacc[16];
-        if (SD) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) sacc[j] = 0.f;
-        }
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             const int ch = lane + q * 64;
@@ -170,42 +164,9 @@ __device__ __forceinline__ void ln_bwd_row(const int row, int C, const T* __rest
                         for (int e = 0; e < 4; ++e) om[4 * gq + e] = kp[e] ? from_f32<T>(to_f32(o[4 * gq + e]) * inv) : from_f32<T>(0.f);
                     }
                     *reinterpret_cast<uint4*>(dxm + (size_t)row * C + ch * VEC) = *reinterpret_cast<uint4*>(om);
-                    if constexpr (SD) {      // bf16 pairs straight into v_dot2_f32_bf16 (no conversions): 4 per 16-byte chunk and rank
-                        typedef __attribute__((ext_vector_type(2))) __bf16 bfp_t;
-                        bfp_t op[4];
-                        __builtin_memcpy(op, om, 16);
-#pragma unroll
-                        for (int jh = 0; jh < 16; jh += 8) {
-                            uint4 rb[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) rb[j] = *reinterpret_cast<const uint4*>(sB + (size_t)(jh + j) * C + ch * VEC);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                bfp_t bp[4];
-                                __builtin_memcpy(bp, &rb[j], 16);
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) sacc[jh + j] = __builtin_amdgcn_fdot2_f32_bf16(op[k], bp[k], sacc[jh + j], false);
-                            }
-                        }
-                    }
+                    if constexpr (SD) *reinterpret_cast<uint4*>(somrow + ch * VEC) = *reinterpret_cast<uint4*>(om);      // the row, for the side product
                 }
             }
-        }
-        if (SD) {
-            // 16 sums over 64 lanes: each exchange halves the sums a lane carries; lane l ends with sum number
-            // 8 b5 + 4 b4 + 2 b3 + b2 (bits of l) over its group of four, folded by the last two exchanges
-            const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
-            float v8[8], v4[4], v2[2];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v8[j] = (b5 ? sacc[j + 8] : sacc[j]) + __shfl_xor(b5 ? sacc[j] : sacc[j + 8], 32);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v4[j] = (b4 ? v8[j + 4] : v8[j]) + __shfl_xor(b4 ? v8[j] : v8[j + 4], 16);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) v2[j] = (b3 ? v4[j + 2] : v4[j]) + __shfl_xor(b3 ? v4[j] : v4[j + 2], 8);
-            float v1 = (b2 ? v2[1] : v2[0]) + __shfl_xor(b2 ? v2[0] : v2[1], 4);
-            v1 += __shfl_xor(v1, 1);
-            v1 += __shfl_xor(v1, 2);
-            if ((lane & 3) == 0) sV[(size_t)row * 16 + (b5 ? 8 : 0) + (b4 ? 4 : 0) + (b3 ? 2 : 0) + (b2 ? 1 : 0)] = from_f32<T>(v1 * salpha);
         }
         return;
     }
@@ -246,9 +207,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(int rows, int C, const T* _
     ln_bwd_row<T, VP, MK, false, NCH, RL>(row, C, x, gamma, beta, mean, rstd, RL ? relu : 0, post, dy, dres, dx, mp, mseed, msite, dxm);
 }
 
-// The side-product form: B^T ([16][C] bf16, 32 KB at C = 1024) is staged in LDS once per block and every wave walks rows
-// blockIdx.x * 4 + w, + 4 * gridDim.x, ...: read straight from L2 it was 32 KB per ROW (170 MB per launch at 5 328 rows, as much
-// as the launch's own HBM traffic three times over, +7 us).
+// The side-product form.  B^T ([16][C] bf16) is staged in LDS once per workgroup (read straight from L2 it was 32 KB per ROW: 170 MB
+// per launch at 5 328 rows, +7 us); the workgroup walks groups of four rows (one per wave).  After the four waves have left their
+// masked rows in LDS, V[4][16] = rows . B^T is ONE 16x16x32 MFMA chain per wave over a quarter of C (rows 4..15 of the A operand
+// repeat rows 0..3 and are ignored), the four partial tiles meet in LDS.  (Each wave forming its own row's 16 dot products with
+// v_dot2_f32_bf16 read all of B^T from LDS per row: 2.5 / 5 us more than the plain kernel at 2 664 / 5 328 rows.)  Rows are padded
+// by 8 elements so the 16 rows of a B fragment read fall on different banks.
 template <int NCH>
 __global__ void __launch_bounds__(256) ln_bwd_side_kernel(int rows, int C, const bf16_t* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -258,12 +222,40 @@ __global__ void __launch_bounds__(256) ln_bwd_side_kernel(int rows, int C, const
                                                            unsigned msite, bf16_t* __restrict__ dxm, const bf16_t* __restrict__ sB,
                                                            float salpha, bf16_t* __restrict__ sV) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ln_smem[];
-    uint4* bl = reinterpret_cast<uint4*>(ln_smem);
-    for (int i = threadIdx.x; i < 2 * C; i += 256) bl[i] = reinterpret_cast<const uint4*>(sB)[i];      // 16 * C / 8 chunks
+    const int P = C + 8;                                           // LDS row pitch (elements)
+    bf16_t* Bl = reinterpret_cast<bf16_t*>(ln_smem);               // [16][P]
+    bf16_t* Om = Bl + 16 * P;                                      // [4][P]: this pass's masked rows
+    float* Pt = reinterpret_cast<float*>(Om + 4 * P);              // [4 waves][4 rows][16]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+    for (int i = tid; i < 2 * C; i += 256) {                       // 16 * C / 8 chunks
+        const int r = i / (C / 8), c = i % (C / 8);
+        *reinterpret_cast<uint4*>(Bl + r * P + c * 8) = reinterpret_cast<const uint4*>(sB)[i];
+    }
     __syncthreads();
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4)
-        ln_bwd_row<bf16_t, true, true, true, NCH, false>(row, C, x, gamma, beta, mean, rstd, 0, 1.f, dy, dres, dx, mp, mseed, msite, dxm,
-                                             reinterpret_cast<const bf16_t*>(ln_smem), salpha, sV);
+    const int groups = (rows + 3) >> 2, kq = C >> 2;               // k columns per wave
+    for (int g = blockIdx.x; g < groups; g += gridDim.x) {          // (workgroup-uniform: every wave meets every barrier)
+        const int row = g * 4 + w;
+        if (row < rows)
+            ln_bwd_row<bf16_t, true, true, true, NCH, false>(row, C, x, gamma, beta, mean, rstd, 0, 1.f, dy, dres, dx, mp, mseed, msite, dxm,
+                                                             Om + w * P);
+        __syncthreads();
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += 32) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Om + (l15 & 3) * P + k0 + kg * 8);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bl + l15 * P + k0 + kg * 8);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+        }
+        if (kg == 0) {                                             // D[m = 4 kg + i][n = l15]: rows 0..3
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Pt[(w * 4 + i) * 16 + l15] = acc[i];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int r = tid >> 4, j = tid & 15;
+            const float v = (Pt[(0 * 4 + r) * 16 + j] + Pt[(1 * 4 + r) * 16 + j]) + (Pt[(2 * 4 + r) * 16 + j] + Pt[(3 * 4 + r) * 16 + j]);
+            if (g * 4 + r < rows) sV[(size_t)(g * 4 + r) * 16 + j] = (bf16_t)(v * salpha);
+        }
+    }
 }
 
 template <typename T>
@@ -348,9 +340,12 @@ extern "C" int cvft_layernorm_bwd_mask_side(int rows, int C, const void* x, cons
     const bool ra = ((reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(dxm) | reinterpret_cast<uintptr_t>(Bt)) & 15) == 0;
     CVFT_CHECK_ARG(ra && ln_vec_ok<bf16_t>(C, x, dy, dx),
                    "cvft_layernorm_bwd_mask_side: needs the vector path (bf16, C % 8 == 0, C <= 2048, 16-byte aligned pointers)");
+    CVFT_CHECK_ARG(C % 128 == 0 && C <= 1536,
+                   "cvft_layernorm_bwd_mask_side: C must be a multiple of 128 (a quarter of the row per wave, 32 columns per MFMA) and <= 1536 (LDS)");
     if (rows == 0) return 0;
     const int groups = (rows + 3) / 4, per = (groups + 1023) / 1024;          // equal shares: no block walks one group more than another needs to
-#define LN_SIDE(NCHv) hipLaunchKernelGGL(ln_bwd_side_kernel<NCHv>, dim3((groups + per - 1) / per), dim3(256), (size_t)32 * C,            \
+    const size_t lds = (size_t)20 * (C + 8) * 2 + 4 * 4 * 16 * 4;             // B^T, four rows, four partial tiles
+#define LN_SIDE(NCHv) hipLaunchKernelGGL(ln_bwd_side_kernel<NCHv>, dim3((groups + per - 1) / per), dim3(256), lds,                       \
                                          (hipStream_t)stream, rows, C, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dy,    \
                                          (const bf16_t*)dres, (bf16_t*)dx, p, (const long long*)seed, site, (bf16_t*)dxm,              \
                                          (const bf16_t*)Bt, alpha, (bf16_t*)V)

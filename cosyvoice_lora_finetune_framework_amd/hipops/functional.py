@@ -381,9 +381,9 @@ _PRE_MASKED = {}    # data_ptr of the dx a LayerNormForkFn backward wrote -> (dx
 # When that linear carries a rank-16 adapter, side = (Bt, scale) and the same LayerNorm-backward launch can also form
 # V = scale * dxm Bt^T (cvft_layernorm_bwd_mask_side), the product the adapter's backward would open with as a launch of its own
 # (40 launches per LLM step and chain): parked under dxm's address until _lin_bwd asks for exactly (dxm, Bt, scale).
-# Opt-in (CVFT_LN_BWD_SIDE=1): per launch 9.7 / 17.4 us against 7.2 + 4.9 / 12.4 + 4.9 us for the two launches (2 664 / 5 328 rows,
-# tools/bench_ln_side.py) -- the 32 KB of B^T each row re-reads from LDS costs what the second launch did; same-box steps:
-# joint 21.94 / 22.01 (off) vs 22.02 / 21.99 (on), llm_only 13.14 vs 13.25 ms.
+# Opt-in (CVFT_LN_BWD_SIDE=1): per launch 9.0 / 16.5 us against 7.1 + 4.9 / 12.4 + 5.2 us for the two launches (2 664 / 5 328 rows,
+# tools/bench_ln_side.py; matrix-core form: four rows per workgroup pass against B^T in LDS) -- less kernel time and one launch
+# fewer, and still no faster in the step: same box, joint 21.48 / 21.54 (off) vs 21.55 / 21.57 (on), llm_only 13.49 vs 13.60 ms.
 _PRE_V = {}         # data_ptr of dxm -> (V, Bt data_ptr, scale)
 import os as _os  # noqa: E402
 LN_BWD_MASK = _os.environ.get("CVFT_LN_BWD_MASK", "1") != "0"
@@ -395,7 +395,7 @@ def _note_out_drop(y: torch.Tensor, od, side=None) -> None:
     if LN_BWD_MASK and od is not None:
         if not (LN_BWD_SIDE and side is not None and side[0] is not None and side[0].dtype == torch.bfloat16 and y.dtype == torch.bfloat16
                 and side[0].dim() == 2 and side[0].shape[0] == 16 and side[0].shape[1] == y.shape[1] and side[0].is_contiguous()
-                and side[0].data_ptr() % 16 == 0):
+                and side[0].data_ptr() % 16 == 0 and y.shape[1] % 128 == 0 and y.shape[1] <= 1536):
             side = None
         _ODROP_OUT[y.data_ptr()] = (float(od[0]), int(od[1]), side)
 

@@ -186,7 +186,7 @@ int cvft_layernorm_bwd_mask(int dtype, int rows, int C, const void* x, const flo
 /* cvft_layernorm_bwd_mask (bf16) for a linear that carries a rank-16 LoRA adapter (lora.py:64-76): the same launch also writes
  * V = alpha * dxm Bt^T  ([rows][16]; Bt = lora_B^T in the compute dtype, [16][C] row-major), the product that adapter's
  * backward starts with (dA = V^T drop(x), dx += V A) -- the wave that writes a row of dxm still holds it in registers.
- * R must be 16; vector path only as above. */
+ * R must be 16, C a multiple of 128 and at most 1536; vector path only as above. */
 int cvft_layernorm_bwd_mask_side(int rows, int C, const void* x, const float* gamma, const float* beta,
                                  const float* mean, const float* rstd, const void* dy, const void* dres, void* dx,
                                  float p, const int64_t* seed, unsigned site, void* dxm,
