@@ -50,12 +50,19 @@ __device__ __forceinline__ void lora_rank_body(int M, const RankProb& pr) {
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c0 = (blockIdx.x * 4 + wid) * 64;
-    if (c0 >= Cn) return;                            // whole wave (no barriers in this kernel)
-    const int mb = blockIdx.y * rows_per_block;
-    if (mb >= M) return;                             // the grid is sized for the problem with more slabs / columns
-    const int me = min(M, mb + rows_per_block);
-    const int nchunk = (me - mb + 31) >> 5;
+    // rows_per_block % 128 == 0 ("stacked"): the four waves share ONE 64-column stripe and each walks a quarter of the slab's rows;
+    // their four partial tiles meet in LDS and leave as one.  Same number of waves and chunks per wave as four stripes over a
+    // quarter of the rows, a quarter of the slabs to write and to reduce (the LLM's adapter products were 42 slabs each,
+    // ~0.8 GB of slab traffic per step each way and a 215 us reduce on the step's serial tail).
+    const bool stacked = (rows_per_block & 127) == 0;
+    const int c0 = stacked ? blockIdx.x * 64 : (blockIdx.x * 4 + wid) * 64;
+    if (c0 >= Cn) return;                            // not stacked: whole wave, no barriers; stacked: whole workgroup
+    const int mb0 = blockIdx.y * rows_per_block;
+    if (mb0 >= M) return;                            // the grid is sized for the problem with more slabs / columns
+    const int me0 = min(M, mb0 + rows_per_block);
+    const int mb = stacked ? mb0 + wid * (rows_per_block >> 2) : mb0;
+    const int me = stacked ? min(me0, mb + (rows_per_block >> 2)) : me0;
+    const int nchunk = max(0, (me - mb + 31) >> 5);
     unsigned char* my = smem + wid * 2 * BUF;
 
     // DMA source of the wide operand: lane -> (row i*8 + lane/8, slot lane%8); slot s of row r holds global chunk
@@ -116,8 +123,10 @@ __device__ __forceinline__ void lora_rank_body(int M, const RankProb& pr) {
     }
     const int a_lo = WD_BYTES + rlo * (R * 2) + pp * 8, a_hi = WD_BYTES + rhi * (R * 2) + pp * 8;
 
-    issue(0, 0);
-    load_rk(0);
+    if (nchunk > 0) {                                          // (stacked: a wave whose quarter starts past M only joins the reduction)
+        issue(0, 0);
+        load_rk(0);
+    }
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk c: DMA landed, Rk registers arrived
@@ -143,6 +152,31 @@ __device__ __forceinline__ void lora_rank_body(int M, const RankProb& pr) {
     // acc[jb][nt][i] = slab[j = jb*16 + kg*4 + i][c = c0 + nt*16 + (lane & 15)]
     float* base = out + (size_t)blockIdx.y * part_stride;
     const int l15 = lane & 15;
+    if (stacked) {
+        // partial tiles into the wave's own staging region (RB * 4 KB <= 2 * BUF), then wave w sums and stores column tile nt = w
+        f32x4* red = reinterpret_cast<f32x4*>(my);
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) red[(jb * 4 + nt) * 64 + lane] = acc[jb][nt];
+        __syncthreads();
+        const int cl = c0 + wid * 16 + l15;
+#pragma unroll
+        for (int jb = 0; jb < RB; ++jb) {
+            f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) sacc += reinterpret_cast<const f32x4*>(smem + ww * 2 * BUF)[(jb * 4 + wid) * 64 + lane];
+            if (cl >= Cn) continue;
+            const int j = jb * 16 + kg * 4;
+            if (transpose_out) {
+                *reinterpret_cast<float4*>(&base[(size_t)cl * ldo + j]) = make_float4(sacc[0], sacc[1], sacc[2], sacc[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) base[(size_t)(j + i) * ldo + cl] = sacc[i];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int jb = 0; jb < RB; ++jb)
 #pragma unroll
@@ -199,7 +233,7 @@ static RankProb make_prob(int Cn, int r, const void* Wd, int ldw, const void* Rk
 static void rank_launch(int M, int r, const RankPair& pp, int nprob, hipStream_t st) {
     int gx = 0, gy = 0;
     for (int i = 0; i < nprob; ++i) {
-        gx = max(gx, (pp.p[i].Cn + 255) / 256);
+        gx = max(gx, pp.p[i].rows_per_block % 128 == 0 ? (pp.p[i].Cn + 63) / 64 : (pp.p[i].Cn + 255) / 256);
         gy = max(gy, (M + pp.p[i].rows_per_block - 1) / pp.p[i].rows_per_block);
     }
     dim3 grid(gx, gy, nprob);
@@ -283,7 +317,7 @@ extern "C" int cvft_lora_rank_partial_batch(int r, int n, const cvft_rank_prob_m
             e.Wd = (const bf16_t*)q.Wd; e.Rk = (const bf16_t*)q.Rk; e.out = q.part; e.M = q.M; e.Cn = q.C; e.ldw = q.ldw; e.ldr = q.ldr;
             e.rows_per_block = q.rows_per_block; e.transpose_out = q.transpose_out;
             if (i < nb) {
-                gx = max(gx, (q.C + 255) / 256);
+                gx = max(gx, q.rows_per_block % 128 == 0 ? (q.C + 63) / 64 : (q.C + 255) / 256);
                 gy = max(gy, (q.M + q.rows_per_block - 1) / q.rows_per_block);
             }
         }

@@ -636,8 +636,10 @@ class LoraGradSink:
         slabs that still give >= 512 blocks (long row loops per block amortise the cross-wave reduction)."""
         colblocks = -(-Cn // 64)
         rpb = 64
-        for cand in (128, 256, 512, 768, 1024, 2048):
-            if colblocks * (-(-M // cand)) >= SINK_PLAN_BLOCKS:
+        # slabs of a multiple of 128 rows run "stacked" (csrc/lora_grad.hip): four waves per 64-column stripe, each on a quarter
+        # of the slab's rows -- four wave stripes per slab and column block
+        for cand in (128, 256, 512, 768, 1024, 2048, 4096):
+            if colblocks * SINK_STACK * (-(-M // cand)) >= SINK_PLAN_BLOCKS:
                 rpb = cand
         return rpb, -(-M // rpb)
 
@@ -822,10 +824,11 @@ STACKED_DROP_DEFER = _os.environ.get('CVFT_STACKED_DROP_DEFER', '1') != '0'
 KEEP_DROPPED = _os.environ.get('CVFT_KEEP_DROPPED', '1') != '0'   # forward writes drop(x) for the backward's dA (no re-derivation launch)
 LN_SKINNY = _os.environ.get('CVFT_LN_SKINNY', '1') != '0'    # LayerNorm launch also emits the dropped rank-side product of the adapter it feeds
 XDROP_ON = _os.environ.get('CVFT_XDROP', '1') != '0'        # lora_dropout dgrad: masked rank extension inside the GEMM launch
-SINK_PLAN_BLOCKS = int(_os.environ.get('CVFT_SINK_PLAN_BLOCKS', 512))     # wave stripes per launch; round 3, same-box: 256 -> 22.75 / 22.69 / 22.79, 512 -> 22.45 / 22.52 / 22.50, 1024 -> 22.33-22.38 vs 22.29-22.34 (round 2 had 256 best by 0.2 ms)
+SINK_PLAN_BLOCKS = int(_os.environ.get('CVFT_SINK_PLAN_BLOCKS', 768))     # wave stripes per launch; with the stacked slab kernel (four waves per stripe and slab), same box: 512 -> 21.57, 768 -> 21.45 / 21.45, 1024 -> 21.56, 1536 -> 21.61 ms (the kernel before it: 21.70; round 3 had 512 best of 256 / 512 / 1024 for one wave per stripe, round 2 256)
+SINK_STACK = int(_os.environ.get('CVFT_SINK_STACK', 4))       # wave stripes the planner counts per slab and column block (1: plan as before the stacked kernel)
 SINK_DEFER = _os.environ.get('CVFT_SINK_DEFER', '1') != '0'
 SINK_DEFER_MAX = int(_os.environ.get('CVFT_SINK_DEFER_MAX', 12_000_000))      # x.numel() + dY.numel(): the flow branch's layers
-SINK_DEFER_RPB = int(_os.environ.get('CVFT_SINK_DEFER_RPB', 256))
+SINK_DEFER_RPB = int(_os.environ.get('CVFT_SINK_DEFER_RPB', 1024))     # stacked: 256 rows per wave as before, a quarter of the slabs (256 / 512 / 1024 / 2048: 22.04 / 21.81 / 21.80 / 21.20 vs 21.14 on a second box)
 SINK_DEFER_EARLY = _os.environ.get('CVFT_SINK_DEFER_EARLY', '1') != '0'     # full batches leave during backward on their chain's stream
 SINK_EARLY_BATCH = int(_os.environ.get('CVFT_SINK_EARLY_BATCH', 24))       # (= CVFT_RANK_BATCH, one launch)
 FUSE_MAX_MN = int(_os.environ.get('CVFT_FUSE_MAX_MN', 3_000_000))   # measured (tools/bench_fused.py): the in-launch side path wins for the small estimator GEMMs only

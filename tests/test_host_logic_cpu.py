@@ -275,8 +275,8 @@ def test_slab_plans_are_legal_for_the_rank_kernels():
         for Cn in (64, 256, 768, 1024, 4096):
             rpb, ns = HF.LoraGradSink.plan(M, Cn)
             assert rpb % 32 == 0 and ns * rpb >= M > (ns - 1) * rpb
-            if rpb > 64:
-                assert -(-Cn // 64) * ns >= HF.SINK_PLAN_BLOCKS
+            if rpb > 64:      # slabs of k * 128 rows run four waves per 64-column stripe (the stacked form of the slab kernel)
+                assert rpb % 128 == 0 and -(-Cn // 64) * HF.SINK_STACK * ns >= HF.SINK_PLAN_BLOCKS
         rpb, ns = HF.LoraGradSink.plan_deferred(M)
         assert rpb % 32 == 0 and ns * rpb >= M > (ns - 1) * rpb
 

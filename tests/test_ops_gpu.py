@@ -1380,10 +1380,13 @@ def test_fp8_linear_path_close_to_bf16():
     assert rel(outs[1][0], outs[0][0]) > 1e-4            # and it really ran in different arithmetic
 
 
+@pytest.mark.parametrize("rpb", [64, 256, 1024])
 @pytest.mark.parametrize("r", [16, 48])
-def test_lora_rank_partial_batch_matches_torch(r):
+def test_lora_rank_partial_batch_matches_torch(r, rpb):
     """cvft_lora_rank_partial_batch: slab products of MANY layers (each its own row count / width / orientation) in one
-    launch (70 problems -> two launches of <= 64), summed over their slabs and compared with torch."""
+    launch (70 problems -> two launches of <= 64), summed over their slabs and compared with torch.  rpb 64: one wave per
+    64-column stripe and slab; 256 / 1024 (multiples of 128): the stacked form, four waves per stripe on a quarter of the slab's
+    rows each -- including slabs shorter than a quarter (M = 64: three waves only join the reduction) and ragged last slabs."""
     import ctypes
     from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
     HF = HFmod()
@@ -1394,7 +1397,6 @@ def test_lora_rank_partial_batch_matches_torch(r):
     for e, (M, Cn, tr) in zip(arr, shapes):
         Wd = torch.randn(M, Cn, generator=g).to(DEV, torch.bfloat16)
         Rk = torch.randn(M, r, generator=g).to(DEV, torch.bfloat16)
-        rpb = 256
         ns = -(-M // rpb)
         ws = torch.zeros(ns * r * Cn, dtype=torch.float32, device=DEV)
         e.M, e.C, e.Wd, e.ldw, e.Rk, e.ldr, e.part, e.transpose_out, e.rows_per_block = M, Cn, Wd.data_ptr(), Cn, Rk.data_ptr(), r, ws.data_ptr(), tr, rpb
