@@ -150,7 +150,15 @@ def test_replay_of_small_layout_after_larger_layout_replaced_workspaces(tiny_met
     large = synth_batch([160, 150], text_lens=[9, 8], token_lens=[80, 75], seed=2, text_vocab=100, speech_vocab=50)
     seq = [small, large, small, large, small]
     dfn = lambda ep, bi, b: cfm_draws(2, b["speech_feat"].shape[1], 7)
-    tr, grads = _fit(jm, seq, dfn, train_mode=False, use_graph=True)
+    # slabs of 64 rows for the postponed products, so that the 320-row layout needs more of them than the 40-row one (the
+    # default, 1024 rows per slab, gives both layouts one slab and nothing to replace)
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    rpb_default = HF.SINK_DEFER_RPB
+    HF.SINK_DEFER_RPB = 64
+    try:
+        tr, grads = _fit(jm, seq, dfn, train_mode=False, use_graph=True)
+    finally:
+        HF.SINK_DEFER_RPB = rpb_default
     assert tr.graph_stats["captures"] == 2 and tr.graph_stats["replays"] == 5 and tr.graph_stats["eager"] == 0, tr.graph_stats
     retired = sum(len(getattr(p, "_cvft_part_retired", [])) for p in jm.parameters())
     assert retired > 0, "the larger layout was expected to replace slab workspaces"
