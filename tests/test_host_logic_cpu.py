@@ -281,6 +281,32 @@ def test_slab_plans_are_legal_for_the_rank_kernels():
         assert rpb % 32 == 0 and ns * rpb >= M > (ns - 1) * rpb
 
 
+def test_loss_recombination_forms_agree():
+    """The launch-saving recombination of the branch losses (llm_flow_model._scaled / _total, train_joint._weighted_total:
+    unit factors skipped, no `0 + x`, one dot for the weighted sum) against the plain op-per-factor form: same value, same
+    gradients, for one and two loss terms and with gradient accumulation."""
+    from cosyvoice_lora_finetune_framework_amd import llm_flow_model as J
+    from cosyvoice_lora_finetune_framework_amd import train_joint as TJ
+    default = J.LOSS_FUSE
+    try:
+        for keys, accum in ((("llm", "flow"), 1), (("llm", "flow"), 4), (("flow",), 1), (("llm",), 2)):
+            out = {}
+            for fuse in (True, False):
+                J.LOSS_FUSE = fuse
+                leaves = {k: torch.tensor(1.5 + i, requires_grad=True) for i, k in enumerate(keys)}
+                parts = {k: J._scaled(J._total([J._scaled(v * 0.25, 1.0), J._scaled(v * 0.75, torch.tensor(1.0))]), 2.0 if k == "llm" else 1)
+                         for k, v in leaves.items()}
+                w = torch.tensor([0.5, 1.25])
+                total = TJ._weighted_total({f"{k}_loss": v for k, v in parts.items()}, keys, w, accum)
+                total.backward()
+                out[fuse] = (total.detach(), [leaves[k].grad.clone() for k in keys])
+            assert torch.allclose(out[True][0], out[False][0], rtol=1e-6)
+            for a, b in zip(out[True][1], out[False][1]):
+                assert torch.allclose(a, b, rtol=1e-6)
+    finally:
+        J.LOSS_FUSE = default
+
+
 def test_shard_sampler_reshuffles_per_epoch_and_ranks_stay_disjoint():
     """Trainer.fit calls sampler.set_epoch(epoch); every epoch is a new common shuffle, the ranks' shards are
     disjoint and together cover whole global batches only."""
