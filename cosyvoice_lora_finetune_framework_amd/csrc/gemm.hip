@@ -353,7 +353,7 @@ static int gemm_launch(const cvft_gemm_args* a, hipStream_t st) {
     p.bytesL = 0;
     p.xdrop_p = a->xdrop_p; p.xdrop_seed = (const long long*)a->xdrop_seed;
     for (int i = 0; i < 4; ++i) p.xdrop_sites[i] = a->xdrop_sites[i];
-    p.odrop_p = a->odrop_p; p.odrop_site = a->odrop_site;
+    p.odrop_p = a->odrop_p; p.odrop_site = a->odrop_site; p.row_off = 0;
     if (p.odrop_p > 0.f) {
         if (!p.xdrop_seed || !cvft_drop_rate_ok(p.odrop_p) || p.N % 4 != 0 || p.ldc != p.N || p.Tm != p.M || p.out_stride != 1 || p.out_off != 0 || p.Tout != p.Tm) {
             cvft_set_error("cvft_gemm: output dropout needs a seed, 2^-16 <= p <= 1 - 2^-16, N %% 4 == 0, ldc == N and identity row geometry");

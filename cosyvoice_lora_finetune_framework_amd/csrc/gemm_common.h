@@ -38,6 +38,8 @@ struct GP {
     int xcd_nsplit;               // LDS-DMA kernels: XCDs across N (1 = linear tile ranges; 2/4/8 = rectangles, see kernel)
     float xdrop_p; const long long* xdrop_seed; unsigned xdrop_sites[4];      // masked rank extension (cvft.h); 0 = off
     float odrop_p; unsigned odrop_site;     // output dropout (cvft.h): C = residual + keep / (1 - p) * epi(.), seed = xdrop_seed; 0 = off
+    int row_off;                  // rows in front of this launch's row 0 in the tensor the dropout masks index (a launch that computes a
+                                  // row range of a larger product: gemm_p256_launch's row split); 0 otherwise
 };
 
 // keep / (1 - p) factors of the output-dropout mask for the 4-element group holding flat output element `idx` (idx % 4 == 0)
@@ -103,7 +105,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GP<T>& p, const float*
             }
             if (p.odrop_p > 0.f) {
 #pragma unroll
-                for (int e = 0; e < VEC; e += 4) gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, orow * (unsigned long long)p.N + nb + e, v + e);
+                for (int e = 0; e < VEC; e += 4) gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, (orow + p.row_off) * (unsigned long long)p.N + nb + e, v + e);
             }
             if (p.residual) {
                 uint4 rv = *reinterpret_cast<const uint4*>(&p.residual[orow * p.ldr + nb]);
@@ -124,7 +126,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GP<T>& p, const float*
                 x = act_apply(p.act, x);
                 if (p.dact_src) x *= act_grad(p.dact, to_f32(p.dact_src[orow * p.ldd + n]));
                 if (p.odrop_p > 0.f) {
-                    const unsigned long long idx = orow * (unsigned long long)p.N + n;
+                    const unsigned long long idx = (orow + p.row_off) * (unsigned long long)p.N + n;
                     bool k4[4];
                     cvft_keep4(cvft_drop_key(p.xdrop_seed, p.odrop_site), idx >> 2, cvft_drop_thr(p.odrop_p), k4);
                     x = k4[idx & 3] ? x / (1.f - p.odrop_p) : 0.f;
@@ -167,7 +169,7 @@ __device__ __forceinline__ void gemm_epilogue_direct4(const GP<bf16_t>& p, const
         float ds[4] = {(float)d[0], (float)d[1], (float)d[2], (float)d[3]};
         act_grad_mul_vec<4>(p.dact, v, ds);
     }
-    if (p.odrop_p > 0.f) gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, orow * (unsigned long long)p.N + n, v);
+    if (p.odrop_p > 0.f) gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, (orow + p.row_off) * (unsigned long long)p.N + n, v);
     if (p.residual) {
         const bf16x4 r = *reinterpret_cast<const bf16x4*>(&p.residual[orow * p.ldr + n]);
 #pragma unroll
@@ -214,8 +216,8 @@ __device__ __forceinline__ void gemm_epilogue_direct8(const GP<bf16_t>& p, const
         act_grad_mul_vec<8>(p.dact, v, ds);
     }
     if (p.odrop_p > 0.f) {
-        gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, orow * (unsigned long long)p.N + n, v);
-        gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, orow * (unsigned long long)p.N + n + 4, v + 4);
+        gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, (orow + p.row_off) * (unsigned long long)p.N + n, v);
+        gemm_odrop4(p.odrop_p, p.xdrop_seed, p.odrop_site, (orow + p.row_off) * (unsigned long long)p.N + n + 4, v + 4);
     }
     if (p.residual) {
         const bf16x8 r = *reinterpret_cast<const bf16x8*>(&p.residual[orow * p.ldr + n]);
@@ -228,7 +230,45 @@ __device__ __forceinline__ void gemm_epilogue_direct8(const GP<bf16_t>& p, const
     *reinterpret_cast<bf16x8*>(&p.C[orow * p.ldc + n]) = o;
 }
 
+// ---------------------------------------------------------------- shared by the LDS-DMA kernels (gemm_glds.hip, gemm_p256.hip)
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// register epilogue (gemm_epilogue_direct4) is legal: 8-byte aligned bf16 rows everywhere, 16-byte aligned bias
+__host__ __device__ inline bool glds_direct_epilogue(const GP<bf16_t>& p) {
+    return p.direct_epi && (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 7) == 0) &&
+           (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
+           (!p.preact || ((p.ldp % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.preact) & 7) == 0))) &&
+           (!p.dact_src || ((p.ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.dact_src) & 7) == 0))) &&
+           (!p.residual || ((p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 7) == 0)));
+}
+
+// register epilogue in its 8-wide form (gemm_epilogue_direct8): 16-byte aligned rows and bias
+__host__ __device__ inline bool glds_wide_epilogue(const GP<bf16_t>& p) {
+    return (p.N % 8 == 0) && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+           (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
+           (!p.preact || ((p.ldp % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.preact) & 15) == 0))) &&
+           (!p.dact_src || ((p.ldd % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.dact_src) & 15) == 0))) &&
+           (!p.residual || ((p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
+}
+
+// Column map of the W image.  The MFMA is issued with swapped operands, so lane (kg, l15) of output tile j owns row
+// l15 and the four n-slots 4*kg .. 4*kg+3 of that tile.  Slot s of tile j is NOT column 16*j + s: it is
+//     col(j, s) = 32*(j >> 1) + 8*(s >> 2) + 4*(j & 1) + (s & 3)
+// so that the lane's accumulators of the tile pair (j, j+1) are the 8 consecutive columns 32*(j>>1) + 8*kg .. +7: the
+// epilogue moves 16 bytes per lane and the 4 kg-lanes of a row cover 64 contiguous bytes.  Only the W side knows: the
+// fragment of tile j reads image rows col(j, 0..15) (four runs of 4 rows, 8 apart), and the source-side XOR of the W
+// image is wswz(r) = bit1(r) | bits3..4(r) << 1, which keeps those reads bank-conflict free (the A image keeps
+// (r >> 1) & 7 for its 16 consecutive rows).
+__host__ __device__ constexpr int glds_col(int j, int s) { return 32 * (j >> 1) + 8 * (s >> 2) + 4 * (j & 1) + (s & 3); }
+__host__ __device__ constexpr int glds_wswz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+
 // LDS-DMA (global_load_lds) bf16 kernels for identity-geometry GEMMs; returns 1 when the shape is not eligible.
 int gemm_glds_launch(const GP<bf16_t>& p, hipStream_t st, int cfg);
 // rank-side products C[M, R<=64] = alpha * A W^T without epilogue (skinny.hip); returns 1 when not eligible.
 int skinny_launch(const GP<bf16_t>& p, hipStream_t st);
+// 256x256 tile, 8 waves, 8-phase LDS-DMA pipeline for the LLM-sized launches (gemm_p256.hip); returns 1 when not eligible.
+int gemm_p256_launch(const GP<bf16_t>& p, hipStream_t st);

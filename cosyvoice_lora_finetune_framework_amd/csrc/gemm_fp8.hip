@@ -238,7 +238,7 @@ extern "C" int cvft_gemm_fp8(const cvft_gemm_args* a, const void* A8, int lda8, 
     p.La = nullptr; p.ldla = 0; p.lora_scale = 0.f; p.Uout = nullptr; p.fuse = 0; p.direct_epi = 1; p.xcd_nsplit = 1;
     p.bytesA = p.bytesW = p.bytesU = p.bytesB = p.bytesL = 0;
     p.vecA = p.vecW = 1; p.vecU = p.vecB = 1;
-    p.xdrop_p = 0.f; p.xdrop_seed = (const long long*)a->xdrop_seed; p.odrop_p = a->odrop_p; p.odrop_site = a->odrop_site;
+    p.xdrop_p = 0.f; p.xdrop_seed = (const long long*)a->xdrop_seed; p.odrop_p = a->odrop_p; p.odrop_site = a->odrop_site; p.row_off = 0;
     CVFT_CHECK_ARG(p.odrop_p <= 0.f || (p.xdrop_seed && cvft_drop_rate_ok(p.odrop_p) && p.ldc == p.N), "cvft_gemm_fp8: output dropout needs a seed, p < 1 and ldc == N");
     for (int i = 0; i < 4; ++i) p.xdrop_sites[i] = 0;
     if (p.R > 0)

@@ -16,8 +16,6 @@
 #include <stdlib.h>
 #include "gemm_common.h"
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
 
 // RT > 0 (fused side path): U = lora_scale * A . La^T  (La [R <= 16*RT][K]) is produced inside the launch: the La k-tile
 // rides along as 16*RT more DMA rows, the wn == 0 waves run RT extra MFMAs per A fragment, the bf16 result goes through
@@ -25,37 +23,6 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // NS = LDS stages: tiles kt+1 .. kt+NS-1 are in flight while tile kt feeds the MFMAs (counted s_waitcnt vmcnt, raw
 // s_barrier -- __syncthreads() would drain the DMA queue).  These GEMMs are small (1-4 blocks per CU, 4-16 k-tiles):
 // with one tile of lookahead every k-tile cost a full memory round trip (~0.9 us measured in the training step).
-// register epilogue (gemm_epilogue_direct4) is legal: 8-byte aligned bf16 rows everywhere, 16-byte aligned bias
-__host__ __device__ inline bool glds_direct_epilogue(const GP<bf16_t>& p) {
-    return p.direct_epi && (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 7) == 0) &&
-           (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
-           (!p.preact || ((p.ldp % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.preact) & 7) == 0))) &&
-           (!p.dact_src || ((p.ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.dact_src) & 7) == 0))) &&
-           (!p.residual || ((p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 7) == 0)));
-}
-
-// register epilogue in its 8-wide form (gemm_epilogue_direct8): 16-byte aligned rows and bias
-__host__ __device__ inline bool glds_wide_epilogue(const GP<bf16_t>& p) {
-    return (p.N % 8 == 0) && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
-           (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
-           (!p.preact || ((p.ldp % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.preact) & 15) == 0))) &&
-           (!p.dact_src || ((p.ldd % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.dact_src) & 15) == 0))) &&
-           (!p.residual || ((p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
-}
-
-// Column map of the W image.  The MFMA is issued with swapped operands, so lane (kg, l15) of output tile j owns row
-// l15 and the four n-slots 4*kg .. 4*kg+3 of that tile.  Slot s of tile j is NOT column 16*j + s: it is
-//     col(j, s) = 32*(j >> 1) + 8*(s >> 2) + 4*(j & 1) + (s & 3)
-// so that the lane's accumulators of the tile pair (j, j+1) are the 8 consecutive columns 32*(j>>1) + 8*kg .. +7: the
-// epilogue moves 16 bytes per lane and the 4 kg-lanes of a row cover 64 contiguous bytes.  Only the W side knows: the
-// fragment of tile j reads image rows col(j, 0..15) (four runs of 4 rows, 8 apart), and the source-side XOR of the W
-// image is wswz(r) = bit1(r) | bits3..4(r) << 1, which keeps those reads bank-conflict free (the A image keeps
-// (r >> 1) & 7 for its 16 consecutive rows).
-__host__ __device__ constexpr int glds_col(int j, int s) { return 32 * (j >> 1) + 8 * (s >> 2) + 4 * (j & 1) + (s & 3); }
-__host__ __device__ constexpr int glds_wswz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 __device__ unsigned long long cvft_glds_stamps[2 * 16 * 8];      // diagnostics (CVFT_GLDS_STAMP=1, tools/glds_stamps.py)
 
 template <int BM, int BN, int WM, int WN, int RT, int NS, bool DE, bool STAMP = false, bool DX = false>
@@ -347,7 +314,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_glds_kernel(GP<bf16_t> p) {
                 const unsigned long long key = cvft_drop_key(p.xdrop_seed, p.xdrop_sites[t]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    const unsigned long long m = (unsigned long long)min(m0 + wm * TM + i * 16 + l15, p.M - 1);
+                    const unsigned long long m = (unsigned long long)(min(m0 + wm * TM + i * 16 + l15, p.M - 1) + p.row_off);
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
                         f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -473,8 +440,12 @@ static int glds_launch_cfg(const GP<bf16_t>& p, hipStream_t st) {
 }
 
 // Returns 1 when the launch is not eligible (the caller falls back to gemm.hip's register-staged kernel).
-int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int /*cfg*/) {
+int gemm_glds_launch(const GP<bf16_t>& p_in, hipStream_t st, int cfg) {
     static const int direct_mode = getenv("CVFT_GLDS_DIRECT") ? atoi(getenv("CVFT_GLDS_DIRECT")) : 2;   // 0 off, 1 only plain epilogues, 2 whenever legal
+    if (cfg != -256) {   // LLM-sized launches: 256x256 tile on the 8-phase pipeline (gemm_p256.hip; -256 = its own remainder launch)
+        const int rc = gemm_p256_launch(p_in, st);
+        if (rc != 1) return rc;
+    }
     GP<bf16_t> p = p_in;
     const bool simple = !p.preact && !p.dact_src && !p.residual;
     p.direct_epi = direct_mode == 2 || (direct_mode == 1 && simple);
