@@ -58,6 +58,21 @@ def step_record(workload, frames, utt_per_s_per_gpu, dtype):
     return {"tflops": tf, "frac_of_mfma_peak": tf / peak, "gflop_per_utt": gf, "peak_tflops": peak}
 
 
+def _build_id():
+    from cosyvoice_lora_finetune_framework_amd.build_id import csrc_sha16
+    return csrc_sha16()
+
+
+def _stale(d, path):
+    """None when the profile record `d` was written from the kernel sources this process runs (its `csrc_sha16` equals
+    build_id.csrc_sha16()); else the reason the bench line prints instead of the figure."""
+    have, want = d.get("csrc_sha16"), _build_id()
+    if have == want:
+        return None
+    return (f"{os.path.join('profiles', os.path.basename(path))} was recorded on kernel sources {have or '(no identity recorded)'}, "
+            f"this build is {want}: rerun tools/refresh_profiles.sh")
+
+
 def trace_summary(workload, batch, frames):
     """launches and kernel time per step of this configuration from the committed rocprofv3 kernel trace of the same command
     (profiles/*step_summary.json, written by tools/prof_summary.py; the trace cannot be taken inside the bench process)"""
@@ -68,6 +83,9 @@ def trace_summary(workload, batch, frames):
         except Exception:
             continue
         if d.get("workload") == workload and d.get("batch") == batch and d.get("frames") == frames:
+            why = _stale(d, f)
+            if why:
+                return {"launches_per_step": None, "kernel_ms_per_step": None, "source": None, "not_quoted": why}
             return {"launches_per_step": d["launches_per_step"], "kernel_ms_per_step": d["kernel_ms_per_step"],
                     "source": os.path.join("profiles", os.path.basename(f))}
     return None
@@ -157,9 +175,27 @@ def cpu_baseline(jm, workload, T, seconds_budget=30.0):
     for _ in range(n):
         one()
     dt_ = (time.time() - t0) / n
-    return {"value": B / dt_, "unit": "utterances/s", "cores": cores, "kind": "port",
+    return {"value": B / dt_, "unit": "utterances/s", "cores": cores, "kind": "port", "reference_modules": reference_modules_record(),
             "sample": f"{n} fwd+bwd steps of {B} utterance(s) ({T}-frame mel, {workload}), torch fp32 CPU oracle "
                       f"(oracle/ref_math.py), same random-init weights, no dropout; optimiser step excluded (negligible)"}
+
+
+def reference_modules_record():
+    """The reference's OWN modules timed on the CPU (it cannot travel to the GPU box): the newest committed
+    profiles/r*_cpu_reference_timing.json (tools/cpu_reference_timing.py, build container), quoted beside the port's figure with
+    its own host and core count -- a different host than `cpu_baseline.value`'s, so context, not a ratio."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*cpu_reference_timing.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            return {"value": d["reference"]["utt_per_s"], "unit": "utterances/s", "cores": d["cores"], "cpu": d.get("cpu"),
+                    "s_per_step": d["reference"]["s_per_step"], "batch": d["batch"], "frames": d["frames"], "mode": d.get("mode"),
+                    "includes": d["reference"].get("includes"), "port_on_that_host_utt_per_s": d.get("oracle_port", {}).get("utt_per_s"),
+                    "source": os.path.join("profiles", os.path.basename(f)),
+                    "note": "measured in the build container, not on this run's host"}
+        except Exception:
+            continue
+    return None
 
 
 def pmc_traffic(kernel: str):
@@ -173,6 +209,9 @@ def pmc_traffic(kernel: str):
         except Exception:
             continue
         if d.get("kernel") == kernel:
+            why = _stale(d, f)
+            if why:
+                return None, "not quoted: " + why
             return d["traffic_bytes_per_launch"], os.path.join("profiles", os.path.basename(f))
     return None, None
 
@@ -184,17 +223,24 @@ def pmc_mfma_busy(kernel: str):
     import glob
     import re
     m = re.match(r"gemm_glds_kernel<bf16,(\d+),(\d+),(\d+),(\d+),ns(\d+)", kernel)
-    if not m:
+    if m:
+        bm, bn, wm, wn, ns = m.groups()
+        key = f"gemm_glds<{bm}ELi{bn}ELi{wm}ELi{wn}ELi0ELi{ns}E"
+    elif kernel.startswith("gemm_p256_kernel"):
+        key = "gemm_p256"
+    else:
         return None, None
-    bm, bn, wm, wn, ns = m.groups()
-    key = f"gemm_glds<{bm}ELi{bn}ELi{wm}ELi{wn}ELi0ELi{ns}E"
     for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*counters.json")), reverse=True):
         try:
-            ks = json.load(open(f))["kernels"]
+            doc = json.load(open(f))
+            ks = doc["kernels"]
         except Exception:
             continue
         hit = [v for k, v in ks.items() if k.startswith(key)]
         if hit:
+            why = _stale(doc, f)
+            if why:
+                return None, "not quoted: " + why
             n = sum(v["launches_sampled"] for v in hit)
             return sum(v["mfma_busy"] * v["launches_sampled"] for v in hit) / n, os.path.join("profiles", os.path.basename(f))
     return None, None

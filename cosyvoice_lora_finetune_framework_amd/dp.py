@@ -25,8 +25,16 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         local = 0
     if world > 1 and not dist.is_initialized():
         # this rank's share of the host first: the threads the process group and torch create inherit it
-        lw = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        host_budget(int(os.environ.get("LOCAL_RANK", "0")) % max(lw, 1), lw)
+        # local world: LOCAL_WORLD_SIZE, else the node's GPU count capped by the world (device_count does not initialise
+        # the GPU on this stack); the share is only taken when this rank's place on the node is known (LOCAL_RANK set):
+        # a rank-only launcher would otherwise pin every rank to slice 0
+        if "LOCAL_WORLD_SIZE" in os.environ:
+            lw = int(os.environ["LOCAL_WORLD_SIZE"])
+        else:
+            ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            lw = min(world, ndev) if ndev > 0 else world
+        if "LOCAL_RANK" in os.environ:
+            host_budget(local % max(lw, 1), lw)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -95,6 +103,31 @@ def loss_weights(local_denoms: Dict[str, float], device) -> Dict[str, float | to
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     w = t * world_size() / tot.clamp_min(1e-12)
     return {k: w[i] for i, k in enumerate(keys)}
+
+
+class DenomExchange:
+    """The loss-denominator exchange of `loss_weights`, taken OFF the step's critical path: the trainer's prefetch thread
+    calls `weights()` for batch i + 1 (host floats, a 2-float all-reduce over a gloo group of its own) while the main thread
+    replays the captured step of batch i, so no collective -- i.e. no cross-rank rendez-vous -- sits on the compute stream in
+    front of a replay.  Ranks must call `weights()` once per batch index, in order, batch present or not (a rank whose batch
+    failed to decode contributes zeros), exactly like `loss_weights`.  Construct on the main thread (collective: new_group)."""
+
+    def __init__(self, keys: Sequence[str]):
+        self.keys = sorted(keys)
+        self.world = world_size()
+        self.group = dist.new_group(backend="gloo") if self.world > 1 else None      # CPU tensors whatever the main backend is
+        self.calls = 0
+
+    def weights(self, local_denoms: Dict[str, float]) -> torch.Tensor:
+        """float32 HOST vector, one entry per key (sorted): world * den_local / sum_ranks(den); ones at world == 1."""
+        assert sorted(local_denoms) == self.keys, (sorted(local_denoms), self.keys)
+        t = torch.tensor([float(local_denoms[k]) for k in self.keys], dtype=torch.float32)
+        if self.world == 1:
+            return torch.ones_like(t)
+        tot = t.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        self.calls += 1
+        return t * self.world / tot.clamp_min(1e-12)
 
 
 def allreduce_flat_grads(flat_g: torch.Tensor) -> float:

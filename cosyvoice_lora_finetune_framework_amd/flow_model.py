@@ -362,7 +362,7 @@ def build_flow_model(pretrained_path: Optional[str] = None, device: str = 'cuda'
     if pretrained_path is not None:
         wf = os.path.join(pretrained_path, 'flow.pt') if os.path.isdir(pretrained_path) else pretrained_path
         if os.path.exists(wf):
-            sd = torch.load(wf, map_location='cpu')
+            sd = torch.load(wf, map_location='cpu', weights_only=True)
             try:
                 model.load_state_dict(sd, strict=True)
                 print("Weights loaded successfully (strict=True)")

@@ -141,7 +141,7 @@ def build_llm_model(pretrained_path: Optional[str] = None, device: str = 'cuda',
         import os
         wf = os.path.join(pretrained_path, 'llm.pt') if os.path.isdir(pretrained_path) else pretrained_path
         if os.path.exists(wf):
-            model.load_state_dict(torch.load(wf, map_location='cpu'), strict=True)
+            model.load_state_dict(torch.load(wf, map_location='cpu', weights_only=True), strict=True)
         else:
             print(f"Warning: Weight file not found: {wf}\nUsing random initialization")
     return model.to(device)

@@ -6,7 +6,10 @@ loop + rank-r side path appended to the K loop) instead of 3 ``F.linear`` + scal
 Differences from the reference, all deliberate:
   * compute happens in libcvft (HIP); CPU tensors raise -- there is no eager fallback;
   * ``lora_dropout`` is accepted and stored, and applied (to the side-path input only, as in
-    lora.py:70) with a torch-generated mask when the module is in training mode and p > 0.
+    lora.py:70) when the module is in training mode and p > 0: the mask is counter-based and
+    drawn INSIDE the rank-side kernel (a pure function of the device-side step seed, the call
+    site and the element index; ``hipops.functional.dropout_begin_step``), re-derived in
+    backward instead of stored.  fp32 / odd shapes fall back to ``nn.Dropout``'s torch mask.
 """
 from __future__ import annotations
 
@@ -127,7 +130,7 @@ def save_lora_weights(model: nn.Module, path: str):
 
 def load_lora_weights(model: nn.Module, path: str):
     """reference lora.py:246-256."""
-    sd = torch.load(path, map_location='cpu')
+    sd = torch.load(path, map_location='cpu', weights_only=True)
     msd = model.state_dict()
     for name, param in sd.items():
         if name in msd:

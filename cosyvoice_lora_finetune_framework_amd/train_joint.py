@@ -434,6 +434,8 @@ class Trainer:
         self._packer = _BatchPacker()
         self._graphs: Dict[tuple, _StepGraph] = {}
         self._layouts: List[tuple] = []    # (T, Lt, text, LM length, B) of every captured step, read by the prefetch thread
+        self._denoms = None                # dp.DenomExchange while fit() runs at world > 1
+        self._term_keys: List[str] = []
         self.rank, _, self.world = (0, 0, 1) if not torch.distributed.is_initialized() else \
             (torch.distributed.get_rank(), 0, torch.distributed.get_world_size())
 
@@ -461,7 +463,7 @@ class Trainer:
         """Resume like Lightning: the stored epoch has finished, training continues with the next one; the best-loss
         mark, the callbacks' counters and the dropout seed continue too."""
         from .hipops import functional as HF
-        ck = torch.load(path, map_location="cpu")
+        ck = torch.load(path, map_location="cpu", weights_only=True)      # tensors + plain scalars / lists / dicts only
         own = module.model.state_dict()
         for k, v in ck["state_dict"].items():
             kk = k[len("model."):] if k.startswith("model.") else k
@@ -480,8 +482,15 @@ class Trainer:
 
     # -- one micro-step ---------------------------------------------------------------------
     def _prepare(self, module, batch):
-        """Host side of a micro-step (runs on the prefetch thread): bucket the text length, build the LM index maps,
-        copy the batch to the device on the copy stream.  Returns (batch, prepared, ready-event)."""
+        """Host side of a micro-step (runs on the prefetch thread): the data-parallel loss weights of this batch (world > 1),
+        then the layout work of `_prepare_layout`.  Returns (batch, prepared, ready-event, weights)."""
+        w = self._exchange_weights(module, batch)
+        return self._prepare_layout(module, batch) + (w,)
+
+    def _prepare_layout(self, module, batch):
+        """bucket the text length, build the LM index maps, copy the batch to the device on the copy stream.  Returns
+        (batch, prepared, ready-event).  No collective in here: `_micro_step` calls it again for a batch that was prepared
+        before the step covering it was captured."""
         if batch is None or not (self.use_graph and hasattr(module.model, 'prepare_batch')):
             return batch, None, None
         dev = module.device
@@ -494,6 +503,27 @@ class Trainer:
         with torch.cuda.stream(self._copy_stream):
             ev.record()
         return batch, packed, ev            # (draws_fn / loss denominators see the batch as the loader made it)
+
+    def _exchange_weights(self, module, batch):
+        """world > 1 (prefetch thread): this batch's loss weights (dp.DenomExchange -- a 2-float all-reduce over a gloo group
+        of its own, one batch ahead of the step that uses them) as a device vector in `term_keys` order, copied on the copy
+        stream from pinned memory; the step's stream waits for the batch's `ready` event or, on the eager path, for the event
+        stored beside the vector.  None at world == 1."""
+        if self._denoms is None:
+            return None
+        wh = self._denoms.weights(_batch_denoms(batch, module.training_mode))        # host floats, sorted-key order
+        order = [self._denoms.keys.index(k) for k in self._term_keys]
+        wh = wh[order].contiguous()
+        dev = module.device
+        if torch.device(dev).type != "cuda":
+            return wh, None
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream()
+        with torch.cuda.stream(self._copy_stream):
+            wd = wh.pin_memory().to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return wd, ev
 
     def _fit_layout(self, batch):
         """Shape side of the graph path: text length to its bucket, and (T, Lt, text, LM length) up to the layout of an
@@ -542,7 +572,7 @@ class Trainer:
             main = torch.cuda.current_stream()
             if self._layouts and prepared.dims not in self._layouts and self._fit_layout(batch)[1] != prepared.dims:
                 # prepared (by the prefetch thread) before the step that covers it was captured: fit it again
-                _, prepared, ready = self._prepare(module, batch)
+                _, prepared, ready = self._prepare_layout(module, batch)
             if draws is not None:
                 T2 = prepared.dims[0]
                 with torch.cuda.stream(self._copy_stream):
@@ -596,6 +626,10 @@ class Trainer:
         keys = ("loss", "llm_loss", "flow_loss", "llm_acc")
         term_keys = [k for k in ("llm", "flow") if k in _batch_denoms(None, module.training_mode)]   # order of _micro_step
         ones = torch.ones(len(term_keys), device=dev)
+        self._term_keys = term_keys
+        # world > 1: the denominators of batch i + 1 are exchanged by the prefetch thread over a gloo group of its own while
+        # batch i's step replays -- no collective in front of a replay (dp.DenomExchange; created here: new_group is collective)
+        self._denoms = dp.DenomExchange(sorted(term_keys)) if self.world > 1 else None
         for epoch in range(self.current_epoch, self.max_epochs):
             self.current_epoch = epoch
             sampler = getattr(dataloader, "sampler", None)
@@ -609,13 +643,16 @@ class Trainer:
                 self._copy_stream = torch.cuda.Stream()
             prefetch = _Prefetcher(dataloader, lambda b: self._prepare(module, b))
             try:
-                for bi, (batch, prepared, ready) in enumerate(prefetch):
+                for bi, (batch, prepared, ready, wx) in enumerate(prefetch):
                     # A rank whose batch failed to decode (collate_fn -> None) still takes part in every collective of the
-                    # step with a zero-weight contribution: no rank ever skips an all-reduce the others enter.
+                    # step with a zero-weight contribution: no rank ever skips an all-reduce the others enter (the prefetch
+                    # thread has already exchanged this batch's denominators: _exchange_weights).
                     w = ones
-                    if self.world > 1:
-                        lw = dp.loss_weights(_batch_denoms(batch, module.training_mode), dev)
-                        w = torch.stack([torch.as_tensor(lw[k], dtype=torch.float32, device=dev) for k in term_keys])
+                    if wx is not None:
+                        w, w_ready = wx
+                        if w_ready is not None:
+                            torch.cuda.current_stream().wait_event(w_ready)
+                            w.record_stream(torch.cuda.current_stream())
                     if batch is not None:
                         draws = self.draws_fn(epoch, bi, batch) if self.draws_fn else None
                         losses = self._micro_step(module, opt, batch, draws, w, prepared, ready)

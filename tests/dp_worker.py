@@ -47,10 +47,22 @@ def main():
         rows = list(range(rank, len(fl), world))
         batches.append({k: (v[rows] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == len(fl) else v) for k, v in full.items()})
         draws.append({k: v[rows] for k, v in d.items()})
+    # every all-reduce of the run, with the thread that issued it: the test asserts that the loss-denominator exchange never
+    # runs on the main thread (i.e. in front of a step's launches / replay), VERDICT round 3 item 8
+    import threading
+    import torch.distributed as dist
+    calls = []
+    if world > 1:
+        orig = dist.all_reduce
+
+        def recording_all_reduce(t, *a, **k):
+            calls.append((threading.current_thread() is threading.main_thread(), t.numel(), t.device.type, k.get("group") is not None))
+            return orig(t, *a, **k)
+        dist.all_reduce = recording_all_reduce
     tr = Trainer(max_epochs=2, accumulate_grad_batches=2, gradient_clip_val=1.0, train_mode=False, log_every_n_steps=1,
                  save_checkpoints=False, use_graph=bool(use_graph), draws_fn=lambda ep, bi, b: draws[bi])
     tr.fit(module, batches)
-    torch.save({"history": tr.history, "world": world, "rank": rank, "graph_stats": tr.graph_stats,
+    torch.save({"history": tr.history, "world": world, "rank": rank, "graph_stats": tr.graph_stats, "allreduce_calls": calls,
                 "params": {k: v.detach().cpu() for k, v in jm.named_parameters() if v.requires_grad}}, out_path)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

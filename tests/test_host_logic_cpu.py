@@ -114,6 +114,25 @@ def _dp_worker(rank, world, port, q):
     glob.backward()
     m = dp.reduce_metrics(torch.tensor([float(num_local), float(den_local)]))
     ok = torch.allclose(g_dp, th2.grad, rtol=1e-5, atol=1e-6) and abs(float(m[0] / m[1]) - float(glob)) < 1e-5
+    # dp.DenomExchange (what Trainer.fit uses): the same weights, exchanged by a second thread over a group of its own WHILE the
+    # main thread runs collectives on the default group (the flat-gradient all-reduce of the step in flight); a rank without a
+    # batch contributes zeros and still takes part
+    import threading
+    ex = dp.DenomExchange(["llm", "flow"])
+    den = lambda i: {"flow": 10.0 * (rank + 1) + i, "llm": 0.0 if (i == 2 and rank == 1) else 3.0 + rank}
+    side = []
+    th = threading.Thread(target=lambda: side.extend(ex.weights(den(i)) for i in range(5)))
+    th.start()
+    for i in range(5):
+        t = torch.ones(4)
+        dist.all_reduce(t)
+        ok = ok and float(t[0]) == world
+    th.join()
+    for i in range(5):
+        lw = dp.loss_weights(den(i), torch.device("cpu"))
+        want = torch.stack([torch.as_tensor(lw[k], dtype=torch.float32) for k in ex.keys])
+        ok = ok and torch.allclose(side[i], want, rtol=1e-6, atol=0)
+    ok = ok and ex.calls == 5 and ex.keys == ["flow", "llm"]
     q.put((rank, bool(ok)))
     dp.barrier()
     dist.destroy_process_group()

@@ -210,3 +210,11 @@ def test_data_parallel_trainer_equals_global_batch(tmp_path, use_graph, big):
         assert rel(got[0]["params"][k], v) < 2e-5, (k, rel(got[0]["params"][k], v))
     if use_graph:
         assert got[0]["graph_stats"]["replays"] > 0
+    # no collective in front of a step: the 2-float denominator exchange of each of the 8 micro-steps ran on the prefetch thread
+    # over its own (gloo, CPU tensor) group; the main thread all-reduced only the flat gradient (4 optimiser steps) and the epoch
+    # metrics (2 epochs)
+    for g in got:
+        side = [c for c in g["allreduce_calls"] if not c[0]]
+        main = [c for c in g["allreduce_calls"] if c[0]]
+        assert len(side) == 8 and all(c[1] == 2 and c[2] == "cpu" and c[3] for c in side), g["allreduce_calls"]
+        assert len(main) == 4 + 2 and not any(c[1] == 2 for c in main), main

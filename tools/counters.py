@@ -23,6 +23,8 @@ import os
 import subprocess
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 CMD = ["python3", "bench.py", "--steps", "3", "--warmup", "2", "--via-trainer", "0", "--graph", "0", "--no-cpu-baseline",
        "--no-roofline"]
 PASSES = {"mfma": ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA"],
@@ -32,7 +34,7 @@ PEAK_HBM_GBPS, SIMDS = 8000.0, 1024
 
 def short(name: str) -> str:
     n = name.split("(")[0]
-    for a, b in (("void ", ""), ("_Z16gemm_glds_kernelILi", "gemm_glds<"), ("_Z11gemm_kernelIDF16b", "gemm<bf16,")):
+    for a, b in (("void ", ""), ("_Z16gemm_glds_kernelILi", "gemm_glds<"), ("_Z16gemm_p256_kernelI", "gemm_p256<"), ("_Z11gemm_kernelIDF16b", "gemm<bf16,")):
         n = n.replace(a, b)
     return n[:72]
 
@@ -80,7 +82,8 @@ def summarise(out: str, dst: str):
                      hbm_frac_of_8tbps=(fb + wb) / dur / PEAK_HBM_GBPS)
         res[k] = e
     top = dict(sorted(res.items(), key=lambda kv: -kv[1]["total_ms_sampled"]))
-    doc = {"command": " ".join(CMD), "method": __doc__.split("Definitions")[1].strip(), "kernels": top}
+    from cosyvoice_lora_finetune_framework_amd.build_id import csrc_sha16
+    doc = {"command": " ".join(CMD), "csrc_sha16": csrc_sha16(), "method": __doc__.split("Definitions")[1].strip(), "kernels": top}
     json.dump(doc, open(dst, "w"), indent=1)
     print(f"{'kernel':74s} {'n':>5s} {'avg us':>8s} {'mfma_busy':>9s} {'VALU/MFMA':>9s} {'GB/s':>8s} {'of 8TB/s':>8s}")
     for k, e in list(top.items())[:40]:

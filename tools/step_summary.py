@@ -5,7 +5,11 @@ usage: step_summary.py <kernel_trace.csv> <out.json> <workload> <batch> <frames>
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cosyvoice_lora_finetune_framework_amd.build_id import csrc_sha16
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 out, workload, batch, frames = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
@@ -27,7 +31,7 @@ for st in steps:
         gtime[key] += (e - s)
 top = [{"kernel": k, "launches_per_step": groups[k] / nsteps, "ms_per_step": gtime[k] / nsteps / 1e6}
        for k, _ in gtime.most_common(25)]
-json.dump({"workload": workload, "batch": batch, "frames": frames, "steps_averaged": nsteps, "launches_per_step": launches,
+json.dump({"csrc_sha16": csrc_sha16(), "workload": workload, "batch": batch, "frames": frames, "steps_averaged": nsteps, "launches_per_step": launches,
            "kernel_ms_per_step": kms, "step_span_ms_under_profiler": span, "top_kernels": top,
            "note": "rocprofv3 --kernel-trace serialises nothing but adds per-dispatch overhead: the span is longer than the un-profiled step"},
           open(out, "w"), indent=1)
