@@ -467,6 +467,18 @@ def main():
             g["flop"] += rec["flop"]
             g["bytes"] += rec.get("bytes", 0.0)
             g["n"] += 1
+        if os.environ.get("CVFT_BENCH_DUMP_PROFILE"):      # diagnostic: per-(kernel, shape, epilogue) table of the instrumented step
+            per = {}
+            for rec in HF.PROFILE:
+                key = f"{rec['kernel']} {rec.get('shape')} {rec.get('epi', '')}"
+                g = per.setdefault(key, {"ms": 0.0, "flop": 0.0, "n": 0})
+                g["ms"] += max(rec["start"].elapsed_time(rec["end"]) - evt_ms, 1e-4)
+                g["flop"] += rec["flop"]
+                g["n"] += 1
+            rows = sorted(per.items(), key=lambda kv: -kv[1]["ms"])
+            with open(os.environ["CVFT_BENCH_DUMP_PROFILE"], "w") as fh:
+                for k, g in rows:
+                    fh.write(f"{g['ms']:8.3f} ms  n {g['n']:4d}  avg {g['ms'] * 1e3 / g['n']:7.1f} us  {g['flop'] / (g['ms'] * 1e-3) / 1e12:7.1f} TF/s  {k}\n")
         HF.PROFILE = None
         if groups:
             mfma_peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS

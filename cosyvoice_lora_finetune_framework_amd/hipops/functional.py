@@ -144,6 +144,9 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
         r_eff = a.R if (U is not None or La is not None) else 0
         PROFILE.append({"kernel": lib().cvft_gemm_last_kernel().decode(),
                         "start": e0, "end": e1, "shape": (a.M, N, K, ntaps, a.R if (U is not None or La is not None) else 0),
+                        "epi": "".join(c for c, on in (("b", bias is not None), ("a", act is not None), ("p", preact is not None),
+                                                        ("d", dact_src is not None), ("r", residual is not None), ("o", odrop is not None),
+                                                        ("x", xdrop is not None), ("f", La is not None)) if on),
                         "flop": 2.0 * a.M * N * (ntaps * K + r_eff) + (2.0 * a.M * K * a.R if La is not None else 0.0),
                         # algorithmic bytes: every operand and result once
                         "bytes": x.element_size() * (x.shape[0] * K + N * ntaps * K + a.M * N * (1 + (preact is not None) + (dact_src is not None) + (residual is not None))
@@ -275,13 +278,9 @@ def dropout_begin_step() -> None:
         set_dropout_seed_state(int(torch.initial_seed()))
     _DROPOUT["seed"].add_(1)
     _DROPOUT["site"] = 0
-    _DROPPED.clear()              # dropped inputs a previous forward wrote and no backward consumed
-    _ODROP_OUT.clear()
-    _PRE_MASKED.clear()
-    _PRE_V.clear()
-    _FORK_OPEN.clear()
-    _PRE_DX.clear()
-    _PRE_U.clear()                # a LayerNorm hand-off no adapter took (with the dropped copies it keeps alive)
+    _DROPPED.clear()              # dropped inputs a previous forward wrote and no backward consumed (keyed by mask site)
+    _PRE_DX.clear()               # parked fork gradients nobody took (keyed by a token drawn in forward)
+    # (every other node-to-node hand-over rides ON the tensor object that is handed over -- _hand / _take_hand -- and dies with it)
 
 
 class DropoutAddFn(torch.autograd.Function):
@@ -371,20 +370,48 @@ def dropout_raw(x: torch.Tensor, p: float, site: int) -> torch.Tensor:
 _DROPPED = {}       # mask site -> drop(x) written by the forward skinny kernel, consumed by that adapter's backward (dA = V^T drop(x))
 
 
-_PRE_U = {}        # LN output data_ptr -> (U, A data_ptr, alpha, p, sites): the rank-side product the LayerNorm launch already made
+# Node-to-node hand-overs.  A launch that makes a second product for the autograd node NEXT to it (the LayerNorm's rank-side U for
+# the adapter that reads its output, a producer's mask site for the LayerNorm that reads ITS output, the masked gradient and side
+# product a LayerNorm backward writes for the linear in front of it, the resnet fork's pairing) hands it over ON the tensor object
+# that travels between the two nodes -- an attribute in the tensor's __dict__ -- never in a table keyed by the tensor's ADDRESS: an
+# address can be recycled by the caching allocator between the two nodes (one wrong-gradient incident, round 3: a table keyed by
+# x's address read in backward after x had been freed), an attribute cannot outlive or be detached from its tensor.  The receiver
+# sees the same Python object whenever autograd passes the tensor through unchanged (one consumer, contiguous); when it does not
+# (fan-in sum, a copy made by _c / a dtype cast), the attribute is simply absent and the receiver computes the product itself --
+# every hand-over has that fallback, and every receiver still re-checks what it takes against its own identity ((p, site),
+# (B^T address, scale), shapes).  Forward -> backward crossings use tokens drawn in forward (_DROPPED: mask site; _PRE_DX).
+_H_PRE_U = "_cvft_pre_u"              # on y = LN(x):   (U, A data_ptr, alpha, p, sites, shape) from the LayerNorm launch
+_H_ODROP = "_cvft_odrop"              # on y = residual + dropout(linear(.)):   (p, site, side) of the producing Function
+_H_PRE_MASKED = "_cvft_pre_masked"    # on the dx a LayerNormForkFn backward returns:   (dxm, p, site, side product or None)
+_H_PRE_V = "_cvft_pre_v"              # on dxm:   (V, Bt data_ptr, scale)
+_H_FORK = "_cvft_fork"                # on x read by both convolutions of a ResnetBlock1D:   token of the "take" conv
+
+
+def _hand(t: torch.Tensor, name: str, value) -> None:
+    t.__dict__[name] = value
+
+
+HANDS_TAKEN = {}                      # name -> hand-overs a receiver found on its tensor (tests assert the path was exercised)
+
+
+def _take_hand(t: torch.Tensor, name: str):
+    v = t.__dict__.pop(name, None)
+    if v is not None:
+        HANDS_TAKEN[name] = HANDS_TAKEN.get(name, 0) + 1
+    return v
 
 # The residual-branch dropout of an encoder sublayer, y = residual + dropout(linear(.)), has its mask applied in the GEMM epilogue;
 # in backward the linear needs keep / (1 - p) * dy.  dy is written by the LayerNormForkFn that consumed y (its one consumer), so
 # that launch writes the masked copy too (cvft_layernorm_bwd_mask) and the linear's own mask pass over dy disappears.
-_ODROP_OUT = {}     # data_ptr of y -> (p, site, side), noted by the producing Function, read by the LayerNormForkFn that takes y
-_PRE_MASKED = {}    # data_ptr of the dx a LayerNormForkFn backward wrote -> (dxm, p, site, side product or None)
+# (_H_ODROP on y, noted by the producing Function and read by the LayerNormForkFn that takes y; _H_PRE_MASKED on the dx that
+# LayerNormForkFn's backward returns)
 # When that linear carries a rank-16 adapter, side = (Bt, scale) and the same LayerNorm-backward launch can also form
 # V = scale * dxm Bt^T (cvft_layernorm_bwd_mask_side), the product the adapter's backward would open with as a launch of its own
 # (40 launches per LLM step and chain): parked under dxm's address until _lin_bwd asks for exactly (dxm, Bt, scale).
 # Opt-in (CVFT_LN_BWD_SIDE=1): per launch 9.0 / 16.5 us against 7.1 + 4.9 / 12.4 + 5.2 us for the two launches (2 664 / 5 328 rows,
 # tools/bench_ln_side.py; matrix-core form: four rows per workgroup pass against B^T in LDS) -- less kernel time and one launch
 # fewer, and still no faster in the step: same box, joint 21.48 / 21.54 (off) vs 21.55 / 21.57 (on), llm_only 13.49 vs 13.60 ms.
-_PRE_V = {}         # data_ptr of dxm -> (V, Bt data_ptr, scale)
+# (_H_PRE_V on dxm)
 import os as _os  # noqa: E402
 LN_BWD_MASK = _os.environ.get("CVFT_LN_BWD_MASK", "1") != "0"
 LN_BWD_SIDE = _os.environ.get("CVFT_LN_BWD_SIDE", "0") != "0"
@@ -397,22 +424,22 @@ def _note_out_drop(y: torch.Tensor, od, side=None) -> None:
                 and side[0].dim() == 2 and side[0].shape[0] == 16 and side[0].shape[1] == y.shape[1] and side[0].is_contiguous()
                 and side[0].data_ptr() % 16 == 0 and y.shape[1] % 128 == 0 and y.shape[1] <= 1536):
             side = None
-        _ODROP_OUT[y.data_ptr()] = (float(od[0]), int(od[1]), side)
+        _hand(y, _H_ODROP, (float(od[0]), int(od[1]), side))
 
 
 def _masked_dy(dy: torch.Tensor, od) -> torch.Tensor:
     """keep(site) / (1 - p) * dy: the copy the LayerNorm backward already wrote for exactly this (p, site), else one mask pass."""
-    ent = _PRE_MASKED.pop(dy.data_ptr(), None)
+    ent = _take_hand(dy, _H_PRE_MASKED)
     if ent is not None and ent[1] == float(od[0]) and ent[2] == int(od[1]) and ent[0].shape == dy.shape and ent[0].dtype == dy.dtype:
         if ent[3] is not None:
-            _PRE_V[ent[0].data_ptr()] = ent[3]
+            _hand(ent[0], _H_PRE_V, ent[3])
         return ent[0]
     return dropout_raw(dy, od[0], od[1])
 
 
 def _take_side_v(dz: torch.Tensor, Bt: torch.Tensor, scale: float):
     """The V = scale * dz Bt^T the LayerNorm backward that wrote dz made for exactly this (Bt, scale), else None."""
-    ent = _PRE_V.pop(dz.data_ptr(), None)
+    ent = _take_hand(dz, _H_PRE_V)
     if ent is not None and ent[1] == Bt.data_ptr() and ent[2] == float(scale) and ent[0].shape == (dz.shape[0], Bt.shape[0]):
         return ent[0]
     return None
@@ -426,7 +453,7 @@ def _side_v(dz: torch.Tensor, Bt: torch.Tensor, scale: float) -> torch.Tensor:
 
 def take_pre_u(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, nsites: int):
     """(U, sites) that cvft_ln_skinny_dropout produced together with x = LN(.) for exactly this adapter, else None."""
-    ent = _PRE_U.pop(x.data_ptr(), None)
+    ent = _take_hand(x, _H_PRE_U)
     if ent is None:
         return None
     U, a_ptr, al, pp, sites, shape = ent
@@ -439,7 +466,7 @@ def take_pre_u(x: torch.Tensor, A: torch.Tensor, alpha: float, p: float, nsites:
 
 def drop_pre_u(x: torch.Tensor) -> None:
     """forget a hand-off nobody took (the adapter went down another path after all)"""
-    ent = _PRE_U.pop(x.data_ptr(), None)
+    ent = _take_hand(x, _H_PRE_U)
     if ent is not None:
         for st in ent[4]:
             _DROPPED.pop(st, None)
@@ -447,7 +474,7 @@ def drop_pre_u(x: torch.Tensor) -> None:
 
 def ln_skinny_dropout(x: torch.Tensor, gamma, beta, eps: float, A: torch.Tensor, alpha: float, p: float, nsites: int):
     """(y, mean, rstd) = LayerNorm(x) and, from the same launch, U = alpha * drop_t(y) A_t^T with the dropped copies kept for
-    backward; U is parked in _PRE_U under y's address for the adapter Function that consumes y (take_pre_u)."""
+    backward; U rides on y (_H_PRE_U) to the adapter Function that consumes y (take_pre_u)."""
     M, K = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
@@ -461,7 +488,7 @@ def ln_skinny_dropout(x: torch.Tensor, gamma, beta, eps: float, A: torch.Tensor,
     check(lib().cvft_ln_skinny_dropout(M, K, A.shape[0], ptr(x), ptr(gamma), ptr(beta), float(eps), ptr(y), ptr(mean), ptr(rstd),
                                        ptr(A), A.stride(0), float(alpha), ptr(U), U.stride(0), float(p), ptr(_DROPOUT["seed"]),
                                        _sites_arr(sites), xd, stream()), "cvft_ln_skinny_dropout")
-    _PRE_U[y.data_ptr()] = (U, A.data_ptr(), float(alpha), float(p), sites, (M, K))
+    _hand(y, _H_PRE_U, (U, A.data_ptr(), float(alpha), float(p), sites, (M, K)))
     return y, mean, rstd
 
 
@@ -1676,9 +1703,8 @@ class ConvPack:
 # add their two input gradients with a launch of its own (14 per Flow chain and step).  The later conv in forward order ("park")
 # runs FIRST in backward: it parks its dx and reports a zero gradient; the earlier one ("take") adds the parked tensor in its
 # dgrad epilogue.  The pair is armed in forward only when both saw the same buffer.
-# The pair is matched in forward by x's address (x is alive there); in backward x may be gone and its address reused by another
-# chain's tensor, so the parked gradient travels under a token drawn in forward.
-_FORK_OPEN = {}     # data_ptr of x -> token, set by the "take" conv's forward, consumed by the "park" conv's forward
+# The pair is matched in forward on the x OBJECT both convolutions receive (_H_FORK: the "take" conv's forward leaves its token on x,
+# the "park" conv's forward takes it); in backward x may be gone, so the parked gradient travels under that token.
 _PRE_DX = {}        # token -> dx parked by the "park" conv's backward
 _FORK_TOKEN = [0]
 CONV_FORK = _os.environ.get("CVFT_CONV_FORK", "1") != "0"
@@ -1693,9 +1719,9 @@ class ConvFn(torch.autograd.Function):
             if fork == "take":
                 _FORK_TOKEN[0] += 1
                 ctx.fork, ctx.token = "take", _FORK_TOKEN[0]
-                _FORK_OPEN[x.data_ptr()] = ctx.token
+                _hand(x, _H_FORK, ctx.token)
             elif fork == "park":
-                ctx.token = _FORK_OPEN.pop(x.data_ptr(), None)
+                ctx.token = _take_hand(x, _H_FORK)
                 if ctx.token is not None:
                     ctx.fork = "park"
         pad = (pack.k - 1) // 2
@@ -1791,9 +1817,9 @@ class LayerNormForkFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps: float, side=None):
+        ctx.prev_odrop = _take_hand(x, _H_ODROP)                 # x = residual + dropout(linear(.)): (p, site) of that mask
         x = _c(x)
         rows, Cn = x.shape
-        ctx.prev_odrop = _ODROP_OUT.pop(x.data_ptr(), None)      # x = residual + dropout(linear(.)): (p, site) of that mask
         if side is not None:                  # (A [R, K] compute dtype, alpha, p, nsites): the adapter that will read y
             y, mean, rstd = ln_skinny_dropout(x, gamma, beta, eps, *side)
         else:
@@ -1825,13 +1851,13 @@ class LayerNormForkFn(torch.autograd.Function):
                 check(lib().cvft_layernorm_bwd_mask_side(x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                                          ptr(dy), ptr(dres), ptr(dx), od[0], ptr(_DROPOUT["seed"]), od[1], ptr(dxm),
                                                          ptr(Bt), 16, float(sc), ptr(V), stream()), "cvft_layernorm_bwd_mask_side")
-                _PRE_MASKED[dx.data_ptr()] = (dxm, od[0], od[1], (V, Bt.data_ptr(), float(sc)))
-                ctx.side_keep = Bt             # the parked address stays this tensor's until the adapter's backward has asked
+                _hand(dx, _H_PRE_MASKED, (dxm, od[0], od[1], (V, Bt.data_ptr(), float(sc))))
+                ctx.side_keep = Bt             # (Bt's address identifies the adapter: it stays this tensor's until the adapter's backward has asked)
                 return dx, None, None, None, None
             check(lib().cvft_layernorm_bwd_mask(dt(x), x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                                 ptr(dy), ptr(dres), ptr(dx), od[0], ptr(_DROPOUT["seed"]), od[1], ptr(dxm), stream()),
                   "cvft_layernorm_bwd_mask")
-            _PRE_MASKED[dx.data_ptr()] = (dxm, od[0], od[1], None)
+            _hand(dx, _H_PRE_MASKED, (dxm, od[0], od[1], None))
             return dx, None, None, None, None
         check(lib().cvft_layernorm_bwd(dt(x), x.shape[0], x.shape[1], ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
                                        0, 1.0, ptr(dy), ptr(dres), ptr(dx), stream()), "cvft_layernorm_bwd")
@@ -1841,7 +1867,7 @@ class LayerNormForkFn(torch.autograd.Function):
 def layernorm_fork(x, gamma, beta, eps: float = 1e-5, side=None):
     """-> (x_residual, LN(x)); use x_residual (not x) for the residual connection.
     side = (A [R, K], alpha, p, nsites): y feeds a LoRA adapter under lora_dropout -- its rank-side product comes out of
-    the same launch (ln_skinny_dropout) and waits in _PRE_U for that adapter's Function."""
+    the same launch (ln_skinny_dropout) and rides on y (_H_PRE_U) to that adapter's Function."""
     return LayerNormForkFn.apply(x, gamma, beta, eps, side)
 
 

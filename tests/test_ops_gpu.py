@@ -412,13 +412,15 @@ def test_resnet_block_fork_gradients_meet_in_the_dgrad_launch(dtype):
 
     def run(fork: bool):
         HF.CONV_FORK = fork
-        HF._FORK_OPEN.clear()
         HF._PRE_DX.clear()
+        taken = HF.HANDS_TAKEN.get(HF._H_FORK, 0)
         x = x0.clone().requires_grad_(True)
         y = blk(x, B, T, length, torch.nn.functional.mish(temb.float()).to(dtype))
         y.backward(g)
         torch.cuda.synchronize()
-        assert len(HF._FORK_OPEN) == 0 and len(HF._PRE_DX) == 0
+        # the pairing rode on x (taken by the "park" conv's forward) and the parked gradient was taken under its token
+        assert HF.HANDS_TAKEN.get(HF._H_FORK, 0) - taken == (1 if fork else 0)
+        assert HF._H_FORK not in x.__dict__ and len(HF._PRE_DX) == 0
         return y.detach().clone(), x.grad.clone()
     default = HF.CONV_FORK
     try:
@@ -903,15 +905,16 @@ def test_layernorm_backward_writes_the_producer_mask_copy(dtype):
     def run(handover: bool):
         HF.LN_BWD_MASK = handover
         HF._DROPOUT["site"] = 7
-        HF._ODROP_OUT.clear()
-        HF._PRE_MASKED.clear()
+        t0 = dict(HF.HANDS_TAKEN)
         h.grad = res.grad = None
         x = HF.lora_linear(h, pack, residual=res, out_drop_p=0.1)
+        assert (HF._H_ODROP in x.__dict__) == handover       # the producer's (p, site) rides on its output ...
         xr, xn = HF.layernorm_fork(x, gamma, beta, 1e-5)
-        assert (len(HF._ODROP_OUT) == 0)                     # taken by the LayerNorm (or never noted)
+        assert HF._H_ODROP not in x.__dict__                 # ... and was taken by the LayerNorm (or never noted)
         torch.autograd.backward([xr, xn], [g1, g2])
         torch.cuda.synchronize()
-        assert len(HF._PRE_MASKED) == 0                      # consumed by the linear's backward
+        took = {k: HF.HANDS_TAKEN.get(k, 0) - t0.get(k, 0) for k in (HF._H_ODROP, HF._H_PRE_MASKED)}
+        assert took == ({HF._H_ODROP: 1, HF._H_PRE_MASKED: 1} if handover else {HF._H_ODROP: 0, HF._H_PRE_MASKED: 0}), took
         return x.detach().clone(), h.grad.clone(), res.grad.clone()
     try:
         a = run(True)
@@ -960,9 +963,7 @@ def test_layernorm_backward_writes_the_adapter_side_product(lora_p):
     def run(side: bool):
         HF.LN_BWD_SIDE = side
         HF._DROPOUT["site"] = 7
-        HF._ODROP_OUT.clear()
-        HF._PRE_MASKED.clear()
-        HF._PRE_V.clear()
+        t0 = dict(HF.HANDS_TAKEN)
         h.grad = res.grad = None
         gA = torch.zeros_like(A)
         gB = torch.zeros_like(Bm)
@@ -971,7 +972,8 @@ def test_layernorm_backward_writes_the_adapter_side_product(lora_p):
         xr, xn = HF.layernorm_fork(x, gamma, beta, 1e-5)
         torch.autograd.backward([xr, xn], [g1, g2])
         torch.cuda.synchronize()
-        assert len(HF._PRE_MASKED) == 0 and len(HF._PRE_V) == 0
+        took = {k: HF.HANDS_TAKEN.get(k, 0) - t0.get(k, 0) for k in (HF._H_PRE_MASKED, HF._H_PRE_V)}
+        assert took == {HF._H_PRE_MASKED: 1, HF._H_PRE_V: 1 if side else 0}, took       # both rode on the gradient tensors
         return h.grad.clone(), res.grad.clone(), A.grad.clone(), Bm.grad.clone()
     HF._take_side_v = spy
     side_default = HF.LN_BWD_SIDE
