@@ -62,6 +62,22 @@ def _weighted_total(losses, keys, w, accum: int):
     return t if accum == 1 else t / accum
 
 
+def _fwd_bwd(model, batch, dev, draws, keys, w, accum: int):
+    """One micro-step's forward + backward inside a LoraGradSink; the dict of detached loss scalars.  Chain by chain when the model
+    offers it (JointLLMFlowModel.forward_backward, CVFT_CHAIN_BWD: no join of all chains between the two directions), else the
+    reference's order: forward, weighted total, one backward."""
+    from . import llm_flow_model as J
+    if J.CHAIN_BWD and hasattr(model, "forward_backward"):
+        with LoraGradSink():
+            losses = model.forward_backward(batch, dev, draws, w, accum)
+        return {k: v.detach() for k, v in losses.items()}
+    losses = model(batch, dev, draws)
+    total = _weighted_total(losses, keys, w, accum)
+    with LoraGradSink():
+        total.backward()
+    return {k: v.detach() for k, v in losses.items()}
+
+
 class EarlyStopping:
     """Lightning EarlyStopping(monitor='train_loss_epoch', min_delta=1e-3, patience=10, mode='min')
     as configured at train_joint.py:324-331."""
@@ -341,11 +357,7 @@ class _StepGraph:
                 (k == "flow" and module.training_mode in ('joint', 'flow_only'))]
 
         def run():
-            losses = model(self.batch, dev, self.draws)
-            total = _weighted_total(losses, keys, self.w, accum)
-            with LoraGradSink():
-                total.backward()
-            return {k: v.detach() for k, v in losses.items()}
+            return _fwd_bwd(model, self.batch, dev, self.draws, keys, self.w, accum)
 
         saved = flat_g.clone()
         side = torch.cuda.Stream()
@@ -601,11 +613,7 @@ class Trainer:
                 return g.replay(prepared, draws, w)
             batch = prepared.tree
         self.graph_stats["eager"] += 1
-        losses = module.model(batch, dev, draws)
-        total = _weighted_total(losses, keys, w, self.accum)
-        with LoraGradSink():
-            total.backward()
-        return {k: v.detach() for k, v in losses.items()}
+        return _fwd_bwd(module.model, batch, dev, draws, keys, w, self.accum)
 
     # -- fit ------------------------------------------------------------------------------
     def fit(self, module: JointLightningModule, dataloader, ckpt_path: Optional[str] = None):

@@ -48,6 +48,52 @@ def test_training_curve_matches_reference(tiny_meta):
     assert worst < 1e-3, worst
 
 
+def test_training_curve_bf16_tracks_reference(tiny_meta):
+    """The arithmetic bench.py times (bf16 storage / MFMA operands, fp32 accumulation, fp32 LoRA masters and AdamW) on the same
+    configs[0] run: 8 optimiser steps of the product Trainer against the REFERENCE's fp32 CPU curve (train_tiny_log.json), dropout
+    off.  bf16 cannot meet the north_star's 1e-4 (that is the fp32 path's pin, above); what is pinned here is that the bf16 curve
+    TRACKS the reference step for step -- per-step loss within BF16_CURVE_TOL, learning rates exact, gradient norms and the final
+    LoRA tensors within their tolerances -- with every tolerance <= 3x the measured deviation (printed)."""
+    from cosyvoice_lora_finetune_framework_amd.llm_flow_model import JointLLMFlowModel
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, Trainer
+    # relative, per step; measured on MI355X (this test prints them): loss 6.3e-4, llm_loss 8.5e-4, flow_loss 3.5e-4,
+    # gradient norm 1.24e-3, final LoRA tensors 6.8e-3 -- tolerances <= 3x those
+    BF16_CURVE_TOL = {"loss": 1.9e-3, "llm_loss": 2.5e-3, "flow_loss": 1.0e-3}
+    BF16_GNORM_TOL, BF16_FINAL_TOL = 3.7e-3, 2.0e-2
+    log = load_json("train_tiny_log.json")
+    hp = log["hp"]
+    num = Numerics(dtype=torch.bfloat16)
+    flow = build_flow_product(tiny_meta["flow"], DEV, num)
+    llm = build_llm_product(tiny_meta["llm"], DEV, num)
+    jm = JointLLMFlowModel(llm, flow, 'joint', llm_loss_weight=2.0, flow_loss_weight=1.0)
+    module = JointLightningModule('joint', learning_rate=hp["lr"], min_lr=hp["min_lr"], warmup_steps=hp["warmup"],
+                                  weight_decay=hp["wd"], model=jm, numerics=num)
+    batches = [synth_batch([T], text_lens=[Lx], token_lens=[Lt], seed=100 + i, text_vocab=100, speech_vocab=50)
+               for i, (T, Lx, Lt) in enumerate(log["lens"])]
+    tr = Trainer(max_epochs=hp["epochs"], accumulate_grad_batches=hp["accum"], gradient_clip_val=hp["clip"], train_mode=False,
+                 log_every_n_steps=1, save_checkpoints=False,
+                 draws_fn=lambda ep, bi, b: cfm_draws(1, b["speech_feat"].shape[1], 1000 * ep + bi))
+    tr.fit(module, batches)
+    ref = [r for r in log["log"] if "lr" in r]
+    assert len(tr.history) == len(ref) == log["total_steps"]
+    worst = {k: 0.0 for k in BF16_CURVE_TOL}
+    worst_g = 0.0
+    for got, exp in zip(tr.history, ref):
+        assert abs(got["lr"] - exp["lr"]) <= 1e-9 + 1e-6 * exp["lr"]
+        for k in worst:
+            worst[k] = max(worst[k], abs(got[k] - exp[k]) / abs(exp[k]))
+        worst_g = max(worst_g, abs(got["grad_norm"] - exp["grad_norm"]) / exp["grad_norm"])
+    final = load_npz("train_tiny_final.npz")
+    own = dict(jm.named_parameters())
+    worst_f = max(rel(own[k], v) for k, v in final.items())
+    print(f"[bf16 curve vs reference] worst per-step relative loss deviation {worst}, grad norm {worst_g:.2e}, final LoRA tensors {worst_f:.2e}")
+    for k, tol in BF16_CURVE_TOL.items():
+        assert worst[k] < tol, (k, worst)
+    assert worst_g < BF16_GNORM_TOL and worst_f < BF16_FINAL_TOL, (worst_g, worst_f)
+
+
 def test_trainer_runs_on_parquet_shard(tmp_path):
     """SURVEY 8f rank 2 end to end: create_dataloader over the golden parquet shard (real on-disk schema, augmentation
     and cross-sample prompts on) -> Trainer.fit in train mode (dropouts active) on a small joint model."""
