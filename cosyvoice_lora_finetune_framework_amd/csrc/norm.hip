@@ -702,7 +702,7 @@ __global__ void __launch_bounds__(512) gn_fused_bwd_kernel(int T_, int C, int G,
             dz = live ? dz * gm[q] : 0.f;
             dzr[k][q] = dz;
             s1 += dz;
-            s2 += dz * xh;          // (dz == 0 outside the live frames)
+            s2 += live ? dz * xh : 0.f;      // select, not 0 * xh: x of a frame the forward never normalised (bucket padding) may be anything
         }
         __builtin_amdgcn_sched_barrier(0);      // one chunk's temporaries at a time (interleaved, the 8-chunk form spilled)
     }

@@ -723,10 +723,14 @@ class LoraGradSink:
         self.deferred = {}
 
     def _deferred_added(self, r: int):
-        """CVFT_SINK_DEFER_EARLY=1 (experiment, off): once a chain has postponed SINK_EARLY_BATCH products of one rank, that batch goes
-        out on the chain's own stream instead of after the last chain (the batch launches are ~0.9 ms of kernel time between the end
-        of backward and the reduce).  Measured, joint B = 16: a stream of their own for them 22.2 -> 33.5 ms (a fifth stream in the
-        captured graph shares a hardware queue with a chain); see DESIGN section 12 for the in-chain form."""
+        """CVFT_SINK_DEFER_EARLY (default ON): once a chain has postponed SINK_EARLY_BATCH products of one rank, that batch goes out
+        on the chain's OWN stream, mid-backward, instead of after the last chain has joined (the batch launches were ~0.9 ms of
+        kernel time between the end of backward and the reduce).  A/B that justified the default, same box, joint B = 16:
+        22.04 -> 21.67-21.73 ms for batches of 8-32 (flow_only 14.42 -> 14.32).  The rejected variant is a stream of their own for
+        those batches: 22.2 -> 33.5 ms (a fifth stream in the captured graph shares a hardware queue with a chain).  Rows left over
+        when a chain ends (fewer than a batch, or other chains' rows) leave with flush(); DESIGN section 13.  Covered by
+        tests/test_ops_gpu.py::test_sink_early_batches_equal_end_of_backward_batches (adapter gradients EARLY=0 vs 1, two chains,
+        a row count that is not a multiple of the batch)."""
         if not SINK_DEFER_EARLY:
             return
         cur = torch.cuda.current_stream()

@@ -418,14 +418,15 @@ class Trainer:
     On a GPU the micro-step (forward + backward) replays a captured hipGraph per batch layout (`use_graph`, default on;
     CVFT_TRAINER_GRAPH=0 or use_graph=False launches eagerly): a batch is padded up to the layout of an already captured
     step when one covers it within SHAPE_SLACK (exact maxima travel as device scalars: same results), else its own layout
-    is captured (at most `max_graphs` -- a captured step keeps its activations: ~7.6 GiB at B = 16, T ~ 500, so 16 of them
-    are ~120 of the 288 GB -- eager beyond); the batch reaches the graph's static slab by one DMA + one device
+    is captured (at most `max_graphs` at a time -- a captured step keeps its activations: ~7.6 GiB at B = 16, T ~ 500, so 16 of
+    them are ~120 of the 288 GB; beyond that the least recently replayed step gives up its slot, `evict_after`, and only a
+    corpus that cycles through more uncoverable layouts than slots runs some steps eagerly); the batch reaches the graph's static slab by one DMA + one device
     copy; all-reduce / clip / AdamW stay outside the graph."""
 
     def __init__(self, max_epochs: int = 100, accumulate_grad_batches: int = 1, gradient_clip_val: float = 1.0,
                  callbacks: Optional[list] = None, default_root_dir: str = OUTPUT_DIR, log_every_n_steps: int = 10,
                  draws_fn=None, save_checkpoints: bool = True, train_mode: bool = True, use_graph: Optional[bool] = None,
-                 max_graphs: int = 16, on_step_end=None):
+                 max_graphs: int = 16, on_step_end=None, evict_after: int = 32):
         self.max_epochs, self.accum, self.clip = max_epochs, max(1, accumulate_grad_batches), gradient_clip_val
         self.train_mode = train_mode       # pl.Trainer.fit puts the module tree in .train() (dropouts active); False keeps the caller's mode
         self.callbacks = callbacks or []
@@ -440,6 +441,13 @@ class Trainer:
             use_graph = os.environ.get("CVFT_TRAINER_GRAPH", "1") != "0"
         self.use_graph = bool(use_graph) and torch.cuda.is_available()
         self.max_graphs = max_graphs
+        # When every capture slot is taken and NO captured step covers a batch, the least recently replayed step is retired and
+        # the new layout captured in its place -- provided that step has not been replayed for `evict_after` micro-steps (a
+        # capture costs ~4 eager steps: a corpus cycling through more uncoverable layouts than slots would otherwise pay one per
+        # batch; with the age rule it pays at most one per `evict_after` steps and runs the rest eagerly, 4-5x a replay).
+        self.evict_after = evict_after
+        self._last_used: Dict[tuple, int] = {}
+        self._micro_steps = 0
         self.on_step_end = on_step_end     # optional hook(trainer) after every optimiser step (bench.py --via-trainer)
         self.graph_stats = {"replays": 0, "eager": 0, "captures": 0}
         self._copy_stream = None
@@ -599,21 +607,41 @@ class Trainer:
             # layout of the slab (every tensor's shape / dtype) + the Python scalars the step bakes in (LM length L,
             # sub-batch row ranges) + whether CFM draws are injected
             key = (prepared.key, draws is not None and tuple(sorted(draws)))
+            self._micro_steps += 1
             g = self._graphs.get(key)
             if g is None:
                 # capture at first sight: a layout only gets here when no captured step covers it (_fit_layout)
+                if 0 < self.max_graphs <= len(self._graphs):
+                    self._retire_oldest()
                 if len(self._graphs) < self.max_graphs:
                     g = self._graphs[key] = _StepGraph(module, prepared, draws, w.clone(), self.accum, opt.flat_g)
+                    g.dims = prepared.dims
                     self._layouts.append(prepared.dims)
                     if os.environ.get('CVFT_TRAINER_DEBUG'):
                         print(f"[trainer] captured layout {prepared.dims} (exact {tuple(batch['speech_feat'].shape)}, {tuple(batch['speech_token'].shape)})", flush=True)
                     self.graph_stats["captures"] += 1
             if g is not None:
+                self._last_used[key] = self._micro_steps
                 self.graph_stats["replays"] += 1
                 return g.replay(prepared, draws, w)
             batch = prepared.tree
         self.graph_stats["eager"] += 1
         return _fwd_bwd(module.model, batch, dev, draws, keys, w, self.accum)
+
+    def _retire_oldest(self):
+        """Free the capture slot of the least recently replayed step if it is old enough (see `evict_after`): its graph, its
+        static batch slab and the activations its private pool holds go back to the allocator.  The LoRA slab workspaces and
+        reduce tables it wrote to are never freed (other captured steps may share them)."""
+        key = min(self._graphs, key=lambda k: self._last_used.get(k, 0))
+        if self._micro_steps - self._last_used.get(key, 0) < self.evict_after:
+            return
+        torch.cuda.synchronize()                  # no replay of it may still be in flight
+        g = self._graphs.pop(key)
+        self._last_used.pop(key, None)
+        if g.dims in self._layouts and not any(o.dims == g.dims for o in self._graphs.values()):
+            self._layouts.remove(g.dims)
+        del g
+        self.graph_stats["retired"] = self.graph_stats.get("retired", 0) + 1
 
     # -- fit ------------------------------------------------------------------------------
     def fit(self, module: JointLightningModule, dataloader, ckpt_path: Optional[str] = None):

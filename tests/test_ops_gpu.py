@@ -194,6 +194,32 @@ def test_groupnorm_mish(dtype, G, Cn):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_groupnorm_backward_ignores_bucket_padding_frames(dtype):
+    """frames of a shape-bucketed layout beyond the exact batch's frame count (t >= *t_eff) are never normalised
+    by the forward, so whatever sits there (here: NaN) must not reach the live frames' gradients -- the backward's group
+    reductions are selects, not 0 * x products.  Live-frame dx equals the run on a clean buffer bit for bit; padding dx is 0."""
+    HF = HFmod()
+    B, T, Te, G, Cn = 2, 40, 29, 8, 256
+    lens = torch.tensor([29, 20], dtype=torch.int32, device=DEV)
+    te = torch.tensor([Te], dtype=torch.int32, device=DEV)
+    g, b = (1 + 0.1 * rnd(Cn, seed=2)).to(DEV), (0.1 * rnd(Cn, seed=3)).to(DEV)
+    x0 = q(rnd(B, T, Cn, seed=1) + 0.2, dtype).to(DEV, dtype)
+    gy = q(rnd(B, T, Cn, seed=5), dtype).reshape(B * T, Cn).to(DEV, dtype)
+    res = []
+    for poison in (False, True):
+        x = x0.clone()
+        if poison:
+            x[:, Te:, :] = float("nan")
+        xd = x.reshape(B * T, Cn).requires_grad_(True)
+        y = HF.groupnorm_mish(xd, g, b, B, T, G, 1e-5, lens, None, True, t_eff=te)
+        y.backward(gy)
+        res.append((y.detach().reshape(B, T, Cn), xd.grad.reshape(B, T, Cn)))
+    assert torch.isfinite(res[1][1][:, :Te]).all()
+    assert torch.equal(res[0][0][:, :Te], res[1][0][:, :Te]) and torch.equal(res[0][1][:, :Te], res[1][1][:, :Te])
+    assert float(res[1][1][:, Te:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T,lens", [(50, [50, 33]), (131, [131, 64]), (64, [64, 1])])
 def test_attn_bias(dtype, T, lens):
     """modules.Attention math (modules.py:253-293) with the additive -1e10 key bias."""
@@ -1227,6 +1253,71 @@ def test_qkv_stacked_lora_dropout_matches_torch(defer):
         assert rel(mods[i].lora_A.grad, A.grad) < 3e-2, ("dA", i, rel(mods[i].lora_A.grad, A.grad))
         assert rel(mods[i].lora_B.grad, Bm.grad) < 3e-2, ("dB", i)
     assert rel(x.grad.float(), xf.grad) < 3e-2
+
+
+def test_sink_early_batches_equal_end_of_backward_batches():
+    """the postponed adapter-gradient products leave in batches on their chain's stream during backward
+    (CVFT_SINK_DEFER_EARLY, the shipped default) or all at flush().  Two chains on two streams run the same stacked q|k|v
+    adapters (four postponed products each per call, two calls per chain: eight per chain); with batches of three, each chain
+    sends two full batches early and leaves two rows for flush(), where the two chains' leftovers meet in one launch.  The
+    adapter gradients equal the all-at-flush() form bit for bit (same slabs, same reduce order)."""
+    from cosyvoice_lora_finetune_framework_amd.lora import LoRALinear
+    from cosyvoice_lora_finetune_framework_amd.modules import hip_qkv
+    from cosyvoice_lora_finetune_framework_amd.optim import FlatAdamW
+    HF = HFmod()
+    torch.manual_seed(5)
+    K, N, pdrop = 256, 512, 0.05
+    mods = [LoRALinear(torch.nn.Linear(K, N), r=16, lora_alpha=32, lora_dropout=pdrop).to(DEV) for _ in range(3)]
+    for m in mods:
+        torch.nn.init.normal_(m.lora_B, std=0.05)
+        m.train()
+    params = [p for m in mods for p in (m.lora_A, m.lora_B)]
+    opt = FlatAdamW(params, lr=1e-3)
+    xs = [(torch.randn(M, K, device=DEV) * 0.5).to(torch.bfloat16) for M in (1000, 700, 520, 333)]
+    gs = [torch.randn(x.shape[0], 3 * N, device=DEV).to(torch.bfloat16) for x in xs]
+    side = torch.cuda.Stream()
+    saved = (HF.SINK_DEFER_EARLY, HF.SINK_EARLY_BATCH, HF.STACKED_DROP_DEFER, HF.LoraGradSink.uses_hint)
+    res = []
+    try:
+        HF.SINK_EARLY_BATCH, HF.STACKED_DROP_DEFER = 3, True
+        for early in (False, True):
+            HF.SINK_DEFER_EARLY = early
+            HF.LoraGradSink.uses_hint = 4
+            opt.zero_grad()
+            HF.dropout_begin_step()
+            HF._DROPOUT["seed"].fill_(12345)
+            launches = []
+            orig = HF.LoraGradSink._launch_rows
+            HF.LoraGradSink._launch_rows = staticmethod(lambda r, rows: (launches.append((len(rows), torch.cuda.current_stream().cuda_stream)), orig(r, rows))[1])
+            try:
+                with HF.LoraGradSink() as sink:
+                    outs = []
+                    main = torch.cuda.current_stream()
+                    side.wait_stream(main)
+                    for ci, st in enumerate((main, side)):                 # chain ci: two calls on its stream
+                        with torch.cuda.stream(st):
+                            for x, g in zip(xs[2 * ci: 2 * ci + 2], gs[2 * ci: 2 * ci + 2]):
+                                xi = x.clone().requires_grad_(True)
+                                q_, k_, v_ = hip_qkv(mods[0], mods[1], mods[2], xi)
+                                outs.append(((q_, k_, v_), g))
+                    for (q_, k_, v_), g in outs:                           # backward runs on each call's forward stream
+                        torch.autograd.backward([q_, k_, v_], [g[:, :N], g[:, N:2 * N], g[:, 2 * N:]])
+                    main.wait_stream(side)
+                    left = sum(len(v) for v in sink.deferred.values())
+            finally:
+                HF.LoraGradSink._launch_rows = orig
+            torch.cuda.synchronize()
+            res.append(([p.grad.clone() for p in params], launches, left))
+    finally:
+        HF.SINK_DEFER_EARLY, HF.SINK_EARLY_BATCH, HF.STACKED_DROP_DEFER, HF.LoraGradSink.uses_hint = saved
+    (g0, l0, left0), (g1, l1, left1) = res
+    print("[sink batches] at flush only:", l0, "left", left0, "| early:", l1, "left", left1)
+    assert left0 == 16 and sum(n for n, _ in l0) == 16                     # everything at flush() (one launch per rank)
+    early = [(n, st) for n, st in l1 if n == 3]
+    assert len(early) >= 2 and len({st for _, st in early}) == 2           # full batches left early, each on its own chain's stream
+    assert 0 < left1 < 16 and sum(n for n, _ in l1) == 16                  # ... and the leftovers of both chains with flush()
+    for a, b in zip(g0, g1):
+        assert float(a.abs().max()) > 0 and torch.equal(a, b)
 
 
 @pytest.mark.parametrize("M,K,R,nsites", [(4000, 256, 48, 3), (5376, 1024, 48, 3), (5376, 1024, 16, 1), (1000, 512, 16, 1),
