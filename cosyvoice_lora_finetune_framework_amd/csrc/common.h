@@ -192,8 +192,13 @@ __device__ __forceinline__ unsigned cvft_fmix32(unsigned h) {
 static inline bool cvft_drop_rate_ok(float p) { return p == 0.f || (p >= 1.f / 65536.f && p <= 1.f - 1.f / 65536.f); }
 __device__ __forceinline__ unsigned cvft_drop_thr(float p) { return (unsigned)fminf(65535.f, rintf(p * 65536.f)); }
 // keep flags of elements 4g .. 4g+3: field e of the draw >= thr
+// The group index first goes through a per-site BIJECTION that is not an XOR with a constant: multiplication by an odd multiplier
+// taken from the site key (one more 32-bit multiply per draw; the multiplier is loop-invariant).  With gl ^ key alone every site's
+// and step's mask was one fixed 2^32-entry table read at XOR-relabelled positions: drop counts over aligned power-of-two blocks
+// of elements depended on the key's high bits only, and two sites' masks were permutations of each other block for block
+// (tests/test_host_logic_cpu.py::test_dropout_masks_of_two_sites_are_uncorrelated pins the host replica of this function).
 __device__ __forceinline__ void cvft_keep4(unsigned long long key, unsigned long long g, unsigned thr, bool (&k)[4]) {
-    const unsigned gl = (unsigned)g;
+    const unsigned gl = (unsigned)g * ((unsigned)(key >> 17) | 1u);
     const unsigned lo = cvft_fmix32(gl ^ (unsigned)key), hi = cvft_fmix32(gl ^ (unsigned)(key >> 32));
     k[0] = (lo & 0xffffu) >= thr; k[1] = (lo >> 16) >= thr; k[2] = (hi & 0xffffu) >= thr; k[3] = (hi >> 16) >= thr;
 }

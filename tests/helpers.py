@@ -47,3 +47,38 @@ def rel(a, b):
 
 def lora_grads(model):
     return {n: p.grad for n, p in model.named_parameters() if 'lora_' in n and p.grad is not None}
+
+
+def keep_fields_host(seed: int, site: int, ngroups: int):
+    """Host replica of csrc/common.h cvft_drop_key / cvft_keep4: the 16-bit fields of the mask draws of groups 0 .. ngroups-1 (group g
+    = elements 4g .. 4g+3 of the flat tensor) as a numpy uint32 array [ngroups, 4]; element e is KEPT when its field >= thr,
+    thr = min(65535, rint(p * 65536)).  Every device kernel that draws a mask (cvft_dropout_add, the dropout-skinny product, the
+    masked rank extension of cvft_gemm, GEMM output dropout, the q|k|v chain kernels) calls that one function."""
+    import numpy as np
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mix(z):
+        z = (z + np.uint64(0x9e3779b97f4a7c15)) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & M
+        return z ^ (z >> np.uint64(31))
+
+    def fmix32(h):
+        h = h ^ (h >> np.uint32(16))
+        h = (h.astype(np.uint64) * np.uint64(0x85ebca6b)).astype(np.uint32)
+        h = h ^ (h >> np.uint32(13))
+        h = (h.astype(np.uint64) * np.uint64(0xc2b2ae35)).astype(np.uint32)
+        return h ^ (h >> np.uint32(16))
+    with np.errstate(over="ignore"):
+        key = int(mix(np.uint64(seed) ^ (np.uint64(site) << np.uint64(32))))
+        mul = np.uint64(((key >> 17) & 0xFFFFFFFF) | 1)
+        g = (np.arange(ngroups, dtype=np.uint64) * mul).astype(np.uint32)          # per-site odd multiplier (mod 2^32)
+        lo = fmix32(g ^ np.uint32(key & 0xFFFFFFFF))
+        hi = fmix32(g ^ np.uint32(key >> 32))
+    f = np.uint32(0xFFFF)
+    return np.stack([lo & f, lo >> np.uint32(16), hi & f, hi >> np.uint32(16)], 1)
+
+
+def drop_thr_host(p: float) -> int:
+    import numpy as np
+    return int(min(65535.0, float(np.rint(np.float32(p) * np.float32(65536.0)))))

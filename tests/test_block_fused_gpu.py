@@ -115,31 +115,10 @@ def _qkv_case(M, p, seed):
 
 
 def _keep_mask(M, Kd, p, seed, site):
-    """host replica of the counter-based mask (csrc/common.h): site key = SplitMix64 finaliser of (seed, site); one draw per 4 elements =
-    two murmur3 32-bit finalisers of the group index under the key's halves, 16-bit fields"""
-    import numpy as np
-    M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
-
-    def mix(z):
-        z = (z + np.uint64(0x9e3779b97f4a7c15)) & M64
-        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & M64
-        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & M64
-        return z ^ (z >> np.uint64(31))
-
-    def fmix32(h):
-        h = h ^ (h >> np.uint32(16))
-        h = (h.astype(np.uint64) * np.uint64(0x85ebca6b)).astype(np.uint32)
-        h = h ^ (h >> np.uint32(13))
-        h = (h.astype(np.uint64) * np.uint64(0xc2b2ae35)).astype(np.uint32)
-        return h ^ (h >> np.uint32(16))
-    with np.errstate(over="ignore"):
-        key = mix(np.uint64(seed) ^ (np.uint64(site) << np.uint64(32)))
-        grp = np.arange(M * Kd // 4, dtype=np.uint32)
-        lo = fmix32(grp ^ np.uint32(int(key) & 0xFFFFFFFF))
-        hi = fmix32(grp ^ np.uint32(int(key) >> 32))
-    thr = min(65535, int(round(p * 65536)))
-    fields = np.stack([lo & np.uint32(0xffff), lo >> np.uint32(16), hi & np.uint32(0xffff), hi >> np.uint32(16)], 1).reshape(M, Kd)
-    return torch.from_numpy((fields >= thr).astype("float32"))
+    """host replica of the counter-based mask (csrc/common.h cvft_keep4; tests/helpers.py keep_fields_host): 1.0 where kept"""
+    from helpers import drop_thr_host, keep_fields_host
+    fields = keep_fields_host(int(seed), int(site), M * Kd // 4).reshape(M, Kd)
+    return torch.from_numpy((fields >= drop_thr_host(p)).astype("float32"))
 
 
 @pytest.mark.parametrize("wide", [0, 1])                                    # (1: 64 rows per workgroup, csrc/block_qkv_wide.hip)

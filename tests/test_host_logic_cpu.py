@@ -422,3 +422,32 @@ def test_host_budget_splits_the_cores_between_local_ranks():
     finally:
         os.sched_setaffinity(0, before)
         torch.set_num_threads(threads)
+
+
+def test_dropout_masks_of_two_sites_are_uncorrelated():
+    """the counter-based masks (csrc/common.h cvft_keep4, replicated in tests/helpers.py) of two call sites, and of
+    two steps, are independent draws -- not one table read at XOR-relabelled positions: the rate is p, the drop counts of aligned
+    1024-element blocks at two sites / two seeds are uncorrelated, and no site's block counts equal another's sorted (a
+    relabelling by XOR permutes aligned blocks among themselves: equal multisets of block counts)."""
+    import numpy as np
+    from helpers import drop_thr_host, keep_fields_host
+    p, ng = 0.1, 1 << 18                                        # 2^20 elements
+    thr = drop_thr_host(p)
+    drops = {}
+    for seed, site in ((1234, 7), (1234, 8), (1235, 7), (1234, 7 + 64)):
+        f = keep_fields_host(seed, site, ng)
+        d = (f < thr)
+        assert abs(d.mean() - p) < 4 * np.sqrt(p * (1 - p) / d.size)            # rate
+        assert abs(d[:, 0].mean() - d[:, 3].mean()) < 6 * np.sqrt(2 * p * (1 - p) / ng)      # fields of one draw alike
+        drops[(seed, site)] = d.reshape(-1, 1024).sum(1).astype(np.float64)    # per aligned block of 1024 elements
+    keys = list(drops)
+    for i in range(len(keys)):
+        for j in range(i + 1, len(keys)):
+            a, b = drops[keys[i]], drops[keys[j]]
+            c = np.corrcoef(a, b)[0, 1]
+            assert abs(c) < 5 / np.sqrt(a.size), (keys[i], keys[j], c)          # ~N(0, 1/sqrt(1024 blocks))
+            assert not np.array_equal(np.sort(a), np.sort(b)), (keys[i], keys[j])
+    # within one site: neighbouring elements independent (pair drop rate p^2)
+    d = (keep_fields_host(1234, 7, ng) < thr).reshape(-1)
+    both = (d[:-1] & d[1:]).mean()
+    assert abs(both - p * p) < 5 * np.sqrt(p * p * (1 - p * p) / d.size)

@@ -1144,31 +1144,11 @@ def test_attn_relpos_probability_dropout(dtype, causal):
 
 
 def _keep_scale_host(seed: int, site: int, n: int, p: float) -> torch.Tensor:
-    """Host replica of common.h cvft_drop_key / cvft_keep4 (the mask of cvft_dropout_add, cvft_skinny_dropout and
-    cvft_lora_side_dgrad): flat [n] tensor of {0, 1/(1-p)}."""
+    """Host replica of common.h cvft_drop_key / cvft_keep4 (tests/helpers.py: keep_fields_host): flat [n] tensor of {0, 1/(1-p)}."""
     import numpy as np
-    M = np.uint64(0xFFFFFFFFFFFFFFFF)
-
-    def mix(z):
-        z = (z + np.uint64(0x9e3779b97f4a7c15)) & M
-        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & M
-        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & M
-        return z ^ (z >> np.uint64(31))
-    def fmix32(h):
-        h = h ^ (h >> np.uint32(16))
-        h = (h.astype(np.uint64) * np.uint64(0x85ebca6b)).astype(np.uint32)
-        h = h ^ (h >> np.uint32(13))
-        h = (h.astype(np.uint64) * np.uint64(0xc2b2ae35)).astype(np.uint32)
-        return h ^ (h >> np.uint32(16))
-    with np.errstate(over="ignore"):
-        key = int(mix(np.uint64(seed) ^ (np.uint64(site) << np.uint64(32))))
-        g = np.arange((n + 3) // 4, dtype=np.uint32)
-        lo = fmix32(g ^ np.uint32(key & 0xFFFFFFFF))            # one draw per 4 elements: two 32-bit finalisers, 16-bit fields
-        hi = fmix32(g ^ np.uint32(key >> 32))
-    f = np.uint32(0xFFFF)
-    u = np.stack([lo & f, lo >> np.uint32(16), hi & f, hi >> np.uint32(16)], 1).reshape(-1)[:n].astype(np.uint64)
-    thr = int(min(65535.0, float(np.rint(np.float32(p) * np.float32(65536.0)))))
-    return torch.from_numpy((u >= np.uint64(thr)).astype(np.float64)) / (1.0 - float(np.float32(p)))
+    from helpers import drop_thr_host, keep_fields_host
+    u = keep_fields_host(seed, site, (n + 3) // 4).reshape(-1)[:n].astype(np.uint64)
+    return torch.from_numpy((u >= np.uint64(drop_thr_host(p))).astype(np.float64)) / (1.0 - float(np.float32(p)))
 
 
 @pytest.mark.parametrize("r", [16, 64])
