@@ -122,17 +122,20 @@ DEV void wave_frag_load(bf16x8 (&f)[4], const bf16_t* __restrict__ g, int ld, in
 // with a vmcnt(0) each -- the prefetch then is synchronous.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef u32x4 Tile2[2];
+// NT = threads of the block: 256 (two 16-byte chunks per thread and tile) or 512 (one)
+template <int NT>
 DEV void tload(Tile2& t, const bf16_t* __restrict__ g, int ld, int r0, int rlim, int tid) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i, row = min(max(r0 + (c >> 3), 0), rlim - 1);
+    for (int i = 0; i < 512 / NT; ++i) {
+        const int c = tid + NT * i, row = min(max(r0 + (c >> 3), 0), rlim - 1);
         t[i] = *reinterpret_cast<const u32x4*>(g + (size_t)row * ld + (c & 7) * 8);
     }
 }
+template <int NT>
 DEV void tstore(const Tile2& t, bf16_t* S, int tid) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i;
+    for (int i = 0; i < 512 / NT; ++i) {
+        const int c = tid + NT * i;
         *reinterpret_cast<u32x4*>(S + (c >> 3) * LDK + (c & 7) * 8) = t[i];
     }
 }
@@ -244,9 +247,14 @@ DEV void fwd_scores(f32x16 (&s)[2], const bf16_t* Kc, const bf16x8 (&qu)[4], con
 // The score MFMAs of the NEXT step are issued at the end of a step, so their latency (and the K-fragment LDS reads)
 // hides under the staging stores and the barrier instead of sitting in front of the VALU-bound softmax; K therefore
 // runs one step ahead of V through the LDS ring.
-template <bool REL, bool DROP, int NBUF>
-__global__ void __launch_bounds__(256) attn32_fwd_kernel(AP<bf16_t> p) {
+// NW = waves (x 32 queries) per block: 4, or 8 for the estimator's launches while other chains share the chip -- one block per
+// (batch, head) at T <= 256 instead of two, i.e. the same waves on HALF the CUs with two waves per SIMD (a 4-wave block per CU runs
+// one wave per SIMD with every latency exposed and still owns the CU's time), and every K / V tile staged once per 256 queries.
+template <bool REL, bool DROP, int NBUF, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) attn32_fwd_kernel(AP<bf16_t> p) {
     using namespace a32;
+    static_assert(NW == 4 || (NW == 8 && !REL), "eight-wave blocks: additive-bias (estimator) form only");
+    constexpr int NT_ = 64 * NW, QB = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vs = Ks + NBUF * TILE;
@@ -254,11 +262,11 @@ __global__ void __launch_bounds__(256) attn32_fwd_kernel(AP<bf16_t> p) {
 
     STAMP_DECL();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    const int L = p.L, nblk = (L + 127) >> 7;
+    const int L = p.L, nblk = (L + QB - 1) / QB;
     int bh, blk;
     block_map(blockIdx.x, nblk, p.B * p.H, bh, blk);
     if (REL && p.causal) blk = nblk - 1 - blk;      // longest blocks first
-    const int i0 = blk * 128, hh = bh % p.H, b = bh / p.H;
+    const int i0 = blk * QB, hh = bh % p.H, b = bh / p.H;
     const int iw = i0 + 32 * w, i = iw + l31;
     const size_t rowbase = (size_t)b * L;
     const bf16_t* qg = p.q + rowbase * p.ld + hh * 64;
@@ -271,7 +279,7 @@ __global__ void __launch_bounds__(256) attn32_fwd_kernel(AP<bf16_t> p) {
     int jmax;                                   // keys the block stages
     if (REL) {
         jmax = min(L, lb);
-        if (p.causal) jmax = min(jmax, i0 + 128);
+        if (p.causal) jmax = min(jmax, i0 + QB);
     } else {
         jmax = (lb >= 1) ? min(L, lb) : L;
     }
@@ -298,8 +306,8 @@ __global__ void __launch_bounds__(256) attn32_fwd_kernel(AP<bf16_t> p) {
     f32x16 gcarry = zero16();
     bf16x8 pf0[4], pf1[4];
     Tile2 kr, vr;
-    tload(kr, kg, p.ld, 0, L, tid);      // unconditional: nothing here waits for len[b]
-    tload(vr, vg, p.ld, 0, L, tid);
+    tload<NT_>(kr, kg, p.ld, 0, L, tid);      // unconditional: nothing here waits for len[b]
+    tload<NT_>(vr, vg, p.ld, 0, L, tid);
     if (REL) {
         bf16x8 t0[4];
         wave_frag_load(t0, pg, p.ldp, mlo0 + l31, M2 + 1, hf);
@@ -308,10 +316,10 @@ __global__ void __launch_bounds__(256) attn32_fwd_kernel(AP<bf16_t> p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) gcarry = mfma(t0[s], qv[s], gcarry);
     }
-    tstore(kr, Ks, tid);
+    tstore<NT_>(kr, Ks, tid);
     touch(qu);
     if (REL) touch(qv);
-    tload(kr, kg, p.ld, 64, L, tid);
+    tload<NT_>(kr, kg, p.ld, 64, L, tid);
     __syncthreads();
 
     float* Gw = Gs + w * 32 * SKW + l31 * SKW;
@@ -326,10 +334,10 @@ __global__ void __launch_bounds__(256) attn32_fwd_kernel(AP<bf16_t> p) {
         }
     }
     if (NBUF == 1) __syncthreads();
-    tstore(kr, Ks + (1 % NBUF) * TILE, tid);
-    tstore(vr, Vs, tid);
-    tload(kr, kg, p.ld, 128, L, tid);
-    tload(vr, vg, p.ld, 64, L, tid);
+    tstore<NT_>(kr, Ks + (1 % NBUF) * TILE, tid);
+    tstore<NT_>(vr, Vs, tid);
+    tload<NT_>(kr, kg, p.ld, 128, L, tid);
+    tload<NT_>(vr, vg, p.ld, 64, L, tid);
     __syncthreads();
 
     float m_run = NINF, l_run = 0.f;
@@ -448,10 +456,10 @@ __global__ void __launch_bounds__(256) attn32_fwd_kernel(AP<bf16_t> p) {
         STAMP(1);          // next QK^T (+ band, skew)
         if (NBUF == 1) __syncthreads();
         STAMP(6);          // barrier 1 (single-buffer only) / idle of waves that skipped the step
-        tstore(kr, Ks + ((t + 2) % NBUF) * TILE, tid);      // (past the end: dead stores of a re-loaded last tile)
-        tstore(vr, Vs + ((t + 1) % NBUF) * TILE, tid);
-        tload(kr, kg, p.ld, 64 * (t + 3), L, tid);
-        tload(vr, vg, p.ld, 64 * (t + 2), L, tid);
+        tstore<NT_>(kr, Ks + ((t + 2) % NBUF) * TILE, tid);      // (past the end: dead stores of a re-loaded last tile)
+        tstore<NT_>(vr, Vs + ((t + 1) % NBUF) * TILE, tid);
+        tload<NT_>(kr, kg, p.ld, 64 * (t + 3), L, tid);
+        tload<NT_>(vr, vg, p.ld, 64 * (t + 2), L, tid);
         STAMP(7);          // wait for the prefetch + LDS stores + next loads issued
         __syncthreads();
         STAMP(8);          // barrier 2
@@ -477,9 +485,11 @@ __global__ void __launch_bounds__(256) attn32_fwd_kernel(AP<bf16_t> p) {
 // =====================================================================================================================
 // backward dQ: block = 4 waves x 32 queries, 64 keys per step
 // =====================================================================================================================
-template <bool REL, bool DROP, int NBUF>
+template <bool REL, bool DROP, int NBUF, int NW = 4>
 DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
+    static_assert(NW == 4 || (NW == 8 && !REL), "eight-wave blocks: additive-bias (estimator) form only");
+    constexpr int NT_ = 64 * NW, QB = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vs = Ks + NBUF * TILE;
@@ -488,11 +498,11 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
     bf16_t* Rs = reinterpret_cast<bf16_t*>(Gs + (REL ? 4 * 32 * SKW : 0));   // REL: 4 x 32 x RSK
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    const int L = p.L, nblk = (L + 127) >> 7;
+    const int L = p.L, nblk = (L + QB - 1) / QB;
     int bh, blk;
     block_map(bid, nblk, p.B * p.H, bh, blk);
     if (REL && p.causal) blk = nblk - 1 - blk;      // longest blocks first
-    const int i0 = blk * 128, hh = bh % p.H, b = bh / p.H;
+    const int i0 = blk * QB, hh = bh % p.H, b = bh / p.H;
     const int iw = i0 + 32 * w, i = iw + l31;
     const size_t rowbase = (size_t)b * L;
     const bf16_t* qg = p.q + rowbase * p.ld + hh * 64;
@@ -507,7 +517,7 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
     int jmax;
     if (REL) {
         jmax = min(L, lb);
-        if (p.causal) jmax = min(jmax, i0 + 128);
+        if (p.causal) jmax = min(jmax, i0 + QB);
     } else {
         jmax = (lb >= 1) ? min(L, lb) : L;
     }
@@ -552,23 +562,23 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
     Tile2 kr, vr, br0, br1, br2;
 #define A32_DQ_PREFETCH(J0_)                                                   \
     do {                                                                       \
-        tload(kr, kg, p.ld, (J0_), L, tid);                                    \
-        tload(vr, vg, p.ld, (J0_), L, tid);                                    \
+        tload<NT_>(kr, kg, p.ld, (J0_), L, tid);                                    \
+        tload<NT_>(vr, vg, p.ld, (J0_), L, tid);                                    \
         if (REL) {                                                             \
             const int mb_ = (L - 1) - (i0 + 127) + (J0_);                      \
-            tload(br0, pg, p.ldp, mb_, 2 * L - 1, tid);                        \
-            tload(br1, pg, p.ldp, mb_ + 64, 2 * L - 1, tid);                   \
-            tload(br2, pg, p.ldp, mb_ + 128, 2 * L - 1, tid);                  \
+            tload<NT_>(br0, pg, p.ldp, mb_, 2 * L - 1, tid);                        \
+            tload<NT_>(br1, pg, p.ldp, mb_ + 64, 2 * L - 1, tid);                   \
+            tload<NT_>(br2, pg, p.ldp, mb_ + 128, 2 * L - 1, tid);                  \
         }                                                                      \
     } while (0)
 #define A32_DQ_PUBLISH(BUF_)                                                   \
     do {                                                                       \
-        tstore(kr, Ks + (BUF_) * TILE, tid);                                   \
-        tstore(vr, Vs + (BUF_) * TILE, tid);                                   \
+        tstore<NT_>(kr, Ks + (BUF_) * TILE, tid);                                   \
+        tstore<NT_>(vr, Vs + (BUF_) * TILE, tid);                                   \
         if (REL) {                                                             \
-            tstore(br0, Pb, tid);                                              \
-            tstore(br1, Pb + 64 * LDK, tid);                                   \
-            tstore(br2, Pb + 128 * LDK, tid);                                  \
+            tstore<NT_>(br0, Pb, tid);                                              \
+            tstore<NT_>(br1, Pb + 64 * LDK, tid);                                   \
+            tstore<NT_>(br2, Pb + 128 * LDK, tid);                                  \
         }                                                                      \
     } while (0)
     A32_DQ_PREFETCH(0);      // unconditional: nothing here waits for len[b]
@@ -704,17 +714,19 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
     }
 }
 
-template <bool REL, bool DROP, int NBUF>
-__global__ void __launch_bounds__(256) attn32_bwd_dq_kernel(AP<bf16_t> p) { attn32_bwd_dq_body<REL, DROP, NBUF>(p, blockIdx.x); }
+template <bool REL, bool DROP, int NBUF, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) attn32_bwd_dq_kernel(AP<bf16_t> p) { attn32_bwd_dq_body<REL, DROP, NBUF, NW>(p, blockIdx.x); }
 
 // =====================================================================================================================
 // backward dK, dV: block = 4 waves x 32 keys, 64 queries per step.  OWN_DELTA: delta = rowsum(dO * O) of each staged
 // query tile is formed here from the prefetch registers instead of read from the dQ kernel's output -- the two backward
 // roles then have no dependency and can share one launch (attn32_bwd_fused_kernel).
 // =====================================================================================================================
-template <bool REL, bool DROP, int NBUF, bool OWN_DELTA>
+template <bool REL, bool DROP, int NBUF, bool OWN_DELTA, int NW = 4>
 DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
+    static_assert(NW == 4 || (NW == 8 && !REL), "eight-wave blocks: additive-bias (estimator) form only");
+    constexpr int NT_ = 64 * NW, QB = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Os = Qs + NBUF * TILE;
@@ -723,10 +735,10 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
     float* Gs = del_s + NBUF * 64;                                      // REL: 4 x 32 x SK2
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    const int L = p.L, nblk = (L + 127) >> 7;
+    const int L = p.L, nblk = (L + QB - 1) / QB;
     int bh, blk;
     block_map(bid, nblk, p.B * p.H, bh, blk);      // (causal: key block 0 is the longest and already first)
-    const int j0b = blk * 128, hh = bh % p.H, b = bh / p.H;
+    const int j0b = blk * QB, hh = bh % p.H, b = bh / p.H;
     const int jw = j0b + 32 * w, j = jw + l31;
     const size_t rowbase = (size_t)b * L;
     const bf16_t* qg = p.q + rowbase * p.ld + hh * 64;
@@ -784,31 +796,31 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
         const bf16_t* og = p.o + rowbase * p.ldo + hh * 64;
 #define A32_KV_PREFETCH(I0_)                                                               \
     do {                                                                                   \
-        tload(qr, qg, p.ld, (I0_), L, tid);                                                \
-        tload(dor, dog, p.ldo, (I0_), L, tid);                                             \
+        tload<NT_>(qr, qg, p.ld, (I0_), L, tid);                                                \
+        tload<NT_>(dor, dog, p.ldo, (I0_), L, tid);                                             \
         const int ii_ = min((I0_) + (tid & 63), L - 1);      /* every thread loads */      \
         lse_n = p.lse[((size_t)b * p.H + hh) * L + ii_];                                   \
-        if (OWN_DELTA) tload(orr, og, p.ldo, (I0_), L, tid);                               \
+        if (OWN_DELTA) tload<NT_>(orr, og, p.ldo, (I0_), L, tid);                               \
         else del_n = p.delta[((size_t)b * p.H + hh) * L + ii_];                            \
     } while (0)
 #define A32_KV_PUBLISH(BUF_, I0_)                                                          \
     do {                                                                                   \
-        tstore(qr, Qs + (BUF_) * TILE, tid);                                               \
-        tstore(dor, Os + (BUF_) * TILE, tid);                                              \
+        tstore<NT_>(qr, Qs + (BUF_) * TILE, tid);                                               \
+        tstore<NT_>(dor, Os + (BUF_) * TILE, tid);                                              \
         if (tid < 64) {                                                                    \
             const bool ok_ = (I0_) + tid < L;                                              \
             lse_s[(BUF_) * 64 + tid] = ok_ ? lse_n * LOG2E : __builtin_inff();             \
             if (!OWN_DELTA) del_s[(BUF_) * 64 + tid] = ok_ ? del_n * p.scale : 0.f;        \
         }                                                                                  \
-        if (OWN_DELTA) {      /* thread: 8 columns of rows tid/8 and tid/8 + 32 */          \
-            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                             \
+        if (OWN_DELTA) {      /* thread: 8 columns of row tid/8 (and, 256 threads, tid/8 + 32) */ \
+            _Pragma("unroll") for (int i_ = 0; i_ < 512 / NT_; ++i_) {                     \
                 const bf16x8 d8_ = __builtin_bit_cast(bf16x8, dor[i_]), o8_ = __builtin_bit_cast(bf16x8, orr[i_]); \
                 float s_ = 0.f;                                                            \
                 _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) s_ += (float)d8_[e_] * (float)o8_[e_]; \
                 s_ += __shfl_xor(s_, 1);                                                   \
                 s_ += __shfl_xor(s_, 2);                                                   \
                 s_ += __shfl_xor(s_, 4);                                                   \
-                const int row_ = (tid >> 3) + 32 * i_;                                     \
+                const int row_ = (tid >> 3) + (NT_ / 8) * i_;                              \
                 if ((tid & 7) == 0) del_s[(BUF_) * 64 + row_] = ((I0_) + row_ < L) ? s_ * p.scale : 0.f; \
             }                                                                              \
         }                                                                                  \
@@ -976,10 +988,10 @@ __global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p) {
 // Both backward roles in ONE launch (blocks [0, nq): dQ, blocks [nq, 2 nq): dK/dV with its own delta): at the estimator's
 // sizes a role alone is one 4-wave block per CU (T = 250: 256 blocks), i.e. one wave per SIMD with every latency
 // exposed; together they put two waves on a SIMD, and one launch boundary per attention backward disappears.
-template <bool REL, bool DROP, int NBUF>
-__global__ void __launch_bounds__(256) attn32_bwd_fused_kernel(AP<bf16_t> p, int nq) {
-    if ((int)blockIdx.x < nq) attn32_bwd_dq_body<REL, DROP, NBUF>(p, blockIdx.x);
-    else attn32_bwd_dkv_body<REL, DROP, NBUF, true>(p, blockIdx.x - nq);
+template <bool REL, bool DROP, int NBUF, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) attn32_bwd_fused_kernel(AP<bf16_t> p, int nq) {
+    if ((int)blockIdx.x < nq) attn32_bwd_dq_body<REL, DROP, NBUF, NW>(p, blockIdx.x);
+    else attn32_bwd_dkv_body<REL, DROP, NBUF, true, NW>(p, blockIdx.x - nq);
 }
 
 // =====================================================================================================================
@@ -1007,19 +1019,31 @@ static int set_smem(K kernel, size_t bytes, const char* name) {
     return 0;
 }
 template <typename K>
-static int launch(K kernel, size_t sm, const AP<bf16_t>& p, hipStream_t st, const char* name) {
+static int launch(K kernel, size_t sm, const AP<bf16_t>& p, hipStream_t st, const char* name, int nw = 4) {
     if (set_smem(kernel, sm, name)) return -2;
-    dim3 grid((unsigned)((p.L + 127) / 128) * p.H * p.B);
-    hipLaunchKernelGGL(kernel, grid, dim3(256), sm, st, p);
+    dim3 grid((unsigned)((p.L + 32 * nw - 1) / (32 * nw)) * p.H * p.B);
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * nw), sm, st, p);
     CVFT_LAUNCH_CHECK(name);
     return 0;
+}
+// Waves per block of the estimator's (additive-bias) launches: CVFT_ATTN_NW = 4 (default) | 8.  The eight-wave blocks use half the
+// CUs per launch (T = 250: 128 blocks of 8 waves instead of 256 of 4, two waves per SIMD, every K / V / Q / dO tile staged once
+// per 256 rows) at a few microseconds more latency per launch; measured in the step, same box, 40 steps: joint 21.08 / 21.08 (4)
+// vs 21.23 / 21.26 ms (8), flow_only 14.24 vs 14.36 -- the Flow chains' latency counts for more than the CU-time they free
+// (DESIGN section 14), so the four-wave blocks stay the default and the eight-wave instantiations an opt-in (parity-tested).
+static int est_waves() {
+    static const int env = getenv("CVFT_ATTN_NW") ? atoi(getenv("CVFT_ATTN_NW")) : 0;
+    return env == 8 ? 8 : 4;
 }
 }  // namespace a32
 
 // rel = 0: additive key-bias attention (estimator); rel = 1: rel-pos attention.  Called from attention.hip for bf16.
 int cvft_attn32_fwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
     using namespace a32;
-    if (!rel) return launch(attn32_fwd_kernel<false, false, 2>, smem_fwd(false, 2), p, st, "attn32_fwd");
+    if (!rel) {
+        if (est_waves() == 8) return launch(attn32_fwd_kernel<false, false, 2, 8>, smem_fwd(false, 2), p, st, "attn32_fwd", 8);
+        return launch(attn32_fwd_kernel<false, false, 2>, smem_fwd(false, 2), p, st, "attn32_fwd");
+    }
     if (p.drop_p > 0.f) return launch(attn32_fwd_kernel<true, true, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel_drop");
     return launch(attn32_fwd_kernel<true, false, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel");
 }
@@ -1031,6 +1055,14 @@ int cvft_attn32_bwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
         if (split < 0) {
             const char* e = getenv("CVFT_ATTN_BWD_SPLIT");
             split = (e && e[0] == '1') ? 1 : 0;
+        }
+        if (!split && est_waves() == 8) {
+            const size_t sm = smem_dq(false, 2) > smem_dkv(false, 2) ? smem_dq(false, 2) : smem_dkv(false, 2);
+            if (set_smem(attn32_bwd_fused_kernel<false, false, 2, 8>, sm, "attn32_bwd_fused")) return -2;
+            const int nq = ((p.L + 255) / 256) * p.H * p.B;
+            hipLaunchKernelGGL((attn32_bwd_fused_kernel<false, false, 2, 8>), dim3(2u * nq), dim3(512), sm, st, p, nq);
+            CVFT_LAUNCH_CHECK("attn32_bwd_fused");
+            return 0;
         }
         if (!split) {
             const size_t sm = smem_dq(false, 2) > smem_dkv(false, 2) ? smem_dq(false, 2) : smem_dkv(false, 2);

@@ -35,7 +35,9 @@ struct P256X {
     int S;                      // k-splits per tile (1 = none)
     int nk_total;               // K / 64
     int hb;                     // band height of the tile order (rows of tiles walked column-major inside a band)
-    float* ws;                  // SK: [tiles][S][65536] fp32 slabs
+    float* ws;                  // SK: [tiles][S][65536] fp32 slabs (or the same count of bf16 when slab_bf16)
+    int slab_bf16;              // SK: partial tiles travel as bf16 (half the slab bytes); EVERY partial, the last arriver's own
+                                // included, is rounded the same way before the fp32 sum, so the result does not depend on who arrives last
     unsigned* cnt;              // SK: [tiles] arrival tickets (zero between launches)
 };
 
@@ -324,12 +326,28 @@ __global__ void __launch_bounds__(512, 2) gemm_p256_kernel(GP<bf16_t> p, P256X x
     // ---- split-K: leave the tile in the workspace in register order; the last arriver carries on with the sum
     if constexpr (SK) {
         float* slab = x.ws + ((size_t)tile * x.S + zs) * 65536;
+        bf16_t* slabh = reinterpret_cast<bf16_t*>(x.ws) + ((size_t)tile * x.S + zs) * 65536;
         unsigned* flag = reinterpret_cast<unsigned*>(smem);             // ring is dead (every DMA waited for, all reads done)
+        if (x.slab_bf16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    bf16x8 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h[e] = (bf16_t)acc[i][2 * jp][e]; h[4 + e] = (bf16_t)acc[i][2 * jp + 1][e]; }
+                    *reinterpret_cast<bf16x8*>(slabh + ((i * 2 + jp) * 512 + tid) * 8) = h;
+                    // the own partial enters the sum rounded like everybody else's
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[i][2 * jp][e] = (float)h[e]; acc[i][2 * jp + 1][e] = (float)h[4 + e]; }
+                }
+        } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<float4*>(slab + ((i * 4 + j) * 512 + tid) * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -348,6 +366,27 @@ __global__ void __launch_bounds__(512, 2) gemm_p256_kernel(GP<bf16_t> p, P256X x
         if (*flag == 0u) return;
         // fixed summation order (slab 0 + slab 1 + ...) whoever arrives last, the own tile taken from registers: results do
         // not depend on the arrival order
+        if (x.slab_bf16) {
+            const bf16_t* base = reinterpret_cast<const bf16_t*>(x.ws) + ((size_t)tile * x.S) * 65536;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
+                    for (int z = 0; z < x.S; ++z) {
+                        if (z == zs) {
+                            f0 += acc[i][2 * jp];
+                            f1 += acc[i][2 * jp + 1];
+                        } else {
+                            const bf16x8 h = *reinterpret_cast<const bf16x8*>(base + (size_t)z * 65536 + ((i * 2 + jp) * 512 + tid) * 8);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { f0[e] += (float)h[e]; f1[e] += (float)h[4 + e]; }
+                        }
+                    }
+                    acc[i][2 * jp] = f0;
+                    acc[i][2 * jp + 1] = f1;
+                }
+        } else
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -527,6 +566,7 @@ int gemm_p256_launch(const GP<bf16_t>& p_in, hipStream_t st) {
     static const int hb_env = getenv("CVFT_P256_HB") ? atoi(getenv("CVFT_P256_HB")) : 0;
     static const int rowsplit_env = getenv("CVFT_P256_ROWSPLIT") ? atoi(getenv("CVFT_P256_ROWSPLIT")) : 1;
     static const int stamp_env = getenv("CVFT_P256_STAMP") ? atoi(getenv("CVFT_P256_STAMP")) : 0;
+    static const int slabh_env = getenv("CVFT_P256_SLAB_BF16") ? atoi(getenv("CVFT_P256_SLAB_BF16")) : 1;
     if (mode == 0) return 1;
     GP<bf16_t> p = p_in;
     p.direct_epi = 1;
@@ -538,6 +578,7 @@ int gemm_p256_launch(const GP<bf16_t>& p_in, hipStream_t st) {
     if (p.xdrop_p > 0.f && (p.R % 16 != 0 || p.R <= 0)) return 1;
     P256X x;
     x.tiles_m = (p.M + 255) / 256; x.tiles_n = p.N / 256; x.nk_total = p.K / 64; x.S = 1; x.ws = nullptr; x.cnt = nullptr;
+    x.slab_bf16 = slabh_env ? 1 : 0;
     long tiles = (long)x.tiles_m * x.tiles_n;
     // k-splits (CVFT_P256_SPLIT=n, or -1 = as many as fill the 256 CUs with >= 12 k-tiles each): opt-in.  Measured at
     // 5328 x 1024 x 4096 / x 3072 (84 tiles, three splits): 74 / 64 us against 61 / 50 us for one round of 96x256 tiles -- every

@@ -43,6 +43,7 @@ LOSS_FUSE = os.environ.get("CVFT_LOSS_FUSE", "1") != "0"      # 0: the plain op-
 # joint 21.28 / 21.36 (1) vs 21.33 / 21.34 ms (0), flow_only 14.29 vs 14.27, llm_only 13.38 vs 13.31 -- the step is bound by the
 # chip's CU-time, an idle chain is another chain's CUs
 CHAIN_BWD = os.environ.get("CVFT_CHAIN_BWD", "0") != "0"
+SIDE_STREAM_PRIORITY = int(os.environ.get("CVFT_SIDE_PRIO", "0"))      # priority of the side streams (the Flow chains in joint mode): -1 = high
 
 
 def _scaled(x, w):
@@ -109,7 +110,7 @@ class JointLLMFlowModel(nn.Module):
             st = None
             if use_streams and ci < len(chains) - 1:
                 while len(JointLLMFlowModel._streams) <= ci:
-                    JointLLMFlowModel._streams.append(torch.cuda.Stream())
+                    JointLLMFlowModel._streams.append(torch.cuda.Stream(priority=SIDE_STREAM_PRIORITY))
                 st = JointLLMFlowModel._streams[ci]
                 st.wait_stream(cur)
             with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
