@@ -251,7 +251,7 @@ DEV void fwd_scores(f32x16 (&s)[2], const bf16_t* Kc, const bf16x8 (&qu)[4], con
 // (batch, head) at T <= 256 instead of two, i.e. the same waves on HALF the CUs with two waves per SIMD (a 4-wave block per CU runs
 // one wave per SIMD with every latency exposed and still owns the CU's time), and every K / V tile staged once per 256 queries.
 template <bool REL, bool DROP, int NBUF, int NW = 4>
-__global__ void __launch_bounds__(64 * NW) attn32_fwd_kernel(AP<bf16_t> p) {
+DEV void attn32_fwd_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
     static_assert(NW == 4 || (NW == 8 && !REL), "eight-wave blocks: additive-bias (estimator) form only");
     constexpr int NT_ = 64 * NW, QB = 32 * NW;
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(64 * NW) attn32_fwd_kernel(AP<bf16_t> p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     const int L = p.L, nblk = (L + QB - 1) / QB;
     int bh, blk;
-    block_map(blockIdx.x, nblk, p.B * p.H, bh, blk);
+    block_map(bid, nblk, p.B * p.H, bh, blk);
     if (REL && p.causal) blk = nblk - 1 - blk;      // longest blocks first
     const int i0 = blk * QB, hh = bh % p.H, b = bh / p.H;
     const int iw = i0 + 32 * w, i = iw + l31;
@@ -480,6 +480,18 @@ __global__ void __launch_bounds__(64 * NW) attn32_fwd_kernel(AP<bf16_t> p) {
     }
     STAMP(9);              // epilogue
     STAMP_FLUSH();
+}
+// Launch shape shared by the kernels of this file: gridDim.x workgroups walk `nblocks` owner blocks gridDim.x apart.  A grid
+// smaller than nblocks (CVFT_ATTN_GRID: the rel-pos launches of the LLM chain) keeps the launch on a share of the CUs and leaves
+// the rest to the step's other chains; the barrier separates two blocks' use of the staging LDS.
+#define A32_WALK(BODY_)                                                                         \
+    for (int bid_ = blockIdx.x; bid_ < nblocks; bid_ += gridDim.x) {                           \
+        BODY_;                                                                                 \
+        if (bid_ + (int)gridDim.x < nblocks) __syncthreads();                                  \
+    }
+template <bool REL, bool DROP, int NBUF, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) attn32_fwd_kernel(AP<bf16_t> p, int nblocks) {
+    A32_WALK((attn32_fwd_body<REL, DROP, NBUF, NW>(p, bid_)))
 }
 
 // =====================================================================================================================
@@ -715,7 +727,9 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
 }
 
 template <bool REL, bool DROP, int NBUF, int NW = 4>
-__global__ void __launch_bounds__(64 * NW) attn32_bwd_dq_kernel(AP<bf16_t> p) { attn32_bwd_dq_body<REL, DROP, NBUF, NW>(p, blockIdx.x); }
+__global__ void __launch_bounds__(64 * NW) attn32_bwd_dq_kernel(AP<bf16_t> p, int nblocks) {
+    A32_WALK((attn32_bwd_dq_body<REL, DROP, NBUF, NW>(p, bid_)))
+}
 
 // =====================================================================================================================
 // backward dK, dV: block = 4 waves x 32 keys, 64 queries per step.  OWN_DELTA: delta = rowsum(dO * O) of each staged
@@ -981,8 +995,8 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
 }
 
 template <bool REL, bool DROP, int NBUF>
-__global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p) {
-    attn32_bwd_dkv_body<REL, DROP, NBUF, false>(p, blockIdx.x);
+__global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p, int nblocks) {
+    A32_WALK((attn32_bwd_dkv_body<REL, DROP, NBUF, false>(p, bid_)))
 }
 
 // Both backward roles in ONE launch (blocks [0, nq): dQ, blocks [nq, 2 nq): dK/dV with its own delta): at the estimator's
@@ -1019,12 +1033,23 @@ static int set_smem(K kernel, size_t bytes, const char* name) {
     return 0;
 }
 template <typename K>
-static int launch(K kernel, size_t sm, const AP<bf16_t>& p, hipStream_t st, const char* name, int nw = 4) {
+static int launch(K kernel, size_t sm, const AP<bf16_t>& p, hipStream_t st, const char* name, int nw = 4, int cap = 0) {
     if (set_smem(kernel, sm, name)) return -2;
-    dim3 grid((unsigned)((p.L + 32 * nw - 1) / (32 * nw)) * p.H * p.B);
-    hipLaunchKernelGGL(kernel, grid, dim3(64 * nw), sm, st, p);
+    const int nblocks = ((p.L + 32 * nw - 1) / (32 * nw)) * p.H * p.B;
+    int grid = nblocks;
+    if (cap >= 8 && cap < nblocks) {      // as few rounds as the cap allows, then the smallest grid (multiple of 8: block_map's XCD groups) with that many
+        const int c8 = cap & ~7, rounds = (nblocks + c8 - 1) / c8;
+        grid = (((nblocks + rounds - 1) / rounds) + 7) & ~7;
+        if (grid > c8) grid = c8;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * nw), sm, st, p, nblocks);
     CVFT_LAUNCH_CHECK(name);
     return 0;
+}
+// workgroups a rel-pos launch may keep resident at once (0: all): CVFT_ATTN_GRID
+static int rel_cap() {
+    static const int env = getenv("CVFT_ATTN_GRID") ? atoi(getenv("CVFT_ATTN_GRID")) : 0;
+    return env;
 }
 // Waves per block of the estimator's (additive-bias) launches: CVFT_ATTN_NW = 4 (default) | 8.  The eight-wave blocks use half the
 // CUs per launch (T = 250: 128 blocks of 8 waves instead of 256 of 4, two waves per SIMD, every K / V / Q / dO tile staged once
@@ -1044,8 +1069,8 @@ int cvft_attn32_fwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
         if (est_waves() == 8) return launch(attn32_fwd_kernel<false, false, 2, 8>, smem_fwd(false, 2), p, st, "attn32_fwd", 8);
         return launch(attn32_fwd_kernel<false, false, 2>, smem_fwd(false, 2), p, st, "attn32_fwd");
     }
-    if (p.drop_p > 0.f) return launch(attn32_fwd_kernel<true, true, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel_drop");
-    return launch(attn32_fwd_kernel<true, false, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel");
+    if (p.drop_p > 0.f) return launch(attn32_fwd_kernel<true, true, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel_drop", 4, rel_cap());
+    return launch(attn32_fwd_kernel<true, false, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel", 4, rel_cap());
 }
 int cvft_attn32_bwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
     using namespace a32;
@@ -1077,11 +1102,11 @@ int cvft_attn32_bwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
         return launch(attn32_bwd_dkv_kernel<false, false, 2>, smem_dkv(false, 2), p, st, "attn32_bwd_dkv");
     }
     if (p.drop_p > 0.f) {
-        rc = launch(attn32_bwd_dq_kernel<true, true, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel_drop");
+        rc = launch(attn32_bwd_dq_kernel<true, true, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel_drop", 4, rel_cap());
         if (rc) return rc;
-        return launch(attn32_bwd_dkv_kernel<true, true, 2>, smem_dkv(true, 2), p, st, "attn32_bwd_dkv_rel_drop");
+        return launch(attn32_bwd_dkv_kernel<true, true, 2>, smem_dkv(true, 2), p, st, "attn32_bwd_dkv_rel_drop", 4, 2 * rel_cap());
     }
-    rc = launch(attn32_bwd_dq_kernel<true, false, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel");
+    rc = launch(attn32_bwd_dq_kernel<true, false, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel", 4, rel_cap());
     if (rc) return rc;
-    return launch(attn32_bwd_dkv_kernel<true, false, 2>, smem_dkv(true, 2), p, st, "attn32_bwd_dkv_rel");
+    return launch(attn32_bwd_dkv_kernel<true, false, 2>, smem_dkv(true, 2), p, st, "attn32_bwd_dkv_rel", 4, 2 * rel_cap());
 }

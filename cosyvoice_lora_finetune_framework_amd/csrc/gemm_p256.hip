@@ -109,8 +109,9 @@ __device__ __forceinline__ void p256_epilogue_rows(const GP<bf16_t>& p, const fl
 
 __device__ unsigned long long cvft_p256_stamps[512 * 8];      // diagnostics (CVFT_P256_STAMP=1, tools/bench_p256.py stamps)
 
-template <bool DX, bool SK, bool STAMP = false>
-__global__ void __launch_bounds__(512, 2) gemm_p256_kernel(GP<bf16_t> p, P256X x) {
+// One work item (output tile, or a tile's k-split) of the launch; `item` of `nitems`.
+template <bool DX, bool SK, bool STAMP>
+__device__ __forceinline__ void p256_item(const GP<bf16_t>& p, const P256X& x, const int item, const int nitems) {
     typedef bf16_t T;
     constexpr int HALF = 16384, RING = 10;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -119,16 +120,16 @@ __global__ void __launch_bounds__(512, 2) gemm_p256_kernel(GP<bf16_t> p, P256X x
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int kg = lane >> 4, l15 = lane & 15;
-    const bool rec = STAMP && blockIdx.x < 512 && tid == 0;
-    unsigned long long* sb = cvft_p256_stamps + (blockIdx.x & 511) * 8;
+    const bool rec = STAMP && item < 512 && tid == 0;
+    unsigned long long* sb = cvft_p256_stamps + (item & 511) * 8;
     if (rec) sb[0] = __builtin_amdgcn_s_memrealtime();
 
     // ---- workgroup -> (tile, k-split).  XCD-aware: workgroups b and b + 8 share an XCD, so XCD x takes a contiguous range
     // of the tile order; the order walks bands of hb tile rows column-major, so a range of ~32 tiles is a near-square patch
     // (its A row panels and W column panels stay in that XCD's L2 while the patch streams through k in lock-step).
-    int bid = blockIdx.x;
+    int bid = item;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, rm = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int nwg = nitems, q = nwg >> 3, rm = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
     }
     const int tile = SK ? bid / x.S : bid;
@@ -497,6 +498,17 @@ __global__ void __launch_bounds__(512, 2) gemm_p256_kernel(GP<bf16_t> p, P256X x
     }
 }
 
+// The launch: gridDim.x workgroups walk the items gridDim.x apart.  gridDim.x == items is one item per workgroup (the plain
+// launch); a smaller grid (a multiple of 8, so that an item's index modulo 8 -- the XCD its neighbours share -- stays its
+// workgroup's) leaves CUs to the other chains of the step at the price of more rounds (CVFT_P256_GRID).
+template <bool DX, bool SK, bool STAMP = false>
+__global__ void __launch_bounds__(512, 2) gemm_p256_kernel(GP<bf16_t> p, P256X x, int nitems) {
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        p256_item<DX, SK, STAMP>(p, x, item, nitems);
+        if (item + (int)gridDim.x < nitems) __syncthreads();      // the next item's DMA re-uses the ring the epilogue staged through
+    }
+}
+
 // ---------------------------------------------------------------- host side
 namespace {
 // Split-K workspaces: a pool of equal-sized slots, one per launch stream (chains on different streams run concurrently; a
@@ -552,7 +564,23 @@ int p256_launch_t(const GP<bf16_t>& p, const P256X& x, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) { cvft_set_error("cvft_gemm: hipFuncSetAttribute(163840) failed: %s", hipGetErrorString(e)); return -2; }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(x.tiles_m * x.tiles_n * x.S)), dim3(512), 163840, st, p, x);
+    // Workgroups resident at once.  CVFT_P256_GRID: 0 = one per item, n = at most n; unset = auto: while three or more chains
+    // share the chip (cvft_set_concurrent_chains: the joint step) HALF the CUs, two items per workgroup.  This kernel owns every
+    // CU it runs on (160 KB of LDS); a 252-item launch on 252 CUs stops the step's two Flow chains -- ~1 000 short, dependent
+    // launches each, whose latency the step follows -- for its whole duration.  Measured in the step, same box, 40 steps
+    // (DESIGN section 14): joint 21.30 / 21.30 ms with one workgroup per item, 20.59 / 20.60 with 128, 21.03 with 88 (three
+    // rounds), although the launch itself goes from 45 to 65 us; alone on the chip (llm_only, one chain) the full grid stays.
+    static const int grid_set = getenv("CVFT_P256_GRID") ? atoi(getenv("CVFT_P256_GRID")) : -1;
+    const int grid_env = grid_set >= 0 ? grid_set : (cvft_concurrent_chains() >= 3 ? 128 : 0);
+    const int nitems = x.tiles_m * x.tiles_n * x.S;
+    int grid = nitems;
+    if (grid_env >= 8 && grid_env < nitems && !SK) {     // (split-K: the last arriver of a tile must not queue behind its own partners)
+        // rounds first (as few as the cap allows), then the smallest grid that still needs no more rounds: equal work per workgroup
+        const int cap = grid_env & ~7, rounds = (nitems + cap - 1) / cap;
+        grid = (((nitems + rounds - 1) / rounds) + 7) & ~7;
+        if (grid > cap) grid = cap;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 163840, st, p, x, nitems);
     cvft_set_kernel_label("gemm_p256_kernel<bf16,256,256,2,4,ring10>%s%s", SK ? ",splitk" : "", DX ? ",xdrop" : "");
     CVFT_LAUNCH_CHECK("cvft_gemm");
     return 0;
@@ -591,7 +619,9 @@ int gemm_p256_launch(const GP<bf16_t>& p_in, hipStream_t st) {
         // auto: LLM-sized launches only -- at least ~3/4 of a round of tiles (after splitting) and a k-loop that amortises the
         // prologue / epilogue; everything else is faster on two co-resident 128x128 blocks per CU or on the 64x64 tiles
         if (p.M < 2048 || x.nk_total < 8) return 1;
-        if (tiles * S < 192) return 1;
+        static const int narrow_env = getenv("CVFT_P256_NARROW") ? atoi(getenv("CVFT_P256_NARROW")) : 0;
+        // (CVFT_P256_NARROW=n: also launches of n .. 191 tiles, one per CU on a third of the chip -- the N = 1024 shapes at M ~ 5 000)
+        if (tiles * S < 192 && !(narrow_env > 0 && tiles * S >= narrow_env)) return 1;
     }
     // Row split: a grid between one and ~1.6 rounds of the 256 CUs (N = 4096 at M = 5328: 336 tiles) would hold the chip for two
     // rounds.  The first 256 / tiles_n tile rows make exactly <= one round here; the rows behind them go to gemm_glds.hip's
