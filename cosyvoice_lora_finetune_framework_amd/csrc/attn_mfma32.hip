@@ -250,10 +250,14 @@ DEV void fwd_scores(f32x16 (&s)[2], const bf16_t* Kc, const bf16x8 (&qu)[4], con
 // NW = waves (x 32 queries) per block: 4, or 8 for the estimator's launches while other chains share the chip -- one block per
 // (batch, head) at T <= 256 instead of two, i.e. the same waves on HALF the CUs with two waves per SIMD (a 4-wave block per CU runs
 // one wave per SIMD with every latency exposed and still owns the CU's time), and every K / V tile staged once per 256 queries.
-template <bool REL, bool DROP, int NBUF, int NW = 4>
+// WHOLE (additive-bias form, L <= 64 NBUF): every K / V tile of the (batch, head) is staged ONCE in the prologue (NBUF tiles each)
+// and the step loop runs without staging stores, prefetch waits or barriers -- at the estimator's mid-block length (T = 250: four
+// tiles) a block's whole K and V are 74 KB, and the loop's per-step barrier + staging were a third of a step.
+template <bool REL, bool DROP, int NBUF, int NW = 4, bool WHOLE = false>
 DEV void attn32_fwd_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
     static_assert(NW == 4 || (NW == 8 && !REL), "eight-wave blocks: additive-bias (estimator) form only");
+    static_assert(!WHOLE || !REL, "whole-sequence staging: additive-bias (estimator) form only");
     constexpr int NT_ = 64 * NW, QB = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
@@ -306,8 +310,24 @@ DEV void attn32_fwd_body(const AP<bf16_t>& p, const int bid) {
     f32x16 gcarry = zero16();
     bf16x8 pf0[4], pf1[4];
     Tile2 kr, vr;
+    if constexpr (WHOLE) {      // all loads first (one memory round trip), then all stores, one barrier
+        Tile2 ka[NBUF], va[NBUF];
+#pragma unroll
+        for (int t = 0; t < NBUF; ++t) {
+            tload<NT_>(ka[t], kg, p.ld, 64 * t, L, tid);
+            tload<NT_>(va[t], vg, p.ld, 64 * t, L, tid);
+        }
+#pragma unroll
+        for (int t = 0; t < NBUF; ++t) {
+            tstore<NT_>(ka[t], Ks + t * TILE, tid);
+            tstore<NT_>(va[t], Vs + t * TILE, tid);
+        }
+        touch(qu);
+        __syncthreads();
+    } else {
     tload<NT_>(kr, kg, p.ld, 0, L, tid);      // unconditional: nothing here waits for len[b]
     tload<NT_>(vr, vg, p.ld, 0, L, tid);
+    }
     if (REL) {
         bf16x8 t0[4];
         wave_frag_load(t0, pg, p.ldp, mlo0 + l31, M2 + 1, hf);
@@ -316,11 +336,13 @@ DEV void attn32_fwd_body(const AP<bf16_t>& p, const int bid) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) gcarry = mfma(t0[s], qv[s], gcarry);
     }
+    if constexpr (!WHOLE) {
     tstore<NT_>(kr, Ks, tid);
     touch(qu);
     if (REL) touch(qv);
     tload<NT_>(kr, kg, p.ld, 64, L, tid);
     __syncthreads();
+    }
 
     float* Gw = Gs + w * 32 * SKW + l31 * SKW;
     f32x16 s[2];
@@ -333,12 +355,14 @@ DEV void attn32_fwd_body(const AP<bf16_t>& p, const int bid) {
             wave_frag_load(pf1, pg, p.ldp, mlo0 + 128 + l31, M2 + 1, hf);
         }
     }
+    if constexpr (!WHOLE) {
     if (NBUF == 1) __syncthreads();
     tstore<NT_>(kr, Ks + (1 % NBUF) * TILE, tid);
     tstore<NT_>(vr, Vs, tid);
     tload<NT_>(kr, kg, p.ld, 128, L, tid);
     tload<NT_>(vr, vg, p.ld, 64, L, tid);
     __syncthreads();
+    }
 
     float m_run = NINF, l_run = 0.f;
     f32x16 oacc[2], lacc;
@@ -454,6 +478,7 @@ DEV void attn32_fwd_body(const AP<bf16_t>& p, const int bid) {
             }
         }
         STAMP(1);          // next QK^T (+ band, skew)
+        if constexpr (!WHOLE) {
         if (NBUF == 1) __syncthreads();
         STAMP(6);          // barrier 1 (single-buffer only) / idle of waves that skipped the step
         tstore<NT_>(kr, Ks + ((t + 2) % NBUF) * TILE, tid);      // (past the end: dead stores of a re-loaded last tile)
@@ -463,6 +488,7 @@ DEV void attn32_fwd_body(const AP<bf16_t>& p, const int bid) {
         STAMP(7);          // wait for the prefetch + LDS stores + next loads issued
         __syncthreads();
         STAMP(8);          // barrier 2
+        }
     }
 
     if (i < L) {
@@ -489,18 +515,19 @@ DEV void attn32_fwd_body(const AP<bf16_t>& p, const int bid) {
         BODY_;                                                                                 \
         if (bid_ + (int)gridDim.x < nblocks) __syncthreads();                                  \
     }
-template <bool REL, bool DROP, int NBUF, int NW = 4>
+template <bool REL, bool DROP, int NBUF, int NW = 4, bool WHOLE = false>
 __global__ void __launch_bounds__(64 * NW) attn32_fwd_kernel(AP<bf16_t> p, int nblocks) {
-    A32_WALK((attn32_fwd_body<REL, DROP, NBUF, NW>(p, bid_)))
+    A32_WALK((attn32_fwd_body<REL, DROP, NBUF, NW, WHOLE>(p, bid_)))
 }
 
 // =====================================================================================================================
 // backward dQ: block = 4 waves x 32 queries, 64 keys per step
 // =====================================================================================================================
-template <bool REL, bool DROP, int NBUF, int NW = 4>
+template <bool REL, bool DROP, int NBUF, int NW = 4, bool WHOLE = false>
 DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
     static_assert(NW == 4 || (NW == 8 && !REL), "eight-wave blocks: additive-bias (estimator) form only");
+    static_assert(!WHOLE || !REL, "whole-sequence staging: additive-bias (estimator) form only");
     constexpr int NT_ = 64 * NW, QB = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
@@ -593,6 +620,22 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
             tstore<NT_>(br2, Pb + 128 * LDK, tid);                                  \
         }                                                                      \
     } while (0)
+    if constexpr (WHOLE) {      // (see attn32_fwd_body) all K / V tiles once, barrier-free step loop
+        Tile2 ka[NBUF], va[NBUF];
+#pragma unroll
+        for (int t = 0; t < NBUF; ++t) {
+            tload<NT_>(ka[t], kg, p.ld, 64 * t, L, tid);
+            tload<NT_>(va[t], vg, p.ld, 64 * t, L, tid);
+        }
+#pragma unroll
+        for (int t = 0; t < NBUF; ++t) {
+            tstore<NT_>(ka[t], Ks + t * TILE, tid);
+            tstore<NT_>(va[t], Vs + t * TILE, tid);
+        }
+        touch(qu);
+        touch(dof);
+        __syncthreads();
+    } else {
     A32_DQ_PREFETCH(0);      // unconditional: nothing here waits for len[b]
     A32_DQ_PUBLISH(0);
     touch(qu);
@@ -600,6 +643,7 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
     if (REL) touch(qv);
     A32_DQ_PREFETCH(64);
     __syncthreads();
+    }
 
     f32x16 dqacc[2];
     dqacc[0] = zero16();
@@ -709,10 +753,12 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
                 LDS_FENCE();
             }
         }
+        if constexpr (!WHOLE) {
         if (NBUF == 1 || REL) __syncthreads();
         A32_DQ_PUBLISH((t + 1) % NBUF);
         A32_DQ_PREFETCH(64 * (t + 2));
         __syncthreads();
+        }
     }
 
     if (i < L) {
@@ -728,7 +774,7 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
 
 template <bool REL, bool DROP, int NBUF, int NW = 4>
 __global__ void __launch_bounds__(64 * NW) attn32_bwd_dq_kernel(AP<bf16_t> p, int nblocks) {
-    A32_WALK((attn32_bwd_dq_body<REL, DROP, NBUF, NW>(p, bid_)))
+    A32_WALK((attn32_bwd_dq_body<REL, DROP, NBUF, NW, false>(p, bid_)))
 }
 
 // =====================================================================================================================
@@ -736,10 +782,11 @@ __global__ void __launch_bounds__(64 * NW) attn32_bwd_dq_kernel(AP<bf16_t> p, in
 // query tile is formed here from the prefetch registers instead of read from the dQ kernel's output -- the two backward
 // roles then have no dependency and can share one launch (attn32_bwd_fused_kernel).
 // =====================================================================================================================
-template <bool REL, bool DROP, int NBUF, bool OWN_DELTA, int NW = 4>
+template <bool REL, bool DROP, int NBUF, bool OWN_DELTA, int NW = 4, bool WHOLE = false>
 DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
     static_assert(NW == 4 || (NW == 8 && !REL), "eight-wave blocks: additive-bias (estimator) form only");
+    static_assert(!WHOLE || (!REL && OWN_DELTA), "whole-sequence staging: additive-bias (estimator) form with its own delta only");
     constexpr int NT_ = 64 * NW, QB = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
@@ -839,6 +886,28 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
             }                                                                              \
         }                                                                                  \
     } while (0)
+        if constexpr (WHOLE) {      // (see attn32_fwd_body) all Q / dO tiles (+ lse, delta) once, barrier-free step loop
+            Tile2 qa4[NBUF], da4[NBUF], oa4[NBUF];
+            float ls4[NBUF];
+#pragma unroll
+            for (int t = 0; t < NBUF; ++t) {
+                tload<NT_>(qa4[t], qg, p.ld, 64 * t, L, tid);
+                tload<NT_>(da4[t], dog, p.ldo, 64 * t, L, tid);
+                tload<NT_>(oa4[t], og, p.ldo, 64 * t, L, tid);
+                ls4[t] = p.lse[((size_t)b * p.H + hh) * L + min(64 * t + (tid & 63), L - 1)];
+            }
+#pragma unroll
+            for (int t = 0; t < NBUF; ++t) {
+                qr[0] = qa4[t][0]; qr[1] = qa4[t][1];
+                dor[0] = da4[t][0]; dor[1] = da4[t][1];
+                orr[0] = oa4[t][0]; orr[1] = oa4[t][1];
+                lse_n = ls4[t];
+                A32_KV_PUBLISH(t, 64 * t);
+            }
+            touch(kf);
+            touch(vf);
+            __syncthreads();
+        } else {
         A32_KV_PREFETCH(ibeg);
         A32_KV_PUBLISH(0, ibeg);
         touch(kf);
@@ -850,6 +919,7 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
         }
         A32_KV_PREFETCH(ibeg + 64);
         __syncthreads();
+        }
         float* Gw = Gs + w * 32 * SK2;
 
         for (int t = 0; t < nt; ++t) {
@@ -966,10 +1036,12 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
                     }
                 }
             }
+            if constexpr (!WHOLE) {
             if (NBUF == 1) __syncthreads();
             A32_KV_PUBLISH((t + 1) % NBUF, ibeg + 64 * (t + 1));
             A32_KV_PREFETCH(ibeg + 64 * (t + 2));
             __syncthreads();
+            }
         }
         if (REL) {      // dK_j += (sum_i dS[i,j]) u   (the A operand of dK was raw q)
             const float cs = xh_sum(csum);
@@ -1002,10 +1074,10 @@ __global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p, int n
 // Both backward roles in ONE launch (blocks [0, nq): dQ, blocks [nq, 2 nq): dK/dV with its own delta): at the estimator's
 // sizes a role alone is one 4-wave block per CU (T = 250: 256 blocks), i.e. one wave per SIMD with every latency
 // exposed; together they put two waves on a SIMD, and one launch boundary per attention backward disappears.
-template <bool REL, bool DROP, int NBUF, int NW = 4>
+template <bool REL, bool DROP, int NBUF, int NW = 4, bool WHOLE = false>
 __global__ void __launch_bounds__(64 * NW) attn32_bwd_fused_kernel(AP<bf16_t> p, int nq) {
-    if ((int)blockIdx.x < nq) attn32_bwd_dq_body<REL, DROP, NBUF, NW>(p, blockIdx.x);
-    else attn32_bwd_dkv_body<REL, DROP, NBUF, true, NW>(p, blockIdx.x - nq);
+    if ((int)blockIdx.x < nq) attn32_bwd_dq_body<REL, DROP, NBUF, NW, WHOLE>(p, blockIdx.x);
+    else attn32_bwd_dkv_body<REL, DROP, NBUF, true, NW, WHOLE>(p, blockIdx.x - nq);
 }
 
 // =====================================================================================================================
@@ -1056,6 +1128,11 @@ static int rel_cap() {
 // per 256 rows) at a few microseconds more latency per launch; measured in the step, same box, 40 steps: joint 21.08 / 21.08 (4)
 // vs 21.23 / 21.26 ms (8), flow_only 14.24 vs 14.36 -- the Flow chains' latency counts for more than the CU-time they free
 // (DESIGN section 14), so the four-wave blocks stay the default and the eight-wave instantiations an opt-in (parity-tested).
+// whole-sequence staging for L <= 256 (CVFT_ATTN_WHOLE = 0 | 1, default 1)
+static int est_whole() {
+    static const int env = getenv("CVFT_ATTN_WHOLE") ? atoi(getenv("CVFT_ATTN_WHOLE")) : 1;
+    return env;
+}
 static int est_waves() {
     static const int env = getenv("CVFT_ATTN_NW") ? atoi(getenv("CVFT_ATTN_NW")) : 0;
     return env == 8 ? 8 : 4;
@@ -1067,6 +1144,7 @@ int cvft_attn32_fwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
     using namespace a32;
     if (!rel) {
         if (est_waves() == 8) return launch(attn32_fwd_kernel<false, false, 2, 8>, smem_fwd(false, 2), p, st, "attn32_fwd", 8);
+        if (est_whole() && p.L <= 256) return launch(attn32_fwd_kernel<false, false, 4, 4, true>, smem_fwd(false, 4), p, st, "attn32_fwd_whole");
         return launch(attn32_fwd_kernel<false, false, 2>, smem_fwd(false, 2), p, st, "attn32_fwd");
     }
     if (p.drop_p > 0.f) return launch(attn32_fwd_kernel<true, true, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel_drop", 4, rel_cap());
@@ -1087,6 +1165,14 @@ int cvft_attn32_bwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
             const int nq = ((p.L + 255) / 256) * p.H * p.B;
             hipLaunchKernelGGL((attn32_bwd_fused_kernel<false, false, 2, 8>), dim3(2u * nq), dim3(512), sm, st, p, nq);
             CVFT_LAUNCH_CHECK("attn32_bwd_fused");
+            return 0;
+        }
+        if (!split && est_whole() && p.L <= 256) {
+            const size_t sm = smem_dq(false, 4) > smem_dkv(false, 4) ? smem_dq(false, 4) : smem_dkv(false, 4);
+            if (set_smem(attn32_bwd_fused_kernel<false, false, 4, 4, true>, sm, "attn32_bwd_fused_whole")) return -2;
+            const int nq = ((p.L + 127) / 128) * p.H * p.B;
+            hipLaunchKernelGGL((attn32_bwd_fused_kernel<false, false, 4, 4, true>), dim3(2u * nq), dim3(256), sm, st, p, nq);
+            CVFT_LAUNCH_CHECK("attn32_bwd_fused_whole");
             return 0;
         }
         if (!split) {

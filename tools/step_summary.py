@@ -30,7 +30,7 @@ for st in steps:
         groups[key] += 1
         gtime[key] += (e - s)
 top = [{"kernel": k, "launches_per_step": groups[k] / nsteps, "ms_per_step": gtime[k] / nsteps / 1e6}
-       for k, _ in gtime.most_common(25)]
+       for k, _ in gtime.most_common(70)]
 json.dump({"csrc_sha16": csrc_sha16(), "workload": workload, "batch": batch, "frames": frames, "steps_averaged": nsteps, "launches_per_step": launches,
            "kernel_ms_per_step": kms, "step_span_ms_under_profiler": span, "top_kernels": top,
            "note": "rocprofv3 --kernel-trace serialises nothing but adds per-dispatch overhead: the span is longer than the un-profiled step"},
