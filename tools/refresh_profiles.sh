@@ -9,10 +9,11 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/prof.log 2>&1
 cp "$(find $OUT/prof -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
 python tools/step_summary.py "$(find $OUT/prof -name '*kernel_trace.csv' | head -1)" $OUT/step_summary.json joint 16 500
+python tools/cu_time.py "$(find $OUT/prof -name '*kernel_trace.csv' | head -1)" 5 40 > $OUT/cu_time.txt || true
 rm -rf $OUT/prof
 # (the bench line takes launches / kernel time per step from the newest profiles/*step_summary*.json: this build's trace first)
-cp $OUT/step_summary.json profiles/r3_step_summary.json
-python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.log 2>&1
+cp $OUT/step_summary.json profiles/r4_step_summary.json
+CVFT_BENCH_DUMP_PROFILE=$OUT/insitu_gemm_table.txt python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.log 2>&1
 tail -1 $OUT/bench_n1.log > $OUT/bench_n1.json
 python tools/counters.py collect $OUT/counters > $OUT/counters.log 2>&1
 python tools/counters.py summarise $OUT/counters $OUT/counters.json > $OUT/counters.txt
@@ -20,6 +21,7 @@ F=$(find $OUT/counters/fetch -name '*counter_collection.csv' | head -1)
 W=$(find $OUT/counters/write -name '*counter_collection.csv' | head -1)
 python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi64ELi64ELi2ELi2ELi0ELi4ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,64,64,2,2,ns4,regepi>' $OUT/pmc_traffic.json
 python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi128ELi128ELi4ELi2ELi0ELi2ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,128,128,4,2,ns2,regepi>' $OUT/pmc_traffic_128x128.json
+python tools/pmc_traffic.py $F $W 'gemm_p256_kernel' 'gemm_p256_kernel<bf16,256,256,2,4,ring10>' $OUT/pmc_traffic_p256.json || true
 python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi96ELi256ELi3ELi4ELi0ELi3ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,96,256,3,4,ns3,regepi>' $OUT/pmc_traffic_96x256.json || true
 python tools/pmc_traffic.py $F $W 'block_tail_fwd_kernel' 'block_tail_fwd' $OUT/pmc_traffic_block_tail_fwd.json || true
 python tools/pmc_traffic.py $F $W 'block_qkv_wide_fwd_kernel' 'block_qkv_wide_fwd' $OUT/pmc_traffic_block_qkv_fwd.json || true
