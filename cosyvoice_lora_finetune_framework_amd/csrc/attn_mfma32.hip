@@ -507,17 +507,12 @@ DEV void attn32_fwd_body(const AP<bf16_t>& p, const int bid) {
     STAMP(9);              // epilogue
     STAMP_FLUSH();
 }
-// Launch shape shared by the kernels of this file: gridDim.x workgroups walk `nblocks` owner blocks gridDim.x apart.  A grid
-// smaller than nblocks (CVFT_ATTN_GRID: the rel-pos launches of the LLM chain) keeps the launch on a share of the CUs and leaves
-// the rest to the step's other chains; the barrier separates two blocks' use of the staging LDS.
-#define A32_WALK(BODY_)                                                                         \
-    for (int bid_ = blockIdx.x; bid_ < nblocks; bid_ += gridDim.x) {                           \
-        BODY_;                                                                                 \
-        if (bid_ + (int)gridDim.x < nblocks) __syncthreads();                                  \
-    }
+// (A grid-strided form of these launches -- a capped grid walking the owner blocks, as gemm_p256.hip does -- was measured and
+// dropped: a cap of 128 / 192 / 96 resident blocks on the rel-pos launches cost the joint step +0.3 / +0.07 / +1.7 ms, and the
+// loop wrapper alone slowed the rel-pos forward from 24 to 32 us per launch.)
 template <bool REL, bool DROP, int NBUF, int NW = 4, bool WHOLE = false>
-__global__ void __launch_bounds__(64 * NW) attn32_fwd_kernel(AP<bf16_t> p, int nblocks) {
-    A32_WALK((attn32_fwd_body<REL, DROP, NBUF, NW, WHOLE>(p, bid_)))
+__global__ void __launch_bounds__(64 * NW) attn32_fwd_kernel(AP<bf16_t> p) {
+    attn32_fwd_body<REL, DROP, NBUF, NW, WHOLE>(p, blockIdx.x);
 }
 
 // =====================================================================================================================
@@ -773,8 +768,8 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
 }
 
 template <bool REL, bool DROP, int NBUF, int NW = 4>
-__global__ void __launch_bounds__(64 * NW) attn32_bwd_dq_kernel(AP<bf16_t> p, int nblocks) {
-    A32_WALK((attn32_bwd_dq_body<REL, DROP, NBUF, NW, false>(p, bid_)))
+__global__ void __launch_bounds__(64 * NW) attn32_bwd_dq_kernel(AP<bf16_t> p) {
+    attn32_bwd_dq_body<REL, DROP, NBUF, NW, false>(p, blockIdx.x);
 }
 
 // =====================================================================================================================
@@ -1067,8 +1062,8 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
 }
 
 template <bool REL, bool DROP, int NBUF>
-__global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p, int nblocks) {
-    A32_WALK((attn32_bwd_dkv_body<REL, DROP, NBUF, false>(p, bid_)))
+__global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p) {
+    attn32_bwd_dkv_body<REL, DROP, NBUF, false>(p, blockIdx.x);
 }
 
 // Both backward roles in ONE launch (blocks [0, nq): dQ, blocks [nq, 2 nq): dK/dV with its own delta): at the estimator's
@@ -1105,29 +1100,13 @@ static int set_smem(K kernel, size_t bytes, const char* name) {
     return 0;
 }
 template <typename K>
-static int launch(K kernel, size_t sm, const AP<bf16_t>& p, hipStream_t st, const char* name, int nw = 4, int cap = 0) {
+static int launch(K kernel, size_t sm, const AP<bf16_t>& p, hipStream_t st, const char* name, int nw = 4) {
     if (set_smem(kernel, sm, name)) return -2;
-    const int nblocks = ((p.L + 32 * nw - 1) / (32 * nw)) * p.H * p.B;
-    int grid = nblocks;
-    if (cap >= 8 && cap < nblocks) {      // as few rounds as the cap allows, then the smallest grid (multiple of 8: block_map's XCD groups) with that many
-        const int c8 = cap & ~7, rounds = (nblocks + c8 - 1) / c8;
-        grid = (((nblocks + rounds - 1) / rounds) + 7) & ~7;
-        if (grid > c8) grid = c8;
-    }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * nw), sm, st, p, nblocks);
+    dim3 grid((unsigned)((p.L + 32 * nw - 1) / (32 * nw)) * p.H * p.B);
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * nw), sm, st, p);
     CVFT_LAUNCH_CHECK(name);
     return 0;
 }
-// workgroups a rel-pos launch may keep resident at once (0: all): CVFT_ATTN_GRID
-static int rel_cap() {
-    static const int env = getenv("CVFT_ATTN_GRID") ? atoi(getenv("CVFT_ATTN_GRID")) : 0;
-    return env;
-}
-// Waves per block of the estimator's (additive-bias) launches: CVFT_ATTN_NW = 4 (default) | 8.  The eight-wave blocks use half the
-// CUs per launch (T = 250: 128 blocks of 8 waves instead of 256 of 4, two waves per SIMD, every K / V / Q / dO tile staged once
-// per 256 rows) at a few microseconds more latency per launch; measured in the step, same box, 40 steps: joint 21.08 / 21.08 (4)
-// vs 21.23 / 21.26 ms (8), flow_only 14.24 vs 14.36 -- the Flow chains' latency counts for more than the CU-time they free
-// (DESIGN section 14), so the four-wave blocks stay the default and the eight-wave instantiations an opt-in (parity-tested).
 // whole-sequence staging for L <= 256 (CVFT_ATTN_WHOLE = 0 | 1, default 1)
 static int est_whole() {
     static const int env = getenv("CVFT_ATTN_WHOLE") ? atoi(getenv("CVFT_ATTN_WHOLE")) : 1;
@@ -1147,8 +1126,8 @@ int cvft_attn32_fwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
         if (est_whole() && p.L <= 256) return launch(attn32_fwd_kernel<false, false, 4, 4, true>, smem_fwd(false, 4), p, st, "attn32_fwd_whole");
         return launch(attn32_fwd_kernel<false, false, 2>, smem_fwd(false, 2), p, st, "attn32_fwd");
     }
-    if (p.drop_p > 0.f) return launch(attn32_fwd_kernel<true, true, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel_drop", 4, rel_cap());
-    return launch(attn32_fwd_kernel<true, false, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel", 4, rel_cap());
+    if (p.drop_p > 0.f) return launch(attn32_fwd_kernel<true, true, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel_drop");
+    return launch(attn32_fwd_kernel<true, false, 1>, smem_fwd(true, 1), p, st, "attn32_fwd_rel");
 }
 int cvft_attn32_bwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
     using namespace a32;
@@ -1188,11 +1167,11 @@ int cvft_attn32_bwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
         return launch(attn32_bwd_dkv_kernel<false, false, 2>, smem_dkv(false, 2), p, st, "attn32_bwd_dkv");
     }
     if (p.drop_p > 0.f) {
-        rc = launch(attn32_bwd_dq_kernel<true, true, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel_drop", 4, rel_cap());
+        rc = launch(attn32_bwd_dq_kernel<true, true, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel_drop");
         if (rc) return rc;
-        return launch(attn32_bwd_dkv_kernel<true, true, 2>, smem_dkv(true, 2), p, st, "attn32_bwd_dkv_rel_drop", 4, 2 * rel_cap());
+        return launch(attn32_bwd_dkv_kernel<true, true, 2>, smem_dkv(true, 2), p, st, "attn32_bwd_dkv_rel_drop");
     }
-    rc = launch(attn32_bwd_dq_kernel<true, false, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel", 4, rel_cap());
+    rc = launch(attn32_bwd_dq_kernel<true, false, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel");
     if (rc) return rc;
-    return launch(attn32_bwd_dkv_kernel<true, false, 2>, smem_dkv(true, 2), p, st, "attn32_bwd_dkv_rel", 4, 2 * rel_cap());
+    return launch(attn32_bwd_dkv_kernel<true, false, 2>, smem_dkv(true, 2), p, st, "attn32_bwd_dkv_rel");
 }
