@@ -758,15 +758,16 @@ static AP<T> make_ap(int B, int H, int L, const void* q, const void* k, const vo
     AP<T> a;
     a.B = B; a.H = H; a.L = L; a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.ld = ld;
     a.p = (const T*)pp; a.ldp = ldp; a.bu = bu; a.bv = bv; a.len = len; a.causal = causal; a.scale = scale;
-    a.o = nullptr; a.ldo = 0; a.lse = nullptr; a.d_o = nullptr; a.delta = nullptr; a.dq = a.dk = a.dv = nullptr; a.ldg = 0;
+    a.o = nullptr; a.o_lo = nullptr; a.ldo = 0; a.lse = nullptr; a.d_o = nullptr; a.delta = nullptr; a.dq = a.dk = a.dv = nullptr; a.ldg = 0;
     a.drop_p = 0.f; a.seed = nullptr; a.site = 0; a.iso = 0; a.dpos = nullptr; a.lddpos = 0;
     return a;
 }
 
 extern "C" int cvft_attn_bias_fwd(int dtype, int B, int H, int T_, const void* q, const void* k, const void* v, int ld,
-                                  const int32_t* klen, float scale, int iso_len, void* o, int ldo, float* lse, void* stream) {
+                                  const int32_t* klen, float scale, int iso_len, void* o, int ldo, float* lse, void* o_lo, void* stream) {
     if (check_common("cvft_attn_bias_fwd", dtype, B, H, T_, ld, ldo, q, k, v)) return -1;
     CVFT_CHECK_ARG(o && lse, "cvft_attn_bias_fwd: null output");
+    CVFT_CHECK_ARG(!o_lo || (dtype == CVFT_BF16 && (((uintptr_t)o_lo) & 7) == 0), "cvft_attn_bias_fwd: o_lo is a bf16 buffer (8-byte aligned) or NULL");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CVFT_F32) {
         AP<float> a = make_ap<float>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
@@ -775,14 +776,17 @@ extern "C" int cvft_attn_bias_fwd(int dtype, int B, int H, int T_, const void* q
     }
     AP<bf16_t> a = make_ap<bf16_t>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
     a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse; a.iso = (iso_len > 0 && iso_len < T_) ? iso_len : 0;
+    a.o_lo = (bf16_t*)o_lo;
     if (!attn_v1() && al8(o) && ldo % 4 == 0) return cvft_attn32_fwd(a, 0, st);
+    if (o_lo) CVFT_HIP_CHECK_RET(hipMemsetAsync(o_lo, 0, (size_t)B * T_ * ldo * sizeof(bf16_t), st), "cvft_attn_bias_fwd");    // (the generic kernels write no residual)
     return launch_fwd<bf16_t, false>(a, st);
 }
 
 extern "C" int cvft_attn_bias_bwd(int dtype, int B, int H, int T_, const void* q, const void* k, const void* v, int ld,
                                   const int32_t* klen, float scale, int iso_len, const void* o, const void* d_o, int ldo,
-                                  const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg, void* stream) {
+                                  const float* lse, const void* o_lo, float* delta, void* dq, void* dk, void* dv, int ldg, void* stream) {
     if (check_common("cvft_attn_bias_bwd", dtype, B, H, T_, ld, ldo, q, k, v)) return -1;
+    CVFT_CHECK_ARG(!o_lo || (dtype == CVFT_BF16 && (((uintptr_t)o_lo) & 15) == 0), "cvft_attn_bias_bwd: o_lo is a bf16 buffer (16-byte aligned) or NULL");
     CVFT_CHECK_ARG(o && d_o && lse && delta && dq && dk && dv && ldg >= H * 64, "cvft_attn_bias_bwd: bad args");
     CVFT_CHECK_ARG((((uintptr_t)d_o) & 15) == 0, "cvft_attn_bias_bwd: dO must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -797,6 +801,7 @@ extern "C" int cvft_attn_bias_bwd(int dtype, int B, int H, int T_, const void* q
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.iso = (iso_len > 0 && iso_len < T_) ? iso_len : 0;
     if (!attn_v1() && al8(dq, dk, dv, o) && ldg % 4 == 0) {
         a.o = (bf16_t*)o;
+        a.o_lo = (bf16_t*)o_lo;
         return cvft_attn32_bwd(a, 0, st);
     }
     return launch_bwd<bf16_t, false>(a, delta, (const bf16_t*)o, st);
@@ -804,9 +809,10 @@ extern "C" int cvft_attn_bias_bwd(int dtype, int B, int H, int T_, const void* q
 
 extern "C" int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
                                     const void* pp, int ldp, const float* bias_u, const float* bias_v,
-                                    const int32_t* len, int causal, float scale, void* o, int ldo, float* lse,
+                                    const int32_t* len, int causal, float scale, void* o, int ldo, float* lse, void* o_lo,
                                     float drop_p, const int64_t* drop_seed, unsigned drop_site, void* stream) {
     if (check_common("cvft_attn_relpos_fwd", dtype, B, H, L, ld, ldo, q, k, v)) return -1;
+    CVFT_CHECK_ARG(!o_lo || (dtype == CVFT_BF16 && (((uintptr_t)o_lo) & 7) == 0), "cvft_attn_relpos_fwd: o_lo is a bf16 buffer (8-byte aligned) or NULL");
     CVFT_CHECK_ARG(cvft_drop_rate_ok(drop_p) && (drop_p == 0.f || drop_seed), "cvft_attn_relpos_fwd: bad dropout args (p == 0 or 2^-16 <= p <= 1 - 2^-16, seed)");
     int vec = dtype == CVFT_BF16 ? 8 : 4;
     CVFT_CHECK_ARG(pp && bias_u && bias_v && o && lse && ldp >= H * 64 && ldp % vec == 0 && (((uintptr_t)pp) & 15) == 0,
@@ -821,16 +827,19 @@ extern "C" int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* 
     AP<bf16_t> a = make_ap<bf16_t>(B, H, L, q, k, v, ld, pp, ldp, bias_u, bias_v, len, causal, scale);
     a.o = (bf16_t*)o; a.ldo = ldo; a.lse = lse;
     a.drop_p = drop_p; a.seed = (const long long*)drop_seed; a.site = drop_site;
+    a.o_lo = (bf16_t*)o_lo;
     if (!attn_v1() && al8(o) && ldo % 4 == 0) return cvft_attn32_fwd(a, 1, st);
+    if (o_lo) CVFT_HIP_CHECK_RET(hipMemsetAsync(o_lo, 0, (size_t)B * L * ldo * sizeof(bf16_t), st), "cvft_attn_relpos_fwd");
     return launch_fwd<bf16_t, true>(a, st);
 }
 
 extern "C" int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
                                     const void* pp, int ldp, const float* bias_u, const float* bias_v,
                                     const int32_t* len, int causal, float scale, const void* o, const void* d_o, int ldo,
-                                    const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg, float* dp,
+                                    const float* lse, const void* o_lo, float* delta, void* dq, void* dk, void* dv, int ldg, float* dp,
                                     float drop_p, const int64_t* drop_seed, unsigned drop_site, void* stream) {
     if (check_common("cvft_attn_relpos_bwd", dtype, B, H, L, ld, ldo, q, k, v)) return -1;
+    CVFT_CHECK_ARG(!o_lo || (dtype == CVFT_BF16 && (((uintptr_t)o_lo) & 15) == 0), "cvft_attn_relpos_bwd: o_lo is a bf16 buffer (16-byte aligned) or NULL");
     CVFT_CHECK_ARG(cvft_drop_rate_ok(drop_p) && (drop_p == 0.f || drop_seed), "cvft_attn_relpos_bwd: bad dropout args (p == 0 or 2^-16 <= p <= 1 - 2^-16, seed)");
     int vec = dtype == CVFT_BF16 ? 8 : 4;
     CVFT_CHECK_ARG(pp && bias_u && bias_v && ldp >= H * 64 && ldp % vec == 0 && (((uintptr_t)pp) & 15) == 0,
@@ -853,6 +862,7 @@ extern "C" int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* 
     a.dpos = dp; a.lddpos = H * 64;
     if (!dp && !attn_v1() && al8(dq, dk, dv, o) && ldg % 4 == 0) {      // (dP is served by the generic kernels)
         a.o = (bf16_t*)o;
+        a.o_lo = (bf16_t*)o_lo;
         return cvft_attn32_bwd(a, 1, st);
     }
     return launch_bwd<bf16_t, true>(a, delta, (const bf16_t*)o, st);

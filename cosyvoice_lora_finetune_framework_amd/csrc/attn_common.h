@@ -26,6 +26,12 @@ struct AP {
     const int* len;
     int causal; float scale;
     T* o; int ldo; float* lse;
+    // bf16 kernels (attn_mfma32.hip): o_lo = bf16(O - bf16(O)), the part of the fp32 output the bf16 store drops, written by the
+    // forward and read by the backward for delta = rowsum(dO . (O + O_lo)) -- with delta taken from the bf16-ROUNDED O alone the
+    // score gradient dS = P (dP - delta) carried a common-mode error per query row that dominated dQ / dK wherever dP is nearly
+    // constant over the keys (flat softmax over value rows that share a large mean: the estimator's mid blocks; 3 % .. 12 % on
+    // dQ / dK against 0.17 % with the residual, tools/delta_error_model.py).  Same pitch as o; null = off.
+    T* o_lo;
     const T* d_o; const float* delta;
     T *dq, *dk, *dv; int ldg;
     // attention-probability dropout (attention.py:118 `self.dropout(attn)`; DROP instantiations only)

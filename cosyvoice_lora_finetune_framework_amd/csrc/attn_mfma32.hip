@@ -501,6 +501,21 @@ DEV void attn32_fwd_body(const AP<bf16_t>& p, const int bid) {
             for (int e = 0; e < 4; ++e)
                 st4(orow + 32 * dt + 8 * e + 4 * hf, oacc[dt][4 * e] * inv, oacc[dt][4 * e + 1] * inv,
                     oacc[dt][4 * e + 2] * inv, oacc[dt][4 * e + 3] * inv);
+        if (p.o_lo) {      // what the bf16 store dropped (attn_common.h: o_lo), for the backward's delta
+            bf16_t* lrow = p.o_lo + (rowbase + i) * p.ldo + hh * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float r4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = oacc[dt][4 * e + c] * inv;
+                        r4[c] = x - (float)(bf16_t)x;
+                    }
+                    st4(lrow + 32 * dt + 8 * e + 4 * hf, r4[0], r4[1], r4[2], r4[3]);
+                }
+        }
         if (hf == 0)
             p.lse[((size_t)b * p.H + hh) * L + i] = lt > 0.f ? (m_run + __log2f(lt)) * LN2 : __builtin_inff();
     }
@@ -564,6 +579,9 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
 
     bf16x8 qu[4], qv[4], dof[4];
     float dsum = 0.f;
+    // (unconditional loads: without a residual buffer the O rows are read twice and the second copy weighted 0)
+    const bf16_t* olg = (p.o_lo ? p.o_lo : p.o) + rowbase * p.ldo + hh * 64;
+    const float lo_w = p.o_lo ? 1.f : 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const bf16x8 f = gfrag(qg, i, L, p.ld, s, hf);
@@ -575,8 +593,9 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
         }
         dof[s] = gfrag(dog, i, L, p.ldo, s, hf);
         const bf16x8 of = gfrag(og, i, L, p.ldo, s, hf);
+        const bf16x8 lf = gfrag(olg, i, L, p.ldo, s, hf);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dsum += (float)dof[s][e] * (float)of[e];
+        for (int e = 0; e < 8; ++e) dsum += (float)dof[s][e] * ((float)of[e] + lo_w * (float)lf[e]);
     }
     // delta[i] = sum_d dO[i][d] O[i][d]; published for the dK/dV kernel, which runs after this one on the stream
     dsum = xh_sum(dsum);
@@ -847,16 +866,18 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
             ptile(pb_, mlo + 32);
         }
 
-        Tile2 qr, dor, orr;
+        Tile2 qr, dor, orr, olr;
         float lse_n = 0.f, del_n = 0.f;
         const bf16_t* og = p.o + rowbase * p.ldo + hh * 64;
+        const bf16_t* olg = (p.o_lo ? p.o_lo : p.o) + rowbase * p.ldo + hh * 64;      // (see the dQ body: second copy weighted 0 when off)
+        const float lo_w = p.o_lo ? 1.f : 0.f;
 #define A32_KV_PREFETCH(I0_)                                                               \
     do {                                                                                   \
         tload<NT_>(qr, qg, p.ld, (I0_), L, tid);                                                \
         tload<NT_>(dor, dog, p.ldo, (I0_), L, tid);                                             \
         const int ii_ = min((I0_) + (tid & 63), L - 1);      /* every thread loads */      \
         lse_n = p.lse[((size_t)b * p.H + hh) * L + ii_];                                   \
-        if (OWN_DELTA) tload<NT_>(orr, og, p.ldo, (I0_), L, tid);                               \
+        if (OWN_DELTA) { tload<NT_>(orr, og, p.ldo, (I0_), L, tid); tload<NT_>(olr, olg, p.ldo, (I0_), L, tid); } \
         else del_n = p.delta[((size_t)b * p.H + hh) * L + ii_];                            \
     } while (0)
 #define A32_KV_PUBLISH(BUF_, I0_)                                                          \
@@ -871,8 +892,9 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
         if (OWN_DELTA) {      /* thread: 8 columns of row tid/8 (and, 256 threads, tid/8 + 32) */ \
             _Pragma("unroll") for (int i_ = 0; i_ < 512 / NT_; ++i_) {                     \
                 const bf16x8 d8_ = __builtin_bit_cast(bf16x8, dor[i_]), o8_ = __builtin_bit_cast(bf16x8, orr[i_]); \
+                const bf16x8 l8_ = __builtin_bit_cast(bf16x8, olr[i_]);                    \
                 float s_ = 0.f;                                                            \
-                _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) s_ += (float)d8_[e_] * (float)o8_[e_]; \
+                _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) s_ += (float)d8_[e_] * ((float)o8_[e_] + lo_w * (float)l8_[e_]); \
                 s_ += __shfl_xor(s_, 1);                                                   \
                 s_ += __shfl_xor(s_, 2);                                                   \
                 s_ += __shfl_xor(s_, 4);                                                   \
@@ -882,13 +904,14 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
         }                                                                                  \
     } while (0)
         if constexpr (WHOLE) {      // (see attn32_fwd_body) all Q / dO tiles (+ lse, delta) once, barrier-free step loop
-            Tile2 qa4[NBUF], da4[NBUF], oa4[NBUF];
+            Tile2 qa4[NBUF], da4[NBUF], oa4[NBUF], la4[NBUF];
             float ls4[NBUF];
 #pragma unroll
             for (int t = 0; t < NBUF; ++t) {
                 tload<NT_>(qa4[t], qg, p.ld, 64 * t, L, tid);
                 tload<NT_>(da4[t], dog, p.ldo, 64 * t, L, tid);
                 tload<NT_>(oa4[t], og, p.ldo, 64 * t, L, tid);
+                tload<NT_>(la4[t], olg, p.ldo, 64 * t, L, tid);
                 ls4[t] = p.lse[((size_t)b * p.H + hh) * L + min(64 * t + (tid & 63), L - 1)];
             }
 #pragma unroll
@@ -896,6 +919,7 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
                 qr[0] = qa4[t][0]; qr[1] = qa4[t][1];
                 dor[0] = da4[t][0]; dor[1] = da4[t][1];
                 orr[0] = oa4[t][0]; orr[1] = oa4[t][1];
+                olr[0] = la4[t][0]; olr[1] = la4[t][1];
                 lse_n = ls4[t];
                 A32_KV_PUBLISH(t, 64 * t);
             }

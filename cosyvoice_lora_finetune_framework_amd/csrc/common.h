@@ -25,6 +25,15 @@ extern "C" int cvft_concurrent_chains(void);
         }                                              \
     } while (0)
 
+#define CVFT_HIP_CHECK_RET(call, name)                                          \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) {                                                \
+            cvft_set_error("%s: %s", name, hipGetErrorString(e__));             \
+            return -2;                                                          \
+        }                                                                       \
+    } while (0)
+
 #define CVFT_LAUNCH_CHECK(name)                                                 \
     do {                                                                        \
         hipError_t e__ = hipGetLastError();                                     \

@@ -120,10 +120,10 @@ SIGNATURES = {
     "cvft_layernorm_bwd_mask_side": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, C.c_uint, _p, _p, _i, _f, _p, _p],
     "cvft_groupnorm_mish_fwd": [_i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _p],
     "cvft_groupnorm_mish_bwd": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p],
-    "cvft_attn_bias_fwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _f, _i, _p, _i, _p, _p],
-    "cvft_attn_bias_bwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _f, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p],
-    "cvft_attn_relpos_fwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _f, _p, _i, _p, _f, _p, C.c_uint, _p],
-    "cvft_attn_relpos_bwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _p, _p,
+    "cvft_attn_bias_fwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _f, _i, _p, _i, _p, _p, _p],
+    "cvft_attn_bias_bwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _f, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p],
+    "cvft_attn_relpos_fwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _f, _p, _i, _p, _p, _f, _p, C.c_uint, _p],
+    "cvft_attn_relpos_bwd": [_i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _f, _p, _p, _i, _p, _p, _p, _p,
                              _p, _p, _i, _p, _f, _p, C.c_uint, _p],
     "cvft_embed_gather": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "cvft_gather_rows": [_i, _i, _i, _p, _p, _f, _p, _p],

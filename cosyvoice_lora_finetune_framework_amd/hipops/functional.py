@@ -103,7 +103,7 @@ def gemm(x: torch.Tensor, W: torch.Tensor, *, N: Optional[int] = None, K: Option
     a.A, a.lda = ptr(x), x.stride(0)
     a.W, a.ldw = ptr(W), W.stride(0)
     if U is not None:
-        assert Bl is not None and U.shape[0] == a.M and Bl.shape[0] == N and U.shape[1] == Bl.shape[1]
+        assert Bl is not None and U.shape[0] == a.M and Bl.shape[0] == N and U.shape[1] == Bl.shape[1], (tuple(U.shape), a.M, N, None if Bl is None else tuple(Bl.shape))
         a.U, a.ldu, a.R = ptr(U), U.stride(0), U.shape[1]
         a.Bl, a.ldbl = ptr(Bl), Bl.stride(0)
     if La is not None:       # fused side path: U = lora_scale * x La^T computed inside the launch, written to Uout
@@ -1376,7 +1376,6 @@ FFN_TRAIN_FUSE = _os.environ.get("CVFT_FFN_TRAIN_FUSE", "1") != "0"
 # ReLU feed-forward backward from the saved (dropped) hidden activations instead of a pre-activation copy (FeedForwardFn)
 RELU_FROM_H = _os.environ.get("CVFT_RELU_FROM_H", "1") != "0"
 
-_QKV_STACKS = {}
 QKV_STACKING = _os.environ.get("CVFT_QKV_STACK", "1") != "0"
 # rank-48 side products inside the main launches: measured slower than the dedicated skinny kernel (39.7 vs 39.0 ms/step:
 # the extra MFMAs land on half of the block's waves), kept selectable
@@ -1401,12 +1400,14 @@ def _qkv_stacked_operands(x, packs, loras, scales):
     ops = opt.stack_for((Aq, Ak, Av), (Bq, Bk, Bv))
     if ops is None:
         return None
-    key = tuple(id(p) for p in packs)
-    ws = _QKV_STACKS.get(key)
-    if ws is None:
-        ws = QKVStack(packs)
-        _QKV_STACKS[key] = ws
-    return ws, ops
+    # the stacked weight lives ON the first pack (with the two partners it was built from, compared by identity): a module-level
+    # table keyed by id(pack) handed a later model the stack of a freed one whose ids had been recycled (wrong-shape assertion in
+    # tests/test_model_gpu.py when it ran behind tests that build and drop other models)
+    ent = packs[0].__dict__.get("_cvft_qkv_stack")
+    if ent is None or ent[0] is not packs[1] or ent[1] is not packs[2]:
+        ent = (packs[1], packs[2], QKVStack(packs))
+        packs[0].__dict__["_cvft_qkv_stack"] = ent
+    return ent[2], ops
 
 
 def lora_linear_qkv(x, packs, loras, scales, drop_p: float = 0.0):
@@ -1914,6 +1915,17 @@ def groupnorm_mish(x, gamma, beta, B: int, T: int, G: int, eps: float = 1e-5, le
 # ---------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------
+# The bf16 attention forward also writes O's rounding residual (include/cvft.h `o_lo`) when a backward will follow: the backward's
+# delta = rowsum(dO (O + O_lo)) then carries fp32-level accuracy instead of bf16's (csrc/attn_common.h).  CVFT_ATTN_OLO=0: off.
+ATTN_OLO = int(_os.environ.get("CVFT_ATTN_OLO", "1"))      # 0 off, 1 estimator (additive-bias) attention only, 2 rel-pos attention too
+
+
+def _attn_residual(ctx, o: torch.Tensor, rel: bool = False):
+    if ATTN_OLO >= (2 if rel else 1) and o.dtype == torch.bfloat16 and any(ctx.needs_input_grad[:3]):
+        return torch.empty_like(o)
+    return None
+
+
 class AttnBiasFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, B: int, H: int, T: int, klen, scale: float, iso_len: int = 0):
@@ -1921,16 +1933,17 @@ class AttnBiasFn(torch.autograd.Function):
         assert q.stride(0) == k.stride(0) == v.stride(0)
         o = torch.empty((B * T, H * 64), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+        o_lo = _attn_residual(ctx, o)
         with _Bracket("attn_bias_fwd", 4.0 * B * H * T * T * 64, 4.0 * B * T * H * 64 * q.element_size()):     # QK^T, PV
             check(lib().cvft_attn_bias_fwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, int(iso_len), ptr(o),
-                                           o.stride(0), ptr(lse), stream()), "cvft_attn_bias_fwd")
-        ctx.save_for_backward(q, k, v, o, lse)
+                                           o.stride(0), ptr(lse), ptr(o_lo), stream()), "cvft_attn_bias_fwd")
+        ctx.save_for_backward(q, k, v, o, lse, o_lo)
         ctx.args = (B, H, T, klen, scale, int(iso_len))
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse = ctx.saved_tensors
+        q, k, v, o, lse, o_lo = ctx.saved_tensors
         B, H, T, klen, scale, iso_len = ctx.args
         do = _c(do)
         dqkv = torch.empty((B * T, 3 * H * 64), dtype=q.dtype, device=q.device)
@@ -1938,7 +1951,7 @@ class AttnBiasFn(torch.autograd.Function):
         delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
         with _Bracket("attn_bias_bwd", 10.0 * B * H * T * T * 64, 8.0 * B * T * H * 64 * q.element_size()):    # S, dP, dV, dK, dQ
             check(lib().cvft_attn_bias_bwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, iso_len, ptr(o),
-                                           ptr(do), o.stride(0), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                           ptr(do), o.stride(0), ptr(lse), ptr(o_lo), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                            dqkv.stride(0), stream()), "cvft_attn_bias_bwd")
         return dq, dk, dv, None, None, None, None, None, None
 
@@ -1957,19 +1970,20 @@ class AttnRelPosFn(torch.autograd.Function):
         seed = _DROPOUT["seed"] if drop_p > 0 else None
         o = torch.empty((B * L, H * 64), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+        o_lo = _attn_residual(ctx, o, rel=True)
         vis = 0.5 if causal else 1.0                      # share of the (query, key) square a causal launch has to compute
         with _Bracket("attn_relpos_fwd", 6.0 * vis * B * H * L * L * 64, 4.0 * B * L * H * 64 * q.element_size()):   # QK^T, band, PV
             check(lib().cvft_attn_relpos_fwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
                                              ptr(bias_u), ptr(bias_v), ptr(length), int(causal), scale, ptr(o), o.stride(0),
-                                             ptr(lse), float(drop_p), ptr(seed), drop_site, stream()), "cvft_attn_relpos_fwd")
-        ctx.save_for_backward(q, k, v, p, bias_u, bias_v, o, lse)
+                                             ptr(lse), ptr(o_lo), float(drop_p), ptr(seed), drop_site, stream()), "cvft_attn_relpos_fwd")
+        ctx.save_for_backward(q, k, v, p, bias_u, bias_v, o, lse, o_lo)
         ctx.args = (B, H, L, length, causal, scale)
         ctx.drop = (float(drop_p), seed, drop_site)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, p, bu, bv, o, lse = ctx.saved_tensors
+        q, k, v, p, bu, bv, o, lse, o_lo = ctx.saved_tensors
         B, H, L, length, causal, scale = ctx.args
         do = _c(do)
         dpos = None
@@ -1982,7 +1996,7 @@ class AttnRelPosFn(torch.autograd.Function):
         with _Bracket("attn_relpos_bwd", 14.0 * vis * B * H * L * L * 64, 8.0 * B * L * H * 64 * q.element_size()):  # S, band, dP, dV, dK, dQ (k and p terms)
             check(lib().cvft_attn_relpos_bwd(dt(q), B, H, L, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(p), p.stride(0),
                                              ptr(bu), ptr(bv), ptr(length), int(causal), scale, ptr(o), ptr(do), o.stride(0),
-                                             ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), ptr(dpos),
+                                             ptr(lse), ptr(o_lo), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), ptr(dpos),
                                              ctx.drop[0], ptr(ctx.drop[1]), ctx.drop[2], stream()),
                   "cvft_attn_relpos_bwd")
         dp_out = None if dpos is None else dpos.to(p.dtype)

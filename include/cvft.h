@@ -222,13 +222,16 @@ int cvft_groupnorm_mish_bwd(int dtype, int B, int T, int C, int G, const void* x
  * (B,T,T) mask_to_bias tensor (decoder.py:238-240, utils.py:103-109).
  * ------------------------------------------------------------------------------- */
 int cvft_attn_bias_fwd(int dtype, int B, int H, int T, const void* q, const void* k, const void* v, int ld,
-                       const int32_t* klen, float scale, int iso_len, void* o, int ldo, float* lse, void* stream);
+                       const int32_t* klen, float scale, int iso_len, void* o, int ldo, float* lse,
+                       void* o_lo /* bf16 only, [B*T][ldo] or NULL: bf16(O - bf16(O)), the part of the fp32 output the bf16
+                                     store drops; hand it to the backward entry point (its delta = rowsum(dO (O + O_lo))) */,
+                       void* stream);
 /* iso_len > 0: prompt-isolation mask (modules.py:844-879): frames [0, iso_len) and [iso_len, T) attend only within
  * their own segment (block-diagonal -inf bias on top of the key-padding bias). */
 int cvft_attn_bias_bwd(int dtype, int B, int H, int T, const void* q, const void* k, const void* v, int ld,
                        const int32_t* klen, float scale, int iso_len, const void* o, const void* d_o, int ldo,
-                       const float* lse, float* delta /*[B][H][T] ws*/, void* dq, void* dk, void* dv, int ldg,
-                       void* stream);
+                       const float* lse, const void* o_lo /* the forward's, or NULL */, float* delta /*[B][H][T] ws*/,
+                       void* dq, void* dk, void* dv, int ldg, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Fused relative-position attention (Transformer-XL / ESPnet), head_dim 64:
@@ -242,6 +245,7 @@ int cvft_attn_bias_bwd(int dtype, int B, int H, int T, const void* q, const void
 int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
                          const void* p, int ldp, const float* bias_u, const float* bias_v,
                          const int32_t* len, int causal, float scale, void* o, int ldo, float* lse,
+                         void* o_lo /* as cvft_attn_bias_fwd */,
                          float drop_p, const int64_t* drop_seed, unsigned drop_site, void* stream);
 /* drop_p > 0: attention-probability dropout (attention.py:118): the PV operand is masked / scaled by 1/(1-p), the softmax
  * denominator is not; the mask is a function of (*drop_seed (device int64), drop_site, b, h, i, j) and is re-derived by
@@ -249,7 +253,7 @@ int cvft_attn_relpos_fwd(int dtype, int B, int H, int L, const void* q, const vo
 int cvft_attn_relpos_bwd(int dtype, int B, int H, int L, const void* q, const void* k, const void* v, int ld,
                          const void* p, int ldp, const float* bias_u, const float* bias_v,
                          const int32_t* len, int causal, float scale, const void* o, const void* d_o, int ldo,
-                         const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg,
+                         const float* lse, const void* o_lo, float* delta, void* dq, void* dk, void* dv, int ldg,
                          float* dp /*[2L-1][H*64] fp32 accum or NULL*/,
                          float drop_p, const int64_t* drop_seed, unsigned drop_site, void* stream);
 

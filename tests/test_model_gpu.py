@@ -219,18 +219,19 @@ def test_full_size_llm_matches_reference(case):
 
 
 # Stated tolerances of the reduced-precision BACKWARD at full size (relative L2 against the reference's fp32 CPU gradients) --
-# each <= 3x the value measured on MI355X in round 3 (printed by _check_backward):
-#   bf16: loss 3.1e-5 .. 4.5e-4, total gradient norm 3.6e-4 .. 4.3e-3, worst picked adapter tensor 3.6e-2 .. 7.3e-2 at T = 500 / LLM
-#         and 2.1e-1 at the flow's T = 1000 / r = 64 case;  fp8 (LLM, T = 1000): loss 1.05e-4, norm 1.2e-3;  fp32: 1e-6 / 5e-6 / 8e-4.
-# Where the 2.1e-1 comes from (tools/grad_error_profile.py, T = 1000 / r = 64, bf16 against the fp32 product path): it sits on the
-# to_q / to_k adapters of the estimator's MID blocks only -- tensors that hold 3e-4 .. 5e-4 of the gradient norm each (|g| ~ 1e-3
-# against 0.6 for the first block's to_v).  With 500 keys per query at that U-Net level the softmax is nearly flat, and the
-# score gradient dS = P (dP - delta) is a small difference of nearly equal bf16-rounded numbers; the to_v adapters of the very same
-# blocks are at 2e-2, so it is neither depth (mid_blocks.5 and .11 read alike) nor the slab accumulation order.  Tensors holding
-# > 2 % of the gradient norm are all <= 4.3e-2 and the whole-gradient error is 2.2e-2 -- hence a per-tensor bound that scales
-# with the tensor's share of the norm (BF16_SMALL_TENSOR_TOL for shares < 0.2 %).
-BF16_LOSS_TOL, BF16_GRAD_NORM_TOL = 1.5e-3, 1.5e-2
-BF16_GRAD_TENSOR_TOL, BF16_SMALL_TENSOR_TOL, SMALL_SHARE = 2.2e-1, 6.5e-1, 2e-3
+# each <= 3x the value measured on MI355X in round 4 (printed by _check_backward):
+#   bf16: loss 3.2e-5 .. 3.7e-4, total gradient norm 3.5e-4 .. 5.7e-3, worst picked adapter tensor 2.3e-2 .. 3.8e-2 on the flow
+#         (T = 500 / r = 16 and T = 1000 / r = 64) and 6.7e-2 .. 7.3e-2 on the LLM;  fp8 (LLM, T = 1000): loss 1.06e-4, norm 1.3e-3;
+#         fp32: 1e-6 / 5e-6 / 8e-4.
+# Round 3 had 2.1e-1 on the to_q / to_k adapters of the estimator's MID blocks at T = 1000 / r = 64 (tensors holding 3e-4 .. 5e-4 of
+# the gradient norm): with ~500 keys per query the softmax is nearly flat, dP is nearly constant over the keys, and the score
+# gradient dS = P (dP - delta) inherited the error of delta = rowsum(dO . O) taken from the bf16-ROUNDED forward output as a
+# common-mode error of the whole row (tools/delta_error_model.py: 3 % .. 10 % on dQ / dK in that regime).  The forward now also
+# writes O's rounding residual and the backward forms delta from O + residual (include/cvft.h `o_lo`, csrc/attn_common.h): the same
+# tensors are at 3.8e-2 (CVFT_ATTN_OLO=0 restores the old form: 1.1e-1 on this build), and one per-tensor bound serves tensors of
+# every share of the norm.
+BF16_LOSS_TOL, BF16_GRAD_NORM_TOL = 1.1e-3, 1.5e-2
+BF16_GRAD_TENSOR_TOL, BF16_SMALL_TENSOR_TOL, SMALL_SHARE = 1.1e-1, 1.1e-1, 2e-3
 FP8_LOSS_TOL, FP8_GRAD_NORM_TOL = 5e-4, 4e-3
 
 
