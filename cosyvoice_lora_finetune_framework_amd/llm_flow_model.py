@@ -43,6 +43,7 @@ LOSS_FUSE = os.environ.get("CVFT_LOSS_FUSE", "1") != "0"      # 0: the plain op-
 # joint 21.28 / 21.36 (1) vs 21.33 / 21.34 ms (0), flow_only 14.29 vs 14.27, llm_only 13.38 vs 13.31 -- the step is bound by the
 # chip's CU-time, an idle chain is another chain's CUs
 CHAIN_BWD = os.environ.get("CVFT_CHAIN_BWD", "0") != "0"
+CHAIN_ORDER = int(os.environ.get("CVFT_CHAIN_ORDER", "0"))      # 1: chains enqueued Flow first, LLM last (the caller's stream then carries the LLM) -- see forward()
 SIDE_STREAM_PRIORITY = int(os.environ.get("CVFT_SIDE_PRIO", "0"))      # priority of the side streams (the Flow chains in joint mode): -1 = high
 
 
@@ -100,6 +101,9 @@ class JointLLMFlowModel(nn.Module):
         do_llm = self.training_mode in ('joint', 'llm_only')
         do_flow = self.training_mode in ('joint', 'flow_only')
         chains = [('llm', k) for k in range(len(parts['llm']))] * do_llm + [('flow', k) for k in range(len(parts['flow']))] * do_flow
+        if CHAIN_ORDER and len(chains) == 3:      # (A/B: which chain keeps the caller's stream and in which order the others fork)
+            import itertools
+            chains = [chains[i] for i in list(itertools.permutations(range(3)))[CHAIN_ORDER % 6]]
         use_streams = BRANCH_STREAMS and torch.cuda.is_available() and len(chains) > 1
         if torch.cuda.is_available():      # tile-shape hint for the kernels that would own a whole CU (cvft.h)
             HF.lib().cvft_set_concurrent_chains(CHAINS_HINT if CHAINS_HINT else (len(chains) if use_streams else 1))
