@@ -44,6 +44,8 @@ extern "C" int cvft_debug_block_stamps(unsigned long long* host_out) {
 #define BF_LDS_PAR (BF_LDS_BIAS + 4 * BF_MAX_F)      // 4 x 256 floats: bo | gamma | beta | b2 (a late global load would queue
                                                      // behind the 32 KB of weight fragments in flight: vmcnt retires in order)
 #define BF_LDS_TOTAL (BF_LDS_PAR + 4 * 4 * BF_D)
+#define BF_LDS_DUMMY BF_LDS_TOTAL          // 256 bytes: landing area of bf_touch_stream_lds (kernels launched with BF_LDS_TOTAL_DMA)
+#define BF_LDS_TOTAL_DMA (BF_LDS_TOTAL + 256)
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -135,6 +137,20 @@ __device__ __forceinline__ BfTouch bf_touch_stream(const void* stream, int total
         r.v[i] = *reinterpret_cast<const unsigned*>(base + (size_t)min(i * 256 + (int)threadIdx.x, lines - 1) * 128);
     return r;
 }
+// The same touches through the LDS-DMA path: the loaded words go to a 256-byte dummy area of LDS nobody reads (every wave and every
+// request lands on the same bytes), so no register waits for them -- for the kernel that has none to spare (block_link_fwd_kernel:
+// with the eight values held in registers to its end the compiler spills, and a spilled load result is a wait for every load in
+// flight).  lds_dummy: 256 bytes of dynamic LDS behind BF_LDS_TOTAL.
+__device__ __forceinline__ void bf_touch_stream_lds(const void* stream, int total_frags, char* lds_dummy) {
+    typedef __attribute__((address_space(3))) void lds_v;
+    typedef const __attribute__((address_space(1))) void glb_v;
+    const int part = (blockIdx.x >> 3) & 7;
+    const int lines = total_frags;
+    const char* base = reinterpret_cast<const char*>(stream) + (size_t)part * lines * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((glb_v*)(base + (size_t)min(i * 256 + (int)threadIdx.x, lines - 1) * 128), (lds_v*)lds_dummy, 4, 0, 0);
+}
 __device__ __forceinline__ unsigned bf_touch_fold(const BfTouch& r) {
     unsigned a = 0;
 #pragma unroll
@@ -200,10 +216,10 @@ __device__ __forceinline__ f32x16 bf_bias_init(const float* b1s, int ht, int h) 
 
 
 template <typename K>
-static int bf_prepare(K kernel) {
+static int bf_prepare(K kernel, int lds_bytes = BF_LDS_TOTAL) {
     // (cheap and idempotent; called once per instantiation)
-    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_TOTAL) != hipSuccess) {
-        cvft_set_error("block kernels: cannot reserve %d bytes of LDS", BF_LDS_TOTAL);
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+        cvft_set_error("block kernels: cannot reserve %d bytes of LDS", lds_bytes);
         return -2;
     }
     return 0;

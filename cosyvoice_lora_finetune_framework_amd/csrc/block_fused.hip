@@ -21,7 +21,7 @@
 // features of the output projection) and meet once per link in LDS (fp32 partial tiles, 128 KB).
 // Bound: the per-CU L2 -> register rate (~120 GB/s per CU with one workgroup per CU, tools/ub/mfma_rate.hip): 1.25 MB of
 // packed weights per row tile each way; 125 workgroups at M = 4000.
-#include "block_common.h"
+#include "block_qkv_body.h"
 
 struct TailFwd {
     int M;
@@ -73,9 +73,12 @@ __device__ __forceinline__ void bf_ffn_second(bf16x8 (&ring)[BF_RING], const bf1
 }
 
 // AR = rounds of 32 fragments in the output projection's stream (DI / 256; 0 = no projection, x1 is the input)
-template <int ACT, int AR>
-__global__ __launch_bounds__(256, 1) void block_tail_fwd_kernel(TailFwd a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// LINK: the NEXT block's head (norm1 + LoRA q|k|v projection, block_qkv_body.h: q) follows on the same 32 rows in the same launch:
+// the block output stays in the wave's registers, and a.Wst is the linked stream -- per wave its tail fragments, then its 192
+// fragments of the head (hipops/blockpack.py, BlockLinkPack) -- so the ring's re-requests run from one product into the other
+// without a refill: the last feed-forward round already requests the head's first 32 fragments.
+template <int ACT, int AR, bool LINK, bool DROP>
+__device__ __forceinline__ void bt_fwd_body(const TailFwd& a, const QkvFwd& q, char* smem) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BF_ROWS;
@@ -111,7 +114,8 @@ __global__ __launch_bounds__(256, 1) void block_tail_fwd_kernel(TailFwd a) {
     for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
     nx += BF_RING * 64;
     BfTouch touched;
-    if (BF_TOUCH) touched = bf_touch_stream(a.Wst, 4 * a.wave_frags);
+    if (BF_TOUCH && !LINK) touched = bf_touch_stream(a.Wst, 4 * a.wave_frags);
+    if (BF_TOUCH && LINK) bf_touch_stream_lds(a.Wst, 4 * a.wave_frags, smem + BF_LDS_DUMMY);
     const float* pbo = reinterpret_cast<const float*>(smem + BF_LDS_PAR), *pgam = pbo + BF_D, *pbet = pbo + 2 * BF_D, *pb2 = pbo + 3 * BF_D;
 
     if (AR > 0) {
@@ -213,24 +217,56 @@ __global__ __launch_bounds__(256, 1) void block_tail_fwd_kernel(TailFwd a) {
         nx += BF_RING * 64;
     }
     BF_STAMP(8 + ntw - 1);
-    bf_ffn_second<ACT, 16, false>(ring, nx, acc1, acc2, zp == nullptr ? nullptr : zp + (size_t)(ntw - 1) * 128);
+    // LINK: the head's LayerNorm parameters / bias are requested here, in front of the last round's re-requests (vmcnt retires in
+    // order: they arrive first), and the last round re-requests its 16 slots too -- positions 16..31 of the head's stream (slots
+    // 0..15 took positions 0..15 in the round before)
+    BqParams hpar;
+    if (LINK) bq_params_load(q, wave, lane, hpar);
+    bf_ffn_second<ACT, 16, LINK>(ring, nx, acc1, acc2, zp == nullptr ? nullptr : zp + (size_t)(ntw - 1) * 128);
+    if (LINK) nx += 16 * 64;
     float v[2][16];
     BF_STAMP(6);
     __syncthreads();                                   // (the y tile / statistics reads are done before `part` is rewritten)
-    bf_reduce(smem, wave, lane, acc2, v);
+    // LINK: lane and row re-enter through an empty asm -- everything the rest of the kernel derives from them (the reduction's LDS
+    // addresses, the output rows, some thirty address registers of the head) is then computed HERE and not at the top of the kernel,
+    // where it would sit through the feed-forward loop and spill; a spill reload is a memory load, i.e. a wait for the whole
+    // fragment ring in flight
+    int lane2 = lane, row2 = row;
+    if (LINK) asm volatile("" : "+v"(lane2), "+v"(row2));
+    const int h2 = lane2 >> 5;
+    if (LINK) bq_params_store(q, smem, wave, lane2, hpar);  // (b1 / gamma / beta were last read in front of that barrier; b2's slot stays)
+    bf_reduce(smem, wave, lane2, acc2, v);
     BF_STAMP(7);
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int c = 64 * wave + 32 * c2 + 8 * g + 4 * h;
+            const int c = 64 * wave + 32 * c2 + 8 * g + 4 * h2;
             const f32x4 bb = *reinterpret_cast<const f32x4*>(pb2 + c);
             bf16x4 yo;
 #pragma unroll
             for (int i = 0; i < 4; ++i) yo[i] = (bf16_t)(v[c2][4 * g + i] + bb[i] + (float)xb[c2][g][i]);
-            if (rvalid) *reinterpret_cast<bf16x4*>(a.out + (size_t)row * BF_D + c) = yo;
+            if (rvalid) *reinterpret_cast<bf16x4*>(a.out + (size_t)row2 * BF_D + c) = yo;
+            if (LINK) xb[c2][g] = yo;                  // the next block's input, as stored
         }
-    if (BF_TOUCH && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.mean[0] = 0.f;      // (keeps the prefetch loads alive; never true)
+    if (LINK) {
+        BqOps<1> hops;                                 // (80 registers: requested only now that the tail's accumulators are dead; first
+        bq_load_ops<1>(q, wave, lane2 & 31, lane2 >> 5, 12 * wave, hops);   //  used behind the LayerNorm's three barriers)
+        bq_head_fwd<DROP, 1>(q, smem, xb, ring, nx, hops, lane2, wave, row2, rvalid, 12 * wave, true);
+    }
+    if (BF_TOUCH && !LINK && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.mean[0] = 0.f;      // (keeps the prefetch loads alive; never true)
+}
+
+template <int ACT, int AR>
+__global__ __launch_bounds__(256, 1) void block_tail_fwd_kernel(TailFwd a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    QkvFwd none;
+    bt_fwd_body<ACT, AR, false, false>(a, none, smem);
+}
+template <int ACT, int AR, bool DROP>
+__global__ __launch_bounds__(256, 1) void block_link_fwd_kernel(TailFwd a, QkvFwd q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bt_fwd_body<ACT, AR, true, DROP>(a, q, smem);
 }
 
 struct TailBwd {
@@ -443,6 +479,53 @@ extern "C" int cvft_block_tail_fwd(const cvft_block_tail_args* p, void* stream) 
     else rc = erf ? launch_fwd<CVFT_ACT_GELU_ERF, 2>(a, st) : launch_fwd<CVFT_ACT_GELU_TANH, 2>(a, st);
     if (rc) return rc;
     CVFT_LAUNCH_CHECK("cvft_block_tail_fwd");
+    return 0;
+}
+
+template <int ACT, int AR, bool DROP>
+static int launch_link_fwd(const TailFwd& a, const QkvFwd& q, hipStream_t st) {
+    static int ready = 0;
+    if (!ready) { if (bf_prepare(block_link_fwd_kernel<ACT, AR, DROP>, BF_LDS_TOTAL_DMA)) return -2; ready = 1; }
+    hipLaunchKernelGGL((block_link_fwd_kernel<ACT, AR, DROP>), dim3((a.M + BF_ROWS - 1) / BF_ROWS), dim3(256), BF_LDS_TOTAL_DMA, st, a, q);
+    return 0;
+}
+
+// The tail of one block and the head of the NEXT one on the same rows in one launch (include/cvft.h).  Both argument blocks mean
+// what they mean for cvft_block_tail_fwd / cvft_block_qkv_fwd, with t->lean == 0, q->wide == 0 and q->x == t->out; W_link replaces
+// both weight streams.
+extern "C" int cvft_block_link_fwd(const cvft_block_tail_args* p, const cvft_block_qkv_args* q, const void* W_link, void* stream) {
+    CVFT_CHECK_ARG(p && q && W_link && al16(W_link), "cvft_block_link_fwd: null / unaligned operand");
+    CVFT_CHECK_ARG(p->M > 0 && q->M == p->M && p->F % 128 == 0 && p->F >= 256 && p->F <= 1024 && q->N3 == 1536,
+                   "cvft_block_link_fwd: need equal M > 0, 256 <= F <= 1024 (F %% 128 == 0), 3N == 1536 (M=%d/%d F=%d)", p->M, q->M, p->F);
+    CVFT_CHECK_ARG(p->lean == 0 && q->wide == 0 && p->o && p->DI == 512 && p->x0 && p->bo && p->ldo % 8 == 0 && al16(p->o),
+                   "cvft_block_link_fwd: the 32-row forms only (lean == 0, wide == 0), with the output projection (DI == 512)");
+    CVFT_CHECK_ARG(p->x1 && p->out && p->b1 && p->b2 && p->gamma && p->beta && p->mean && p->rstd && q->x == p->out &&
+                   q->gamma && q->beta && q->mean && q->rstd && q->A && q->Bb && q->U && q->Y, "cvft_block_link_fwd: null operand, or head x != tail out");
+    CVFT_CHECK_ARG(p->act == CVFT_ACT_GELU_ERF || p->act == CVFT_ACT_GELU_TANH, "cvft_block_link_fwd: act must be a GELU form");
+    CVFT_CHECK_ARG(cvft_drop_rate_ok(q->p) && (q->p == 0.f || q->seed), "cvft_block_link_fwd: bad dropout args (p == 0 or 2^-16 <= p <= 1 - 2^-16, seed)");
+    CVFT_CHECK_ARG(al16(p->x1) && al16(p->out) && al16(p->b1) && al16(p->b2) && al16(p->gamma) && al16(p->beta) && (!p->z || al16(p->z)) &&
+                   al16(p->x0) && al16(p->bo) && al16(q->gamma) && al16(q->beta) && al16(q->A) && al16(q->Bb) && al16(q->Y) && (!q->bias || al16(q->bias)) &&
+                   q->lda % 8 == 0 && q->ldb % 4 == 0 && q->ldu % 4 == 0 && q->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(q->U) & 7) == 0 &&
+                   (!q->y_out || al16(q->y_out)) && (!q->xd[0] || al16(q->xd[0])) && (!q->xd[1] || al16(q->xd[1])) && (!q->xd[2] || al16(q->xd[2])),
+                   "cvft_block_link_fwd: operands must be 16-byte aligned (row pitches: ldo / lda %% 8, ldb / ldu / ldy %% 4)");
+    TailFwd a;
+    a.M = p->M; a.o = (const bf16_t*)p->o; a.ldo = p->ldo; a.x0 = (const bf16_t*)p->x0;
+    a.Wst = (const bf16x8*)W_link; a.wave_frags = p->DI / 8 + p->F / 4 + q->N3 / 8; a.bo = p->bo; a.x1 = (bf16_t*)p->x1;
+    a.gamma = p->gamma; a.beta = p->beta; a.eps = p->eps; a.b1 = p->b1; a.F = p->F; a.b2 = p->b2;
+    a.z = (bf16_t*)p->z; a.mean = p->mean; a.rstd = p->rstd; a.out = (bf16_t*)p->out;
+    QkvFwd h;
+    h.M = q->M; h.x = (const bf16_t*)q->x; h.gamma = q->gamma; h.beta = q->beta; h.eps = q->eps; h.mean = q->mean; h.rstd = q->rstd;
+    h.Wst = nullptr; h.wave_frags = q->N3 / 8; h.bias = q->bias; h.N3 = q->N3;
+    h.A = (const bf16_t*)q->A; h.lda = q->lda; h.Bb = (const bf16_t*)q->Bb; h.ldb = q->ldb;
+    h.alpha = q->alpha; h.p = q->p; h.seed = (const long long*)q->seed;
+    for (int i = 0; i < 3; ++i) { h.sites[i] = q->sites[i]; h.xd[i] = (bf16_t*)q->xd[i]; }
+    h.U = (bf16_t*)q->U; h.ldu = q->ldu; h.y_out = (bf16_t*)q->y_out; h.Y = (bf16_t*)q->Y; h.ldy = q->ldy;
+    const bool erf = p->act == CVFT_ACT_GELU_ERF, drop = q->p > 0.f;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = erf ? (drop ? launch_link_fwd<CVFT_ACT_GELU_ERF, 2, true>(a, h, st) : launch_link_fwd<CVFT_ACT_GELU_ERF, 2, false>(a, h, st))
+                       : (drop ? launch_link_fwd<CVFT_ACT_GELU_TANH, 2, true>(a, h, st) : launch_link_fwd<CVFT_ACT_GELU_TANH, 2, false>(a, h, st));
+    if (rc) return rc;
+    CVFT_LAUNCH_CHECK("cvft_block_link_fwd");
     return 0;
 }
 

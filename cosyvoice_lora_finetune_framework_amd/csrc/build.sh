@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value"
 mkdir -p build
 pids=()
 for f in core gemm gemm_glds gemm_p256 gemm_fp8 skinny lora_grad norm attention attn_mfma32 elementwise ce block_fused block_qkv block_lean block_wide block_wide8 block_qkv_wide; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_common.h -nt build/$f.o ] || [ attn_common.h -nt build/$f.o ] || [ block_common.h -nt build/$f.o ] || [ ../../include/cvft.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_common.h -nt build/$f.o ] || [ attn_common.h -nt build/$f.o ] || [ block_common.h -nt build/$f.o ] || [ block_qkv_body.h -nt build/$f.o ] || [ ../../include/cvft.h -nt build/$f.o ]; then
     # attn_mfma32: MFMA results feed VALU softmax code, so keep them in VGPRs (no v_accvgpr copies)
     EXTRA=""; [ $f = attn_mfma32 ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
     hipcc $FLAGS $EXTRA -c $f.hip -o build/$f.o &

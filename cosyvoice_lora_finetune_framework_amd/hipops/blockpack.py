@@ -189,3 +189,18 @@ class BlockQkvPack:
         bwd = [[WTn[w]] for w in range(8)]
         self.W_bwd_wide, nbw = _streams(bwd)
         assert nbw == self.N3 // 16
+
+
+class BlockLinkPack:
+    """Weight stream of cvft_block_link_fwd (include/cvft.h): block i's tail and block i + 1's q|k|v head in one launch on the same
+    rows.  Per wave: its tail fragments in tail order (BlockTailPack.W_fwd), then its 192 head fragments (BlockQkvPack.W_fwd) -- the
+    fragment ring of the kernel runs from one product into the next without a refill."""
+
+    def __init__(self, tail: BlockTailPack, head: BlockQkvPack):
+        assert tail.DI == 512 and 256 <= tail.F <= 1024, "cvft_block_link_fwd: DI == 512, 256 <= F <= 1024"
+        nt, nh = tail.DI // 8 + tail.F // 4, head.N3 // 8
+        t = tail.W_fwd[:4 * nt].view(4, nt, 64, 8)
+        h = head.W_fwd[:4 * nh].view(4, nh, 64, 8)
+        self.W_fwd, n = _streams([[t[w], h[w]] for w in range(4)])
+        assert n == nt + nh
+        self.tail, self.head = tail, head

@@ -385,6 +385,7 @@ _H_ODROP = "_cvft_odrop"              # on y = residual + dropout(linear(.)):   
 _H_PRE_MASKED = "_cvft_pre_masked"    # on the dx a LayerNormForkFn backward returns:   (dxm, p, site, side product or None)
 _H_PRE_V = "_cvft_pre_v"              # on dxm:   (V, Bt data_ptr, scale)
 _H_FORK = "_cvft_fork"                # on x read by both convolutions of a ResnetBlock1D:   token of the "take" conv
+_H_LINK = "_cvft_link"                # on the block output a linked tail launch wrote:   the NEXT block's head products (_QkvHead)
 
 
 def _hand(t: torch.Tensor, name: str, value) -> None:
@@ -1440,7 +1441,7 @@ class BlockTailFn(torch.autograd.Function):
     ff.net.* in the flow target list (config.py), so backward is input gradients only."""
 
     @staticmethod
-    def forward(ctx, o, x0, pack, act: str):
+    def forward(ctx, o, x0, pack, act: str, link=None):
         x0 = _c(x0)
         M = x0.shape[0]
         a = cb.BlockTailArgs()
@@ -1470,9 +1471,21 @@ class BlockTailFn(torch.autograd.Function):
         a.x1, a.gamma, a.beta, a.eps = ptr(x1), ptr(pack.gamma), ptr(pack.beta), pack.eps
         a.b1, a.F, a.b2, a.act = ptr(pack.b1), pack.F, ptr(pack.b2), ACT[act]
         a.z, a.mean, a.rstd, a.out = ptr(z), ptr(mean), ptr(rstd), ptr(out)
-        with _Bracket("block_tail_fwd", 2.0 * M * 256 * (2 * pack.F + (pack.DI if o is not None else 0)),
-                      2.0 * (M * (3 * 256 + pack.DI) + 256 * (2 * pack.F + pack.DI))):
-            check(lib().cvft_block_tail_fwd(C.byref(a), stream()), "cvft_block_tail_fwd")
+        head = None
+        if link is not None and fwd_form == 0 and o is not None and pack.DI == 512 and 256 <= pack.F <= 1024:
+            # the NEXT block's norm1 + q|k|v head rides in the same launch (csrc/block_fused.hip, block_link_fwd_kernel); its products
+            # wait on `out` for that block's BlockQkvFn
+            hpack, hops, hscale, hp, lpack, hneed = link
+            head = _QkvHead(out, hpack, hops, hscale, hp, hneed, wide=False)
+            with _Bracket("block_link_fwd", 2.0 * M * 256 * (2 * pack.F + pack.DI + hpack.N3 + 48) + 2.0 * M * 48 * 512,
+                          2.0 * (M * (3 * 256 + pack.DI + hpack.N3) + 256 * (2 * pack.F + pack.DI + hpack.N3))):
+                check(lib().cvft_block_link_fwd(C.byref(a), C.byref(head.a), ptr(lpack.W_fwd), stream()), "cvft_block_link_fwd")
+            head.a = None
+            _hand(out, _H_LINK, head)
+        else:
+            with _Bracket("block_tail_fwd", 2.0 * M * 256 * (2 * pack.F + (pack.DI if o is not None else 0)),
+                          2.0 * (M * (3 * 256 + pack.DI) + 256 * (2 * pack.F + pack.DI))):
+                check(lib().cvft_block_tail_fwd(C.byref(a), stream()), "cvft_block_tail_fwd")
         ctx.save_for_backward(x1, z, mean, rstd)
         ctx.pack, ctx.act, ctx.has_o = pack, act, o is not None
         return out
@@ -1495,7 +1508,47 @@ class BlockTailFn(torch.autograd.Function):
         with _Bracket("block_tail_bwd", 2.0 * M * 256 * (2 * pack.F + (pack.DI if do is not None else 0)),
                       2.0 * (M * (3 * 256 + pack.F + pack.DI) + 256 * (2 * pack.F + pack.DI))):
             check(lib().cvft_block_tail_bwd(C.byref(a), stream()), "cvft_block_tail_bwd")
-        return do, dx1, None, None
+        return do, dx1, None, None, None
+
+
+class _QkvHead:
+    """Outputs and argument block of one cvft_block_qkv_fwd-shaped launch on x [M, 256]: built by BlockQkvFn.forward for its own
+    launch, or by the PREVIOUS block's linked tail launch (BlockTailFn.forward), which leaves it on the block output (_H_LINK)."""
+
+    def __init__(self, x, pack, ops, scale: float, drop_p: float, need: bool, wide: bool):
+        M = x.shape[0]
+        A, At, Bb, Bbt = ops
+        N3 = pack.N3
+        self.pack, self.ops, self.scale, self.p, self.need = pack, ops, float(scale), float(drop_p), bool(need)
+        self.Y = torch.empty((M, N3), dtype=x.dtype, device=x.device)
+        self.U = torch.empty((M, 48), dtype=x.dtype, device=x.device)
+        self.mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        self.rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        a = cb.BlockQkvArgs()
+        a.M, a.x, a.gamma, a.beta, a.eps, a.mean, a.rstd = M, ptr(x), ptr(pack.gamma), ptr(pack.beta), pack.eps, ptr(self.mean), ptr(self.rstd)
+        a.W_fwd, a.bias, a.N3 = ptr(pack.W_fwd), ptr(pack.bias), N3
+        a.wide = int(wide)
+        a.A, a.lda, a.Bb, a.ldb = ptr(A), A.stride(0), ptr(Bb), Bb.stride(0)
+        a.alpha, a.p = float(scale), float(drop_p)
+        self.xds, self.y, self.sites = [], None, None
+        if drop_p > 0:
+            self.sites = [_next_drop_site() for _ in range(3)]
+            a.seed = ptr(_DROPOUT["seed"])
+            for i, st in enumerate(self.sites):
+                a.sites[i] = st
+            if need:
+                self.xds = [torch.empty_like(x) for _ in range(3)]
+                for i, t in enumerate(self.xds):
+                    a.xd[i] = t.data_ptr()
+        elif need:
+            self.y = torch.empty_like(x)
+            a.y_out = ptr(self.y)
+        a.U, a.ldu, a.Y, a.ldy = ptr(self.U), self.U.stride(0), ptr(self.Y), self.Y.stride(0)
+        self.a = a
+
+    def serves(self, x, pack, ops, scale: float, drop_p: float, need: bool) -> bool:
+        return (self.pack is pack and len(self.ops) == len(ops) and all(a is b for a, b in zip(self.ops, ops)) and self.scale == float(scale)
+                and self.p == float(drop_p) and (self.need or not need) and self.Y.shape[0] == x.shape[0] and self.Y.dtype == x.dtype)
 
 
 class BlockQkvFn(torch.autograd.Function):
@@ -1506,41 +1559,22 @@ class BlockQkvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, Aq, Bq, Ak, Bk, Av, Bv, pack, ops, scale: float, drop_p: float):
+        linked = _take_hand(x, _H_LINK)
         x = _c(x)
         M = x.shape[0]
-        A, At, Bb, Bbt = ops
         N3 = pack.N3
         need = any(ctx.needs_input_grad[:7])
-        Y = torch.empty((M, N3), dtype=x.dtype, device=x.device)
-        U = torch.empty((M, 48), dtype=x.dtype, device=x.device)
-        mean = torch.empty(M, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-        a = cb.BlockQkvArgs()
-        a.M, a.x, a.gamma, a.beta, a.eps, a.mean, a.rstd = M, ptr(x), ptr(pack.gamma), ptr(pack.beta), pack.eps, ptr(mean), ptr(rstd)
-        a.W_fwd, a.bias, a.N3 = ptr(pack.W_fwd), ptr(pack.bias), N3
         mode = block_qkv_wide()
         ctx.wide = mode in ("1", "both")                    # (backward form)
-        a.wide = int(mode in ("1", "both", "fwd"))
-        a.A, a.lda, a.Bb, a.ldb = ptr(A), A.stride(0), ptr(Bb), Bb.stride(0)
-        a.alpha, a.p = float(scale), float(drop_p)
-        xds, y = [], None
-        ctx.sites = None
-        if drop_p > 0:
-            sites = [_next_drop_site() for _ in range(3)]
-            ctx.sites = sites
-            a.seed = ptr(_DROPOUT["seed"])
-            for i, st in enumerate(sites):
-                a.sites[i] = st
-            if need:
-                xds = [torch.empty_like(x) for _ in range(3)]
-                for i, t in enumerate(xds):
-                    a.xd[i] = t.data_ptr()
-        elif need:
-            y = torch.empty_like(x)
-            a.y_out = ptr(y)
-        a.U, a.ldu, a.Y, a.ldy = ptr(U), U.stride(0), ptr(Y), Y.stride(0)
-        with _Bracket("block_qkv_fwd", 2.0 * M * 256 * (N3 + 48) + 2.0 * M * 48 * 512, 2.0 * (M * (256 + N3) + 256 * N3)):
-            check(lib().cvft_block_qkv_fwd(C.byref(a), stream()), "cvft_block_qkv_fwd")
+        if linked is not None and linked.serves(x, pack, ops, scale, drop_p, need):
+            hd = linked                                     # the previous block's tail launch already ran this head on these rows
+        else:
+            hd = _QkvHead(x, pack, ops, scale, drop_p, need, wide=mode in ("1", "both", "fwd"))
+            with _Bracket("block_qkv_fwd", 2.0 * M * 256 * (N3 + 48) + 2.0 * M * 48 * 512, 2.0 * (M * (256 + N3) + 256 * N3)):
+                check(lib().cvft_block_qkv_fwd(C.byref(hd.a), stream()), "cvft_block_qkv_fwd")
+            hd.a = None
+        Y, U, mean, rstd, xds, y = hd.Y, hd.U, hd.mean, hd.rstd, hd.xds, hd.y
+        ctx.sites = hd.sites
         ctx.pack, ctx.ops, ctx.scale, ctx.p = pack, ops, float(scale), float(drop_p)
         ctx.refs = ((Aq, Bq), (Ak, Bk), (Av, Bv))
         ctx.nx = len(xds)
@@ -1627,9 +1661,10 @@ def block_qkv(x, loras, pack, ops, scale: float, drop_p: float = 0.0):
     return BlockQkvFn.apply(x, Aq, Bq, Ak, Bk, Av, Bv, pack, ops, scale, drop_p)
 
 
-def block_tail(o, x0, pack, act: str = "gelu_erf"):
-    """x0 [M, 256] bf16 residual stream, o [M, DI] attention output (or None: feed-forward half only)."""
-    return BlockTailFn.apply(o, x0, pack, act)
+def block_tail(o, x0, pack, act: str = "gelu_erf", link=None):
+    """x0 [M, 256] bf16 residual stream, o [M, DI] attention output (or None: feed-forward half only).
+    link = (head pack, stacked operands, scale, p, BlockLinkPack, need) of the NEXT block's q|k|v head: run it in the same launch."""
+    return BlockTailFn.apply(o, x0, pack, act, link)
 
 
 def can_block_tail(x: torch.Tensor, d_ff: int, d_inner: int) -> bool:
@@ -1652,6 +1687,20 @@ def block_tail_lean() -> int:
     if BLOCK_LEAN in ("0", "1", "2", "3", "4"):
         return int(BLOCK_LEAN)
     return 3 if lib().cvft_concurrent_chains() >= 3 else 0
+# The tail of block i and the head of block i + 1 in one launch (cvft_block_link_fwd; 32-row forms): "0" off, "1" on, "auto" (default)
+# = on while >= 3 chains share the chip.  Graph-timed per boundary at M = 2000 (tools/bench_link.py): tail + 64-row head 47.6 us, tail +
+# 32-row head on two workgroups per row tile 40.6 us, linked 42.9 us -- a workgroup's time is its weight stream (2 MB at ~50 GB/s per
+# CU), which the link does not shorten: it saves the launch boundary only.  Same-box A/B, two pairs of 40 steps: joint 21.02 / 21.02 ->
+# 20.79 / 20.79 ms (the pair there is tail + 64-row head); flow_only 14.51 / 14.51 -> 14.60 / 14.60 (the pair there is the two-workgroup head)
+BLOCK_LINK = _os.environ.get("CVFT_BLOCK_LINK", "auto")
+
+
+def block_link_on() -> bool:
+    if BLOCK_LINK in ("0", "1"):
+        return BLOCK_LINK == "1"
+    return lib().cvft_concurrent_chains() >= 3
+
+
 BLOCK_QKV_FUSE = _os.environ.get("CVFT_BLOCK_QKV_FUSE", "1") != "0"      # first half of the block (norm1 + stacked LoRA q|k|v)
 # its 64-rows-per-workgroup form (csrc/block_qkv_wide.hip): "0" off, "fwd" forward only (the two directions exchange only standard tensors),
 # "1" / "both" forward and backward, "auto" (default) = both while >= 3 chains share the chip.  Same-box A/B, three pairs of 60 steps:

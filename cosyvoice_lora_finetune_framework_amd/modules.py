@@ -328,7 +328,9 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
 
-    def forward(self, x, B, T, length, gelu: str, iso_len: int = 0):
+    def forward(self, x, B, T, length, gelu: str, iso_len: int = 0, next_tb=None):
+        """next_tb: the block that reads this block's output next (same stage), or None -- its norm1 + q|k|v head then rides in
+        this block's tail launch (HF.block_tail(link=...))."""
         a = self.attn1
         head = self._head_fused(x)
         if head is not None:           # norm1 + stacked LoRA q|k|v projection as one row-tile chain launch each way
@@ -337,7 +339,7 @@ class BasicTransformerBlock(nn.Module):
             x, y = hip_layernorm_fork(self.norm1, x, consumers=(a.to_q, a.to_k, a.to_v))
             q, k, v = hip_qkv(a.to_q, a.to_k, a.to_v, y)
         o = HF.attn_bias(q, k, v, B, a.heads, T, length, a.scale, iso_len)
-        return self._tail(o, x, gelu)
+        return self._tail(o, x, gelu, next_tb)
 
     def _head_fused(self, x):
         """(loras, pack, stacked operands, scale, p) for HF.block_qkv when the block's first half can take the row-tile chain
@@ -386,14 +388,30 @@ class BasicTransformerBlock(nn.Module):
             self.__dict__["_cvft_tail"] = hit
         return hit[1]
 
-    def _tail(self, o, x, gelu: str):
+    def _link(self, pack, next_tb, x):
+        """link argument of HF.block_tail: the next block's head operands + the linked weight stream, or None"""
+        if next_tb is None or not HF.block_link_on() or pack.DI != 512 or not 256 <= pack.F <= 1024:
+            return None
+        head = next_tb._head_fused(x)
+        if head is None:
+            return None
+        loras, hpack, ops, scale, p = head
+        hit = self.__dict__.get("_cvft_link")
+        if hit is None or hit[0] is not pack or hit[1] is not hpack:
+            from .hipops.blockpack import BlockLinkPack
+            hit = (pack, hpack, BlockLinkPack(pack, hpack))
+            self.__dict__["_cvft_link"] = hit
+        need = torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for pair in loras for t in pair))
+        return hpack, ops, scale, p, hit[2], need
+
+    def _tail(self, o, x, gelu: str, next_tb=None):
         """x + to_out(o), then + ff(norm3(.)): one row-tile chain launch each way (HF.block_tail) on the bf16 path, else
         the launch-per-stage form (GEMM, LayerNorm, two GEMMs)."""
         act = "gelu_tanh" if self.ff.net[0].approximate == "tanh" else gelu
         if HF.can_block_tail(x, self.ff.net[0].proj.out_features, self.attn1.to_out[0].in_features) and o.dtype == x.dtype:
             pack = self._tail_pack()
             if pack is not None:
-                return HF.block_tail(o, x, pack, act)
+                return HF.block_tail(o, x, pack, act, self._link(pack, next_tb, x))
         x = hip_linear(self.attn1.to_out[0], o, residual=x)
         x, y = hip_layernorm_fork(self.norm3, x)
         return hip_ffn(self.ff.net[0].proj, self.ff.net[2], y, act, residual=x)
@@ -471,8 +489,8 @@ class ConditionalDecoder(nn.Module):
         te = (lambda l: None) if t_true is None else (lambda l: t_true[l:l + 1])
         for resnet, tblocks, down in self.down_blocks:
             x = resnet(x, B, Tc, lc, temb_mish, te(lv))
-            for tb in tblocks:
-                x = tb(x, B, Tc, lc, gelu, iso(Tc))
+            for i, tb in enumerate(tblocks):
+                x = tb(x, B, Tc, lc, gelu, iso(Tc), tblocks[i + 1] if i + 1 < len(tblocks) else None)
             hiddens.append((x, Tc, lc, lv))
             if isinstance(down, Downsample1D):
                 pk = conv_pack(down.conv, dtype)
@@ -484,15 +502,15 @@ class ConditionalDecoder(nn.Module):
                 # reference appends mask_down[:, :, ::2] then drops it (masks = masks[:-1])
         for resnet, tblocks in self.mid_blocks:
             x = resnet(x, B, Tc, lc, temb_mish, te(lv))
-            for tb in tblocks:
-                x = tb(x, B, Tc, lc, gelu, iso(Tc))
+            for i, tb in enumerate(tblocks):
+                x = tb(x, B, Tc, lc, gelu, iso(Tc), tblocks[i + 1] if i + 1 < len(tblocks) else None)
         for resnet, tblocks, up in self.up_blocks:
             skip, Ts, ls, lvs = hiddens.pop()
             assert Ts == Tc, (Ts, Tc)
             x = torch.cat([x, skip], dim=1)
             x = resnet(x, B, Ts, ls, temb_mish, te(lvs))
-            for tb in tblocks:
-                x = tb(x, B, Ts, ls, gelu, iso(Ts))
+            for i, tb in enumerate(tblocks):
+                x = tb(x, B, Ts, ls, gelu, iso(Ts), tblocks[i + 1] if i + 1 < len(tblocks) else None)
             if isinstance(up, Upsample1D):
                 Tn = hiddens[-1][1]                 # cropped to the next skip's length
                 x = HF.conv1d(x, conv_pack(up.conv, dtype), B, Ts, Tn, in_len=ls)

@@ -480,6 +480,13 @@ typedef struct {
                                             (block_qkv_wide.hip, 8 waves), W_bwd = wave w's feature tile w over all of 3N, [ks] */
 } cvft_block_qkv_bwd_args;
 int cvft_block_qkv_bwd(const cvft_block_qkv_bwd_args* a, void* stream);
+/* The tail of block i and the head of block i + 1 (the two halves either side of a block boundary of modules.py:349-375 inside one
+ * stage of the estimator) on the same 32 rows in ONE launch: exactly cvft_block_tail_fwd(tail) followed by cvft_block_qkv_fwd(head)
+ * with head->x == tail->out -- same outputs, bit for bit, same masks -- but the block output stays in registers between the two and
+ * the weight ring never drains.  32-row forms only (tail->lean == 0, head->wide == 0), with the output projection (DI == 512),
+ * 256 <= F <= 1024.  W_link replaces tail->W_fwd and head->W_fwd: per wave w its DI/8 + F/4 tail fragments (as in W_fwd) followed
+ * by its 192 head fragments, [4 waves][DI/8 + F/4 + 192] + 32 fragments of padding (hipops/blockpack.py, BlockLinkPack). */
+int cvft_block_link_fwd(const cvft_block_tail_args* tail, const cvft_block_qkv_args* head, const void* W_link, void* stream);
 
 /* Diagnostics (development only): cycle stamps of the default 128x128 LDS-DMA GEMM kernel (CVFT_GLDS_BIG=15 launches its
  * stamped build; tools/glds_stamps.py); host_out receives 256 uint64. */

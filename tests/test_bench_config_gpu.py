@@ -191,6 +191,38 @@ def test_hand_overs_survive_recycled_allocations():
         assert rg < 1e-5, rg
 
 
+def test_linked_block_launches_equal_separate_launches():
+    """The estimator's block boundary in one launch (cvft_block_link_fwd: block i's tail + block i + 1's norm1 / q|k|v head; DESIGN
+    section 14) against the separate launches, through the product trainer in train mode (every dropout on, same mask seed): the
+    linked launch computes the same numbers in the same order, so losses and the flat LoRA gradient agree to the fp32-atomics noise
+    of one tensor -- and the heads really were taken from the linked launches (42 of the 56 blocks of a chain have a predecessor
+    in their stage)."""
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    B, T = 4, 120
+    batches = [synth_batch([T, 100, 90, 110], seed=80 + i) for i in range(2)]
+    dfn = lambda ep, bi, b: cfm_draws(B, T, 300 + bi)
+    res, taken = [], []
+    keep = HF.BLOCK_LINK
+    try:
+        for mode in ("0", "1"):
+            HF.BLOCK_LINK = mode
+            HF.HANDS_TAKEN.pop(HF._H_LINK, None)
+            jm = _full_joint(dropout=True)
+            tr, grads = _fit(jm, batches, dfn, train_mode=True, use_graph=True, seed_base=555, max_graphs=0)
+            res.append((tr.history, grads))
+            taken.append(HF.HANDS_TAKEN.get(HF._H_LINK, 0))
+    finally:
+        HF.BLOCK_LINK = keep
+    assert taken[0] == 0 and taken[1] >= 2 * 36, taken
+    for i in range(2):
+        for k in ("loss", "llm_loss", "flow_loss", "grad_norm"):
+            assert abs(res[0][0][i][k] - res[1][0][i][k]) <= 1e-6 * abs(res[0][0][i][k]), (i, k, res[0][0][i], res[1][0][i])
+        rg = rel(res[1][1][i], res[0][1][i])
+        print(f"[linked block launches] step {i}: flat gradient rel-L2 {rg:.2e}, heads taken {taken[1]}")
+        assert rg < 1e-5, rg
+
+
 def test_replay_of_small_layout_after_larger_layout_replaced_workspaces(tiny_meta):
     """capture (T = 20) -> capture (T = 160: more row blocks, every LoRA slab workspace is re-allocated) -> replay (T = 20):
     the first captured step still writes the workspace it was captured with (kept alive in `_cvft_part_retired`)."""

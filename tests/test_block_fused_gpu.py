@@ -203,3 +203,88 @@ def test_block_qkv_matches_fp64_reference(M, p, wide):
     assert rel(V, Vref) < 1e-2, rel(V, Vref)
     assert rel(dx, dxref) < 1.5e-2, rel(dx, dxref)
     HF._DROPOUT["seed"] = None
+
+
+def _tail_args(cb, M, o, x0, pack, x1, out, mean, rstd, z, act):
+    a = cb.BlockTailArgs()
+    a.M, a.o, a.ldo, a.x0, a.DI, a.W_fwd, a.bo = M, cb.ptr(o), o.stride(0), cb.ptr(x0), pack.DI, cb.ptr(pack.W_fwd), cb.ptr(pack.bo)
+    a.x1, a.gamma, a.beta, a.eps = cb.ptr(x1), cb.ptr(pack.gamma), cb.ptr(pack.beta), pack.eps
+    a.b1, a.F, a.b2, a.act = cb.ptr(pack.b1), pack.F, cb.ptr(pack.b2), act
+    a.z, a.mean, a.rstd, a.out, a.lean = cb.ptr(z), cb.ptr(mean), cb.ptr(rstd), cb.ptr(out), 0
+    return a
+
+
+@pytest.mark.parametrize("act", ["gelu_erf", "gelu_tanh"])
+@pytest.mark.parametrize("M,Fh,p", [(64, 1024, 0.05), (250, 1024, 0.0), (37, 256, 0.3), (4000, 1024, 0.05), (2000, 512, 0.0)])
+def test_block_link_equals_tail_then_head_bitwise(M, Fh, p, act):
+    """cvft_block_link_fwd (block i's tail + block i + 1's q|k|v head in one launch, the block output kept in registers) against the
+    two launches it replaces, cvft_block_tail_fwd then cvft_block_qkv_fwd on the stored output: every output of both -- x1, out,
+    the saved gelu' workspace, both LayerNorms' statistics, U, Y, the dropped copies -- bit for bit (same arithmetic in the same
+    order, same masks); ragged M (rows beyond M untouched)."""
+    from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    from cosyvoice_lora_finetune_framework_amd.hipops.blockpack import BlockLinkPack, BlockQkvPack, BlockTailPack
+    import ctypes as C
+    d = lambda t: t.to(DEV)
+    w = _weights(512, Fh, seed=M)
+    wd = {k: d(v) for k, v in w.items()}
+    tpack = BlockTailPack(wd["wo"], wd["bo"], wd["gamma"], wd["beta"], 1e-5, wd["w1"], wd["b1"], wd["w2"], wd["b2"])
+    wq, _, _, _ = _qkv_case(M, p, seed=M + 7)
+    hpack = BlockQkvPack(d(wq["wqkv"]), d(wq["bias"]), d(wq["gamma"]), d(wq["beta"]), 1e-5)
+    lpack = BlockLinkPack(tpack, hpack)
+    A = torch.cat(wq["A"], 0).to(torch.bfloat16)
+    Bb = torch.zeros(1536, 48)
+    for t in range(3):
+        Bb[512 * t:512 * (t + 1), 16 * t:16 * (t + 1)] = wq["B"][t]
+    A, Bb = d(A), d(Bb.to(torch.bfloat16))
+    g = torch.Generator().manual_seed(M + 1)
+    o = d(torch.randn(M, 512, generator=g).to(torch.bfloat16))
+    x0 = d((torch.randn(M, 256, generator=g) * 2.0 + 0.3).to(torch.bfloat16))
+    HF._DROPOUT["seed"] = torch.full((1,), 987654321, dtype=torch.int64, device=DEV)
+    sites = [3, 4, 8]
+    zrows = -(-M // 64) * 64
+    res = {}
+    for linked in (False, True):
+        bf = lambda *s: torch.full(s, 7.0, dtype=torch.bfloat16, device=DEV)       # (sentinel: untouched tails must match too)
+        x1, out, z = bf(M, 256), bf(M, 256), bf(zrows * Fh)
+        mean, rstd, mean2, rstd2 = (torch.full((M,), 7.0, device=DEV) for _ in range(4))
+        Y, U = bf(M, 1536), bf(M, 48)
+        outs = [bf(M, 256) for _ in range(3)]
+        a = _tail_args(cb, M, o, x0, tpack, x1, out, mean, rstd, z, HF.ACT[act])
+        q = cb.BlockQkvArgs()
+        q.M, q.x, q.gamma, q.beta, q.eps, q.mean, q.rstd = M, cb.ptr(out), cb.ptr(hpack.gamma), cb.ptr(hpack.beta), 1e-5, cb.ptr(mean2), cb.ptr(rstd2)
+        q.W_fwd, q.bias, q.N3, q.wide = cb.ptr(hpack.W_fwd), cb.ptr(hpack.bias), 1536, 0
+        q.A, q.lda, q.Bb, q.ldb = cb.ptr(A), 256, cb.ptr(Bb), 48
+        q.alpha, q.p = 2.0, p
+        if p > 0:
+            q.seed = cb.ptr(HF._DROPOUT["seed"])
+            for i in range(3):
+                q.sites[i] = sites[i]
+                q.xd[i] = outs[i].data_ptr()
+        else:
+            q.y_out = cb.ptr(outs[0])
+        q.U, q.ldu, q.Y, q.ldy = cb.ptr(U), 48, cb.ptr(Y), 1536
+        if linked:
+            cb.check(cb.lib().cvft_block_link_fwd(C.byref(a), C.byref(q), cb.ptr(lpack.W_fwd), cb.stream()), "link")
+        else:
+            cb.check(cb.lib().cvft_block_tail_fwd(C.byref(a), cb.stream()), "tail")
+            cb.check(cb.lib().cvft_block_qkv_fwd(C.byref(q), cb.stream()), "head")
+        torch.cuda.synchronize()
+        res[linked] = dict(x1=x1, out=out, z=z[:M * Fh] if M % 32 == 0 else z, mean=mean, rstd=rstd, mean2=mean2, rstd2=rstd2, Y=Y, U=U,
+                           **{f"xd{i}": t for i, t in enumerate(outs)})
+    HF._DROPOUT["seed"] = None
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), (k, rel(res[True][k], res[False][k]))
+    assert float(res[True]["Y"].float().abs().max()) > 0.1
+
+
+def test_block_link_refuses_other_forms():
+    """the linked launch exists for the 32-row forms with the output projection only: anything else is an argument error, not a
+    silently different kernel"""
+    from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
+    import ctypes as C
+    a, q = cb.BlockTailArgs(), cb.BlockQkvArgs()
+    a.M = q.M = 64
+    a.F, q.N3, a.DI, a.lean = 1024, 1536, 512, 2
+    w = torch.zeros(16, device=DEV)
+    assert cb.lib().cvft_block_link_fwd(C.byref(a), C.byref(q), cb.ptr(w), cb.stream()) != 0
