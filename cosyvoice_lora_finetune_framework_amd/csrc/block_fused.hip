@@ -296,10 +296,16 @@ __device__ __forceinline__ void bf_ffn_second_bwd(bf16x8 (&ring)[BF_RING], const
 }
 
 // CR = rounds of 32 fragments in the output projection's dgrad stream (DI / 256; 0 = none)
-template <int ACT, int CR>
-__global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// LINK (block_link_bwd_kernel): the NEXT block's head backward ran in front on the same rows -- dy arrives in registers (dyw: this
+// wave's 64 features of the 32 rows, as stored), the ring already holds this wave's first 32 fragments of the tail's stream and nx
+// points behind them.
+template <int ACT, int CR, bool LINK>
+__device__ __forceinline__ void bt_bwd_body(const TailBwd& a, char* smem, bf16x8 (&ring)[BF_RING], const bf16x8* nx, const bf16x4 (&dyw)[2][4]) {
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (LINK: the lane re-enters through an empty asm, so that this half's addresses are computed here and not in front of the head's
+    //  loop, where they would spill -- block_link_fwd_kernel has the story)
+    if (LINK) asm volatile("" : "+v"(lane));
     const int m = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BF_ROWS;
     const int row = min(m0 + m, a.M - 1);
@@ -309,8 +315,17 @@ __global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
     // LayerNorm backward's operands (used at the end: requested now so that they never queue behind the ring), then the ring
     // dy as B fragments (natural k order): lane (m, h) holds dy[row][16 ks + 8 h .. + 7]
     bf16x8 dyf[BF_KS];
+    if (!LINK) {
 #pragma unroll
-    for (int ks = 0; ks < BF_KS; ++ks) dyf[ks] = *reinterpret_cast<const bf16x8*>(a.dy + (size_t)row * BF_D + 16 * ks + 8 * h);
+        for (int ks = 0; ks < BF_KS; ++ks) dyf[ks] = *reinterpret_cast<const bf16x8*>(a.dy + (size_t)row * BF_D + 16 * ks + 8 * h);
+    } else {
+        // through the LDS tile: every wave needs all 256 features of its rows as B fragments
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<bf16x4*>(smem + BF_LDS_TILE + bf_tile_off(m, 64 * wave + 32 * c2 + 8 * g + 4 * h)) = dyw[c2][g];
+    }
     const int ntw = a.F / 128;
     const bf16x8* zp = reinterpret_cast<const bf16x8*>(a.z) + ((size_t)(blockIdx.x * (a.F / 32) + wave * ntw) * 64 + lane) * 2;
     bf16x8 zs[2] = {zp[0], zp[1]};
@@ -321,18 +336,23 @@ __global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
         for (int g = 0; g < 4; ++g) {
             const int c = 64 * wave + 32 * c2 + 8 * g + 4 * h;
             xr[c2][g] = *reinterpret_cast<const bf16x4*>(a.x1 + (size_t)row * BF_D + c);
-            dr[c2][g] = *reinterpret_cast<const bf16x4*>(a.dy + (size_t)row * BF_D + c);
+            dr[c2][g] = LINK ? dyw[c2][g] : *reinterpret_cast<const bf16x4*>(a.dy + (size_t)row * BF_D + c);
         }
     const float mean = a.mean[row], rstd = a.rstd[row];
+    // (LINK: slot 0 held the head's gamma, last read in front of the head's two row-sum barriers)
     if (wave == 0) reinterpret_cast<f32x4*>(smem + BF_LDS_PAR)[lane] = reinterpret_cast<const f32x4*>(a.gamma)[lane];
     const float* pgam = reinterpret_cast<const float*>(smem + BF_LDS_PAR);
-    const bf16x8* nx = a.Wst + (size_t)wave * a.wave_frags * 64 + lane;
-    bf16x8 ring[BF_RING];
-#pragma unroll
-    for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
-    nx += BF_RING * 64;
     BfTouch touched;
-    if (BF_TOUCH) touched = bf_touch_stream(a.Wst, 4 * a.wave_frags);
+    if (!LINK) {
+        nx = a.Wst + (size_t)wave * a.wave_frags * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < BF_RING; ++i) ring[i] = nx[i * 64];
+        nx += BF_RING * 64;
+        if (BF_TOUCH) touched = bf_touch_stream(a.Wst, 4 * a.wave_frags);
+    } else {
+        __syncthreads();
+        bf_tile_read(smem, lane, dyf);
+    }
 
     // stream: W2^T(0), then per tile t: W2^T(t+1) (slots 16..31), W1^T(t) (slots 0..15); the last tile's W1^T in slots 16..31;
     // then the output projection's dgrad (CR rounds of 32)
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
             if (rvalid) *reinterpret_cast<bf16x4*>(a.dx1 + (size_t)row * BF_D + c) = dx;
             if (CR > 0) *reinterpret_cast<bf16x4*>(smem + BF_LDS_TILE + bf_tile_off(m, c)) = dx;
         }
-    if (BF_TOUCH && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.dx1[0] = (bf16_t)0.f;  // (keeps the prefetch loads alive; never true)
+    if (BF_TOUCH && !LINK && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.dx1[0] = (bf16_t)0.f;  // (keeps the prefetch loads alive; never true)
     if (CR == 0) return;
     __syncthreads();
     // ---- do = dx1 Wo: wave w owns output features [w*DI/4, (w+1)*DI/4): 2 feature tiles per round, stream order [ks][f2]
@@ -424,6 +444,25 @@ __global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
                 }
         }
     }
+}
+
+template <int ACT, int CR>
+__global__ __launch_bounds__(256, 1) void block_tail_bwd_kernel(TailBwd a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16x8 ring[BF_RING];
+    bf16x4 none[2][4];
+    bt_bwd_body<ACT, CR, false>(a, smem, ring, nullptr, none);
+}
+// The head backward of block i + 1 (block_qkv_body.h, bq_bwd_body) and the tail backward of block i on the same 32 rows: the
+// gradient at the block boundary stays in registers, q.Wst is the linked stream (per wave: 192 head fragments, then the tail's).
+template <int ACT, int CR, bool DROP>
+__global__ __launch_bounds__(256, 1) void block_link_bwd_kernel(QkvBwd q, TailBwd a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16x8 ring[BF_RING];
+    const bf16x8* nx;
+    bf16x4 dxo[2][4];
+    bq_bwd_body<DROP, true>(q, smem, ring, nx, dxo);
+    bt_bwd_body<ACT, CR, true>(a, smem, ring, nx, dxo);
 }
 
 template <int ACT, int AR>
@@ -526,6 +565,51 @@ extern "C" int cvft_block_link_fwd(const cvft_block_tail_args* p, const cvft_blo
                        : (drop ? launch_link_fwd<CVFT_ACT_GELU_TANH, 2, true>(a, h, st) : launch_link_fwd<CVFT_ACT_GELU_TANH, 2, false>(a, h, st));
     if (rc) return rc;
     CVFT_LAUNCH_CHECK("cvft_block_link_fwd");
+    return 0;
+}
+
+template <int ACT, int CR, bool DROP>
+static int launch_link_bwd(const QkvBwd& q, const TailBwd& a, hipStream_t st) {
+    static int ready = 0;
+    if (!ready) { if (bf_prepare(block_link_bwd_kernel<ACT, CR, DROP>, BF_LDS_TOTAL_DMA)) return -2; ready = 1; }
+    hipLaunchKernelGGL((block_link_bwd_kernel<ACT, CR, DROP>), dim3((a.M + BF_ROWS - 1) / BF_ROWS), dim3(256), BF_LDS_TOTAL_DMA, st, q, a);
+    return 0;
+}
+
+// The head backward of block i + 1 and the tail backward of block i on the same rows in one launch (include/cvft.h): both argument
+// blocks mean what they mean for cvft_block_qkv_bwd / cvft_block_tail_bwd, with q->wide == 0, p->lean == 0 and p->dy == q->dx.
+extern "C" int cvft_block_link_bwd(const cvft_block_qkv_bwd_args* q, const cvft_block_tail_bwd_args* p, const void* W_link, void* stream) {
+    CVFT_CHECK_ARG(p && q && W_link && al16(W_link), "cvft_block_link_bwd: null / unaligned operand");
+    CVFT_CHECK_ARG(p->M > 0 && q->M == p->M && p->F % 128 == 0 && p->F >= 256 && p->F <= 1024 && q->N3 == 1536,
+                   "cvft_block_link_bwd: need equal M > 0, 256 <= F <= 1024 (F %% 128 == 0), 3N == 1536 (M=%d/%d F=%d)", p->M, q->M, p->F);
+    CVFT_CHECK_ARG(p->lean == 0 && q->wide == 0 && p->dout && p->DI == 512 && p->lddo % 4 == 0 && al16(p->dout),
+                   "cvft_block_link_bwd: the 32-row forms only (lean == 0, wide == 0), with the output projection's dgrad (DI == 512, dout)");
+    CVFT_CHECK_ARG(q->dY && q->x && q->gamma && q->mean && q->rstd && q->At && q->Bbt && q->V && q->dx && p->x1 && p->dy == q->dx &&
+                   p->gamma && p->mean && p->rstd && p->z && p->dx1, "cvft_block_link_bwd: null operand, or tail dy != head dx");
+    CVFT_CHECK_ARG(p->act == CVFT_ACT_GELU_ERF || p->act == CVFT_ACT_GELU_TANH, "cvft_block_link_bwd: act must be a GELU form");
+    CVFT_CHECK_ARG(cvft_drop_rate_ok(q->p) && (q->p == 0.f || q->seed), "cvft_block_link_bwd: bad dropout args (p == 0 or 2^-16 <= p <= 1 - 2^-16, seed)");
+    CVFT_CHECK_ARG(al16(q->dY) && al16(q->x) && al16(q->gamma) && al16(q->Bbt) && al16(q->dx) && (!q->dres || al16(q->dres)) &&
+                   q->lddy % 8 == 0 && q->ldbt % 8 == 0 && q->ldat % 4 == 0 && q->ldv % 4 == 0 && (reinterpret_cast<uintptr_t>(q->At) & 7) == 0 &&
+                   (reinterpret_cast<uintptr_t>(q->V) & 7) == 0 && al16(p->x1) && al16(p->gamma) && al16(p->z) && al16(p->dx1),
+                   "cvft_block_link_bwd: operands must be 16-byte aligned (row pitches: lddy / ldbt %% 8, ldat / ldv / lddo %% 4)");
+    QkvBwd h;
+    h.M = q->M; h.dY = (const bf16_t*)q->dY; h.lddy = q->lddy; h.dres = (const bf16_t*)q->dres; h.x = (const bf16_t*)q->x;
+    h.gamma = q->gamma; h.mean = q->mean; h.rstd = q->rstd; h.Wst = (const bf16x8*)W_link;
+    h.wave_frags = q->N3 / 8 + p->F / 4 + p->DI / 8; h.N3 = q->N3;
+    h.At = (const bf16_t*)q->At; h.ldat = q->ldat; h.Bbt = (const bf16_t*)q->Bbt; h.ldbt = q->ldbt;
+    h.alpha = q->alpha; h.p = q->p; h.seed = (const long long*)q->seed;
+    for (int i = 0; i < 3; ++i) h.sites[i] = q->sites[i];
+    h.V = (bf16_t*)q->V; h.ldv = q->ldv; h.dx = (bf16_t*)q->dx;
+    TailBwd a;
+    a.M = p->M; a.x1 = (const bf16_t*)p->x1; a.dy = (const bf16_t*)p->dy; a.gamma = p->gamma; a.mean = p->mean; a.rstd = p->rstd;
+    a.z = (const bf16_t*)p->z; a.Wst = nullptr; a.wave_frags = p->F / 4 + p->DI / 8; a.F = p->F;
+    a.dx1 = (bf16_t*)p->dx1; a.dout = (bf16_t*)p->dout; a.lddo = p->lddo;
+    const bool erf = p->act == CVFT_ACT_GELU_ERF, drop = q->p > 0.f;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = erf ? (drop ? launch_link_bwd<CVFT_ACT_GELU_ERF, 2, true>(h, a, st) : launch_link_bwd<CVFT_ACT_GELU_ERF, 2, false>(h, a, st))
+                       : (drop ? launch_link_bwd<CVFT_ACT_GELU_TANH, 2, true>(h, a, st) : launch_link_bwd<CVFT_ACT_GELU_TANH, 2, false>(h, a, st));
+    if (rc) return rc;
+    CVFT_LAUNCH_CHECK("cvft_block_link_bwd");
     return 0;
 }
 

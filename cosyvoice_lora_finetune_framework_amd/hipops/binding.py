@@ -154,6 +154,7 @@ SIGNATURES = {
     "cvft_block_tail_bwd": [C.POINTER(BlockTailBwdArgs), _p],
     "cvft_block_qkv_fwd": [C.POINTER(BlockQkvArgs), _p],
     "cvft_block_link_fwd": [C.POINTER(BlockTailArgs), C.POINTER(BlockQkvArgs), _p, _p],
+    "cvft_block_link_bwd": [C.POINTER(BlockQkvBwdArgs), C.POINTER(BlockTailBwdArgs), _p, _p],
     "cvft_block_qkv_bwd": [C.POINTER(BlockQkvBwdArgs), _p],
 }
 

@@ -192,9 +192,10 @@ class BlockQkvPack:
 
 
 class BlockLinkPack:
-    """Weight stream of cvft_block_link_fwd (include/cvft.h): block i's tail and block i + 1's q|k|v head in one launch on the same
-    rows.  Per wave: its tail fragments in tail order (BlockTailPack.W_fwd), then its 192 head fragments (BlockQkvPack.W_fwd) -- the
-    fragment ring of the kernel runs from one product into the next without a refill."""
+    """Weight streams of cvft_block_link_fwd / _bwd (include/cvft.h): block i's tail and block i + 1's q|k|v head in one launch on the
+    same rows.  Forward, per wave: its tail fragments in tail order (BlockTailPack.W_fwd), then its 192 head fragments
+    (BlockQkvPack.W_fwd) -- the fragment ring of the kernel runs from one product into the next without a refill; backward: the
+    head's W_bwd fragments, then the tail's."""
 
     def __init__(self, tail: BlockTailPack, head: BlockQkvPack):
         assert tail.DI == 512 and 256 <= tail.F <= 1024, "cvft_block_link_fwd: DI == 512, 256 <= F <= 1024"
@@ -202,5 +203,10 @@ class BlockLinkPack:
         t = tail.W_fwd[:4 * nt].view(4, nt, 64, 8)
         h = head.W_fwd[:4 * nh].view(4, nh, 64, 8)
         self.W_fwd, n = _streams([[t[w], h[w]] for w in range(4)])
+        assert n == nt + nh
+        # backward (cvft_block_link_bwd): the head's backward runs first, then the tail's
+        tb = tail.W_bwd[:4 * nt].view(4, nt, 64, 8)
+        hb = head.W_bwd[:4 * nh].view(4, nh, 64, 8)
+        self.W_bwd, n = _streams([[hb[w], tb[w]] for w in range(4)])
         assert n == nt + nh
         self.tail, self.head = tail, head

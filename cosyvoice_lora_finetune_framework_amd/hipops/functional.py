@@ -386,6 +386,7 @@ _H_PRE_MASKED = "_cvft_pre_masked"    # on the dx a LayerNormForkFn backward ret
 _H_PRE_V = "_cvft_pre_v"              # on dxm:   (V, Bt data_ptr, scale)
 _H_FORK = "_cvft_fork"                # on x read by both convolutions of a ResnetBlock1D:   token of the "take" conv
 _H_LINK = "_cvft_link"                # on the block output a linked tail launch wrote:   the NEXT block's head products (_QkvHead)
+_H_LINK_BWD = "_cvft_link_bwd"        # on the dx a linked head backward returns:   the _LinkRec whose tail backward ran in that launch
 
 
 def _hand(t: torch.Tensor, name: str, value) -> None:
@@ -1481,6 +1482,8 @@ class BlockTailFn(torch.autograd.Function):
                           2.0 * (M * (3 * 256 + pack.DI + hpack.N3) + 256 * (2 * pack.F + pack.DI + hpack.N3))):
                 check(lib().cvft_block_link_fwd(C.byref(a), C.byref(head.a), ptr(lpack.W_fwd), stream()), "cvft_block_link_fwd")
             head.a = None
+            head.tail_rec = _LinkRec(lpack)
+            head.tail_rec.tail_ctx = ctx                # (one-way: head -> record -> this context, the direction of the autograd edges)
             _hand(out, _H_LINK, head)
         else:
             with _Bracket("block_tail_fwd", 2.0 * M * 256 * (2 * pack.F + (pack.DI if o is not None else 0)),
@@ -1491,24 +1494,44 @@ class BlockTailFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def tail_bwd_args(ctx, dy, lean: int, want_do: bool):
         x1, z, mean, rstd = ctx.saved_tensors
         pack = ctx.pack
-        dy = _c(dy)
         M = x1.shape[0]
         a = cb.BlockTailBwdArgs()
         dx1 = torch.empty_like(x1)
         do = None
         a.M, a.x1, a.dy, a.gamma, a.mean, a.rstd, a.z = M, ptr(x1), ptr(dy), ptr(pack.gamma), ptr(mean), ptr(rstd), ptr(z)
-        a.W_bwd, a.F, a.DI, a.act, a.dx1 = ptr((pack.W_bwd, pack.W_bwd_lean, pack.W_bwd_wide)[ctx.lean]), pack.F, pack.DI, ACT[ctx.act], ptr(dx1)
-        a.lean = int(ctx.lean)
-        if ctx.has_o and ctx.needs_input_grad[0]:
+        a.W_bwd, a.F, a.DI, a.act, a.dx1 = ptr((pack.W_bwd, pack.W_bwd_lean, pack.W_bwd_wide)[lean]), pack.F, pack.DI, ACT[ctx.act], ptr(dx1)
+        a.lean = int(lean)
+        if want_do:
             do = torch.empty((M, pack.DI), dtype=x1.dtype, device=x1.device)
             a.dout, a.lddo = ptr(do), do.stride(0)
+        return a, dx1, do
+
+    @staticmethod
+    def backward(ctx, dy):
+        rec = _take_hand(dy, _H_LINK_BWD)
+        if rec is not None and rec.tail_ctx is ctx and rec.results is not None:
+            dx1, do = rec.results                       # the next block's head backward ran this tail backward in its launch
+            rec.results = rec.tail_ctx = None
+            return do, dx1, None, None, None
+        pack = ctx.pack
+        dy = _c(dy)
+        M = dy.shape[0]
+        a, dx1, do = BlockTailFn.tail_bwd_args(ctx, dy, ctx.lean, ctx.has_o and ctx.needs_input_grad[0])
         with _Bracket("block_tail_bwd", 2.0 * M * 256 * (2 * pack.F + (pack.DI if do is not None else 0)),
                       2.0 * (M * (3 * 256 + pack.F + pack.DI) + 256 * (2 * pack.F + pack.DI))):
             check(lib().cvft_block_tail_bwd(C.byref(a), stream()), "cvft_block_tail_bwd")
         return do, dx1, None, None, None
+
+
+class _LinkRec:
+    """One block boundary that ran as a linked launch in forward (BlockTailFn.forward -> _QkvHead.tail_rec -> BlockQkvFn's ctx):
+    lets the head's backward find the tail's autograd context, and the tail's backward recognise its results."""
+
+    def __init__(self, lpack):
+        self.lpack, self.tail_ctx, self.results = lpack, None, None
 
 
 class _QkvHead:
@@ -1530,7 +1553,7 @@ class _QkvHead:
         a.wide = int(wide)
         a.A, a.lda, a.Bb, a.ldb = ptr(A), A.stride(0), ptr(Bb), Bb.stride(0)
         a.alpha, a.p = float(scale), float(drop_p)
-        self.xds, self.y, self.sites = [], None, None
+        self.xds, self.y, self.sites, self.tail_rec = [], None, None, None
         if drop_p > 0:
             self.sites = [_next_drop_site() for _ in range(3)]
             a.seed = ptr(_DROPOUT["seed"])
@@ -1566,8 +1589,10 @@ class BlockQkvFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad[:7])
         mode = block_qkv_wide()
         ctx.wide = mode in ("1", "both")                    # (backward form)
+        ctx.link_rec = None
         if linked is not None and linked.serves(x, pack, ops, scale, drop_p, need):
             hd = linked                                     # the previous block's tail launch already ran this head on these rows
+            ctx.link_rec = hd.tail_rec
         else:
             hd = _QkvHead(x, pack, ops, scale, drop_p, need, wide=mode in ("1", "both", "fwd"))
             with _Bracket("block_qkv_fwd", 2.0 * M * 256 * (N3 + 48) + 2.0 * M * 48 * 512, 2.0 * (M * (256 + N3) + 256 * N3)):
@@ -1607,8 +1632,22 @@ class BlockQkvFn(torch.autograd.Function):
             for i, st in enumerate(ctx.sites):
                 a.sites[i] = st
         a.V, a.ldv, a.dx = ptr(V), V.stride(0), ptr(dx)
-        with _Bracket("block_qkv_bwd", 2.0 * M * N3 * (256 + 48) + 2.0 * M * 48 * 256, 2.0 * (M * (N3 + 3 * 256) + 256 * N3)):
-            check(lib().cvft_block_qkv_bwd(C.byref(a), stream()), "cvft_block_qkv_bwd")
+        rec = ctx.link_rec
+        tctx = None if rec is None else rec.tail_ctx
+        if (tctx is not None and block_link_bwd_on() and tctx.has_o and tctx.needs_input_grad[0] and tctx.pack.DI == 512
+                and 256 <= tctx.pack.F <= 1024):
+            # the PREVIOUS block's tail backward rides in this launch (csrc/block_fused.hip, block_link_bwd_kernel): dx is its dy
+            a.wide, a.W_bwd = 0, ptr(pack.W_bwd)
+            ta, dx1, do = BlockTailFn.tail_bwd_args(tctx, dx, 0, True)
+            tp = tctx.pack
+            with _Bracket("block_link_bwd", 2.0 * M * N3 * (256 + 48) + 2.0 * M * 48 * 256 + 2.0 * M * 256 * (2 * tp.F + tp.DI),
+                          2.0 * (M * (N3 + 6 * 256 + tp.F + tp.DI) + 256 * (N3 + 2 * tp.F + tp.DI))):
+                check(lib().cvft_block_link_bwd(C.byref(a), C.byref(ta), ptr(rec.lpack.W_bwd), stream()), "cvft_block_link_bwd")
+            rec.results = (dx1, do)
+            _hand(dx, _H_LINK_BWD, rec)
+        else:
+            with _Bracket("block_qkv_bwd", 2.0 * M * N3 * (256 + 48) + 2.0 * M * 48 * 256, 2.0 * (M * (N3 + 3 * 256) + 256 * N3)):
+                check(lib().cvft_block_qkv_bwd(C.byref(a), stream()), "cvft_block_qkv_bwd")
         if not any(ctx.needs_input_grad[1:7]):
             return (dx, None, None, None, None, None, None, None, None, None, None)
         # adapter gradients: dA_t = V_t^T drop_t(y) (three rank-16 products, or one rank-48 product on y when p == 0), dB = dY^T U
@@ -1687,18 +1726,30 @@ def block_tail_lean() -> int:
     if BLOCK_LEAN in ("0", "1", "2", "3", "4"):
         return int(BLOCK_LEAN)
     return 3 if lib().cvft_concurrent_chains() >= 3 else 0
-# The tail of block i and the head of block i + 1 in one launch (cvft_block_link_fwd; 32-row forms): "0" off, "1" on, "auto" (default)
-# = on while >= 3 chains share the chip.  Graph-timed per boundary at M = 2000 (tools/bench_link.py): tail + 64-row head 47.6 us, tail +
-# 32-row head on two workgroups per row tile 40.6 us, linked 42.9 us -- a workgroup's time is its weight stream (2 MB at ~50 GB/s per
-# CU), which the link does not shorten: it saves the launch boundary only.  Same-box A/B, two pairs of 40 steps: joint 21.02 / 21.02 ->
-# 20.79 / 20.79 ms (the pair there is tail + 64-row head); flow_only 14.51 / 14.51 -> 14.60 / 14.60 (the pair there is the two-workgroup head)
+# The tail of block i and the head of block i + 1 in one launch (cvft_block_link_fwd; 32-row forms): "0" off, "1" / "auto" (default) on.
+# Graph-timed per boundary at M = 2000 (tools/bench_link.py): tail + 64-row head 47.4 us, tail + 32-row head on two workgroups per row
+# tile 40.4 us, linked 43.1 us -- a workgroup's time is its weight stream (2 MB at ~50 GB/s per CU), which the link does not shorten:
+# it saves the launch boundary only.  Same-box A/B, two pairs of 40 steps: joint 21.02 / 21.02 -> 20.79 / 20.79 ms (the pair there is
+# tail + 64-row head); flow_only 14.51 / 14.51 -> 14.60 / 14.60 forward alone (the pair there is the two-workgroup head), 14.57 / 14.54
+# -> 14.46 / 14.49 with the backward linked too
 BLOCK_LINK = _os.environ.get("CVFT_BLOCK_LINK", "auto")
 
 
 def block_link_on() -> bool:
-    if BLOCK_LINK in ("0", "1"):
-        return BLOCK_LINK == "1"
-    return lib().cvft_concurrent_chains() >= 3
+    return BLOCK_LINK != "0"
+
+
+# ... and the same boundary backwards (cvft_block_link_bwd: block i + 1's head backward + block i's tail backward), wherever the
+# forward ran linked: "0" off, "1" on, "auto" (default) = on unless >= 3 chains share the chip.  Per boundary (M = 2000): head + tail
+# backward in their 32-row forms 43.9 us, 64-row forms 49.8 us, linked 40.4 us; but the joint step runs the 64-row pair on HALF the
+# CUs, and there CU-time counts: joint 20.67 / 20.67 (pair of 64-row launches) -> 20.90 / 20.89 ms (linked)
+BLOCK_LINK_BWD = _os.environ.get("CVFT_BLOCK_LINK_BWD", "auto")
+
+
+def block_link_bwd_on() -> bool:
+    if BLOCK_LINK_BWD in ("0", "1"):
+        return BLOCK_LINK_BWD == "1"
+    return lib().cvft_concurrent_chains() < 3
 
 
 BLOCK_QKV_FUSE = _os.environ.get("CVFT_BLOCK_QKV_FUSE", "1") != "0"      # first half of the block (norm1 + stacked LoRA q|k|v)

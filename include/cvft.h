@@ -487,6 +487,11 @@ int cvft_block_qkv_bwd(const cvft_block_qkv_bwd_args* a, void* stream);
  * 256 <= F <= 1024.  W_link replaces tail->W_fwd and head->W_fwd: per wave w its DI/8 + F/4 tail fragments (as in W_fwd) followed
  * by its 192 head fragments, [4 waves][DI/8 + F/4 + 192] + 32 fragments of padding (hipops/blockpack.py, BlockLinkPack). */
 int cvft_block_link_fwd(const cvft_block_tail_args* tail, const cvft_block_qkv_args* head, const void* W_link, void* stream);
+/* The same boundary backwards: exactly cvft_block_qkv_bwd(head) followed by cvft_block_tail_bwd(tail) with tail->dy == head->dx
+ * (the gradient at the block boundary, still written) -- same outputs, bit for bit.  32-row forms only (head->wide == 0,
+ * tail->lean == 0), DI == 512 with dout, 256 <= F <= 1024.  W_link: per wave w its 192 head fragments (as in the head's W_bwd)
+ * followed by its F/4 + DI/8 tail fragments (as in the tail's W_bwd), + 32 fragments of padding. */
+int cvft_block_link_bwd(const cvft_block_qkv_bwd_args* head, const cvft_block_tail_bwd_args* tail, const void* W_link, void* stream);
 
 /* Diagnostics (development only): cycle stamps of the default 128x128 LDS-DMA GEMM kernel (CVFT_GLDS_BIG=15 launches its
  * stamped build; tools/glds_stamps.py); host_out receives 256 uint64. */

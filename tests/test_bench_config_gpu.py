@@ -192,8 +192,8 @@ def test_hand_overs_survive_recycled_allocations():
 
 
 def test_linked_block_launches_equal_separate_launches():
-    """The estimator's block boundary in one launch (cvft_block_link_fwd: block i's tail + block i + 1's norm1 / q|k|v head; DESIGN
-    section 14) against the separate launches, through the product trainer in train mode (every dropout on, same mask seed): the
+    """The estimator's block boundary in one launch each way (cvft_block_link_fwd: block i's tail + block i + 1's norm1 / q|k|v
+    head; cvft_block_link_bwd: that head's backward + that tail's backward) against the separate launches, through the product trainer in train mode (every dropout on, same mask seed): the
     linked launch computes the same numbers in the same order, so losses and the flat LoRA gradient agree to the fp32-atomics noise
     of one tensor -- and the heads really were taken from the linked launches (42 of the 56 blocks of a chain have a predecessor
     in their stage)."""
@@ -202,19 +202,22 @@ def test_linked_block_launches_equal_separate_launches():
     B, T = 4, 120
     batches = [synth_batch([T, 100, 90, 110], seed=80 + i) for i in range(2)]
     dfn = lambda ep, bi, b: cfm_draws(B, T, 300 + bi)
-    res, taken = [], []
-    keep = HF.BLOCK_LINK
+    res, taken, taken_bwd = [], [], []
+    keep = HF.BLOCK_LINK, HF.BLOCK_LINK_BWD
     try:
         for mode in ("0", "1"):
-            HF.BLOCK_LINK = mode
+            HF.BLOCK_LINK = HF.BLOCK_LINK_BWD = mode
             HF.HANDS_TAKEN.pop(HF._H_LINK, None)
+            HF.HANDS_TAKEN.pop(HF._H_LINK_BWD, None)
             jm = _full_joint(dropout=True)
             tr, grads = _fit(jm, batches, dfn, train_mode=True, use_graph=True, seed_base=555, max_graphs=0)
             res.append((tr.history, grads))
             taken.append(HF.HANDS_TAKEN.get(HF._H_LINK, 0))
+            taken_bwd.append(HF.HANDS_TAKEN.get(HF._H_LINK_BWD, 0))
     finally:
-        HF.BLOCK_LINK = keep
+        HF.BLOCK_LINK, HF.BLOCK_LINK_BWD = keep
     assert taken[0] == 0 and taken[1] >= 2 * 36, taken
+    assert taken_bwd[0] == 0 and taken_bwd[1] == taken[1], (taken, taken_bwd)      # every linked boundary also ran linked backwards
     for i in range(2):
         for k in ("loss", "llm_loss", "flow_loss", "grad_norm"):
             assert abs(res[0][0][i][k] - res[1][0][i][k]) <= 1e-6 * abs(res[0][0][i][k]), (i, k, res[0][0][i], res[1][0][i])

@@ -288,3 +288,71 @@ def test_block_link_refuses_other_forms():
     a.F, q.N3, a.DI, a.lean = 1024, 1536, 512, 2
     w = torch.zeros(16, device=DEV)
     assert cb.lib().cvft_block_link_fwd(C.byref(a), C.byref(q), cb.ptr(w), cb.stream()) != 0
+
+
+@pytest.mark.parametrize("act", ["gelu_erf", "gelu_tanh"])
+@pytest.mark.parametrize("M,Fh,p", [(64, 1024, 0.05), (250, 1024, 0.0), (37, 256, 0.3), (4000, 1024, 0.05), (2000, 512, 0.0)])
+def test_block_link_bwd_equals_head_then_tail_bitwise(M, Fh, p, act):
+    """cvft_block_link_bwd (block i + 1's head backward + block i's tail backward in one launch, the boundary gradient kept in
+    registers) against cvft_block_qkv_bwd then cvft_block_tail_bwd on the stored gradient: V, dx (still written), dx1 and dout bit
+    for bit; ragged M."""
+    from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    from cosyvoice_lora_finetune_framework_amd.hipops.blockpack import BlockLinkPack, BlockQkvPack, BlockTailPack
+    import ctypes as C
+    d = lambda t: t.to(DEV)
+    w = _weights(512, Fh, seed=M)
+    wd = {k: d(v) for k, v in w.items()}
+    tpack = BlockTailPack(wd["wo"], wd["bo"], wd["gamma"], wd["beta"], 1e-5, wd["w1"], wd["b1"], wd["w2"], wd["b2"])
+    wq, x, dY, dres = _qkv_case(M, p, seed=M + 7)
+    hpack = BlockQkvPack(d(wq["wqkv"]), d(wq["bias"]), d(wq["gamma"]), d(wq["beta"]), 1e-5)
+    lpack = BlockLinkPack(tpack, hpack)
+    A = torch.cat(wq["A"], 0).to(torch.bfloat16)
+    Bb = torch.zeros(1536, 48)
+    for t in range(3):
+        Bb[512 * t:512 * (t + 1), 16 * t:16 * (t + 1)] = wq["B"][t]
+    At, Bbt = d(A.t().contiguous()), d(Bb.to(torch.bfloat16).t().contiguous())
+    g = torch.Generator().manual_seed(M + 1)
+    o = d(torch.randn(M, 512, generator=g).to(torch.bfloat16))
+    x0 = d((torch.randn(M, 256, generator=g) * 2.0 + 0.3).to(torch.bfloat16))
+    HF._DROPOUT["seed"] = torch.full((1,), 987654321, dtype=torch.int64, device=DEV)
+    sites = [3, 4, 8]
+    # forward of the tail (its saved tensors) and the head's statistics on the tail's output
+    bfz = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=DEV)
+    x1, out, z = bfz(M, 256), bfz(M, 256), bfz(-(-M // 64) * 64 * Fh)
+    mean, rstd = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+    a = _tail_args(cb, M, o, x0, tpack, x1, out, mean, rstd, z, HF.ACT[act])
+    cb.check(cb.lib().cvft_block_tail_fwd(C.byref(a), cb.stream()), "tail fwd")
+    of = out.float()
+    mean2 = of.mean(1).contiguous()
+    rstd2 = (of.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    dYd, dresd = d(dY.to(torch.bfloat16)), d(dres.to(torch.bfloat16))
+    res = {}
+    for linked in (False, True):
+        bf = lambda *s: torch.full(s, 7.0, dtype=torch.bfloat16, device=DEV)
+        V, dx, dx1, do = bf(M, 48), bf(M, 256), bf(M, 256), bf(M, 512)
+        b = cb.BlockQkvBwdArgs()
+        b.M, b.dY, b.lddy, b.dres, b.x = M, cb.ptr(dYd), 1536, cb.ptr(dresd), cb.ptr(out)
+        b.gamma, b.mean, b.rstd, b.W_bwd, b.N3, b.wide = cb.ptr(hpack.gamma), cb.ptr(mean2), cb.ptr(rstd2), cb.ptr(hpack.W_bwd), 1536, 0
+        b.At, b.ldat, b.Bbt, b.ldbt = cb.ptr(At), 48, cb.ptr(Bbt), 1536
+        b.alpha, b.p = 2.0, p
+        if p > 0:
+            b.seed = cb.ptr(HF._DROPOUT["seed"])
+            for i in range(3):
+                b.sites[i] = sites[i]
+        b.V, b.ldv, b.dx = cb.ptr(V), 48, cb.ptr(dx)
+        t = cb.BlockTailBwdArgs()
+        t.M, t.x1, t.dy, t.gamma, t.mean, t.rstd, t.z = M, cb.ptr(x1), cb.ptr(dx), cb.ptr(tpack.gamma), cb.ptr(mean), cb.ptr(rstd), cb.ptr(z)
+        t.W_bwd, t.F, t.DI, t.act, t.dx1, t.lean = cb.ptr(tpack.W_bwd), Fh, 512, HF.ACT[act], cb.ptr(dx1), 0
+        t.dout, t.lddo = cb.ptr(do), 512
+        if linked:
+            cb.check(cb.lib().cvft_block_link_bwd(C.byref(b), C.byref(t), cb.ptr(lpack.W_bwd), cb.stream()), "link bwd")
+        else:
+            cb.check(cb.lib().cvft_block_qkv_bwd(C.byref(b), cb.stream()), "head bwd")
+            cb.check(cb.lib().cvft_block_tail_bwd(C.byref(t), cb.stream()), "tail bwd")
+        torch.cuda.synchronize()
+        res[linked] = dict(V=V, dx=dx, dx1=dx1, do=do)
+    HF._DROPOUT["seed"] = None
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), (k, rel(res[True][k], res[False][k]))
+    assert float(res[True]["do"].float().abs().max()) > 1e-3 and torch.isfinite(res[True]["do"].float()).all()

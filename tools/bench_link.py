@@ -80,7 +80,48 @@ def main():
             cb.check(lib.cvft_block_link_fwd(C.byref(a), C.byref(q), cb.ptr(lpack.W_fwd), cb.stream()), "link")
         t0 = timeit(tail_only)
         t32, t64, tl = timeit(lambda: pair(0)), timeit(lambda: pair(1)), timeit(linked)
-        print(f"M={M:5d} p={p}: tail alone {t0:6.1f} us | tail + head(32-row) {t32:6.1f} us | tail + head(64-row) {t64:6.1f} us | linked {tl:6.1f} us")
+        print(f"M={M:5d} p={p}: fwd  tail alone {t0:6.1f} us | tail + head(32-row) {t32:6.1f} us | tail + head(64-row) {t64:6.1f} us | linked {tl:6.1f} us")
+        # ---- backward: head backward (block i + 1) then tail backward (block i)
+        linked()                                           # (statistics / z of the last weight set; values do not matter for timing)
+        dY, dres = bf(M, 1536).normal_(), bf(M, 256).normal_()
+        V, dx, dx1, do = bf(M, 48), bf(M, 256), bf(M, 256), bf(M, 512)
+
+        def bargs(k, wide, lean):
+            tpack, hpack, lpack, A, Bb = sets[k]
+            At, Bbt = A.t().contiguous(), Bb.t().contiguous()
+            keep.append((At, Bbt))
+            b = cb.BlockQkvBwdArgs()
+            b.M, b.dY, b.lddy, b.dres, b.x = M, cb.ptr(dY), 1536, cb.ptr(dres), cb.ptr(out)
+            b.gamma, b.mean, b.rstd, b.N3, b.wide = cb.ptr(hpack.gamma), cb.ptr(mean2), cb.ptr(rstd2), 1536, wide
+            b.W_bwd = cb.ptr(hpack.W_bwd_wide if wide else hpack.W_bwd)
+            b.At, b.ldat, b.Bbt, b.ldbt = cb.ptr(At), 48, cb.ptr(Bbt), 1536
+            b.alpha, b.p = 2.0, p
+            if p > 0:
+                b.seed = cb.ptr(HF._DROPOUT["seed"])
+                for i in range(3):
+                    b.sites[i] = 5 + i
+            b.V, b.ldv, b.dx = cb.ptr(V), 48, cb.ptr(dx)
+            t = cb.BlockTailBwdArgs()
+            t.M, t.x1, t.dy, t.gamma, t.mean, t.rstd, t.z = M, cb.ptr(x1), cb.ptr(dx), cb.ptr(tpack.gamma), cb.ptr(mean), cb.ptr(rstd), cb.ptr(z)
+            t.W_bwd = cb.ptr((tpack.W_bwd, tpack.W_bwd_lean, tpack.W_bwd_wide)[lean])
+            t.F, t.DI, t.act, t.dx1, t.lean = 1024, 512, 3, cb.ptr(dx1), lean
+            t.dout, t.lddo = cb.ptr(do), 512
+            return b, t, lpack
+        keep = []
+        cache = {(k, w, l): bargs(k, w, l) for k in range(4) for (w, l) in ((0, 0), (1, 2))}
+
+        def bpair(wide, lean):
+            b, t, _ = cache[(state["k"] % 4, wide, lean)]
+            state["k"] += 1
+            cb.check(lib.cvft_block_qkv_bwd(C.byref(b), cb.stream()), "head bwd")
+            cb.check(lib.cvft_block_tail_bwd(C.byref(t), cb.stream()), "tail bwd")
+
+        def blinked():
+            b, t, lpack = cache[(state["k"] % 4, 0, 0)]
+            state["k"] += 1
+            cb.check(lib.cvft_block_link_bwd(C.byref(b), C.byref(t), cb.ptr(lpack.W_bwd), cb.stream()), "link bwd")
+        b32, b64, bl = timeit(lambda: bpair(0, 0)), timeit(lambda: bpair(1, 2)), timeit(blinked)
+        print(f"M={M:5d} p={p}: bwd  head + tail (32-row) {b32:6.1f} us | head + tail (64-row) {b64:6.1f} us | linked {bl:6.1f} us")
     HF._DROPOUT["seed"] = None
 
 
