@@ -557,6 +557,10 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
+    from cosyvoice_lora_finetune_framework_amd import llm_flow_model as _J
+    if rank == 0 and _J.CHAIN_EVENTS:                 # CVFT_CHAIN_EVENTS=1 CVFT_CHAIN_BWD=1 (diagnostic): the LAST replay's chain ends
+        for key, ms in sorted(_J.chain_event_offsets_ms().items(), key=lambda kv: kv[1]):
+            print(f"[chain events] +{ms:7.3f} ms  {key}", file=sys.stderr, flush=True)
     if torch.distributed.is_initialized():
         dp.barrier()                                  # the other ranks wait for rank 0's roofline leg, then all leave together
         torch.distributed.destroy_process_group()

@@ -27,3 +27,18 @@ extern "C" int cvft_version(void) { return 101; }
 static int g_chains = 1;
 extern "C" int cvft_set_concurrent_chains(int n) { const int old = g_chains; g_chains = n < 1 ? 1 : n; return old; }
 extern "C" int cvft_concurrent_chains(void) { return g_chains; }
+
+// Diagnostic: a one-thread kernel that writes the device's wall clock (s_memrealtime, 100 MHz) into buf[slot] -- launched between
+// the kernels of a stream (also inside a captured hipGraph, where HIP refuses timing events) it says WHEN the stream got there
+// (llm_flow_model.py, CVFT_CHAIN_EVENTS).
+__global__ void debug_stamp_kernel(unsigned long long* buf, int slot) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    buf[slot] = t;
+}
+extern "C" int cvft_debug_stamp(unsigned long long* buf, int slot, void* stream) {
+    CVFT_CHECK_ARG(buf && slot >= 0, "cvft_debug_stamp: null buffer / negative slot");
+    hipLaunchKernelGGL(debug_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, buf, slot);
+    CVFT_LAUNCH_CHECK("cvft_debug_stamp");
+    return 0;
+}

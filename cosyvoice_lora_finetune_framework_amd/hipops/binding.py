@@ -109,6 +109,7 @@ SIGNATURES = {
     "cvft_lora_rank_partial_multi": [_i, _i, _i, _p, _p],
     "cvft_lora_rank_partial_batch": [_i, _i, _p, _p],
     "cvft_debug_glds_stamps": [_p],
+    "cvft_debug_stamp": [_p, C.c_int, _p],
     "cvft_debug_mfma_fp8_probe": [_p, _p, _p, _p],
     "cvft_quant_fp8_rows": [_i, _i, _p, _i, _p, _i, _p, _p],
     "cvft_gemm_fp8": [_p, _p, _i, _p, _p, _i, _p, _p],

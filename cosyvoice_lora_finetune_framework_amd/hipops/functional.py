@@ -744,6 +744,16 @@ class LoraGradSink:
         keep = set(mine)
         self.deferred[r] = [e for i, e in enumerate(rows) if i not in keep]
 
+    def flush_chain(self):
+        """The postponed products of the CURRENT stream's chain go out now, on that stream (llm_flow_model.forward_backward calls
+        this behind each chain's backward): what is left for flush() behind the join is the reduce alone."""
+        cur = torch.cuda.current_stream().cuda_stream
+        for r, rows in list(self.deferred.items()):
+            mine = [e for e in rows if e[9] == cur]
+            if mine:
+                LoraGradSink._launch_rows(r, mine)
+                self.deferred[r] = [e for e in rows if e[9] != cur]
+
     def workspace(self, P: torch.Tensor, nsplit: int) -> torch.Tensor:
         """Slab workspace (nsplit x P.numel() floats) for the next product on parameter P inside this sink.  Several
         products may hit the SAME parameter within one backward -- the sub-batch chains of a branch run the same adapters

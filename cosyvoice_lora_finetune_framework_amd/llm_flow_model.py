@@ -43,6 +43,31 @@ LOSS_FUSE = os.environ.get("CVFT_LOSS_FUSE", "1") != "0"      # 0: the plain op-
 # joint 21.28 / 21.36 (1) vs 21.33 / 21.34 ms (0), flow_only 14.29 vs 14.27, llm_only 13.38 vs 13.31 -- the step is bound by the
 # chip's CU-time, an idle chain is another chain's CUs
 CHAIN_BWD = os.environ.get("CVFT_CHAIN_BWD", "0") != "0"
+CHAIN_FLUSH = os.environ.get("CVFT_CHAIN_FLUSH", "1") != "0"      # (with CHAIN_BWD: LoraGradSink.flush_chain behind each chain's backward)
+# Diagnostic: with CVFT_CHAIN_EVENTS=1 (and CVFT_CHAIN_BWD=1) forward_backward drops a clock stamp (cvft_debug_stamp: a one-thread
+# kernel node, HIP refuses timing events inside a captured graph) at the fork, behind every chain's forward and backward, and at the
+# join; bench.py prints their offsets after the run: which chain ends the step, and how long the others have been done by then.
+CHAIN_EVENTS = {} if os.environ.get("CVFT_CHAIN_EVENTS", "0") != "0" else None
+_CHAIN_STAMPS = []
+
+
+def _chain_event(key) -> None:
+    if CHAIN_EVENTS is None:
+        return
+    if not _CHAIN_STAMPS:
+        _CHAIN_STAMPS.append(torch.zeros(64, dtype=torch.int64, device='cuda'))
+    slot = CHAIN_EVENTS.setdefault(key, len(CHAIN_EVENTS))
+    from .hipops.binding import check, lib, ptr, stream
+    check(lib().cvft_debug_stamp(ptr(_CHAIN_STAMPS[0]), slot, stream()), "cvft_debug_stamp")
+
+
+def chain_event_offsets_ms():
+    """{key: ms since the fork} of the last step that ran (diagnostic)"""
+    if not CHAIN_EVENTS or not _CHAIN_STAMPS:
+        return {}
+    t = _CHAIN_STAMPS[0].cpu().tolist()
+    t0 = t[CHAIN_EVENTS[('fork',)]]
+    return {k: (t[s] - t0) / 1e5 for k, s in CHAIN_EVENTS.items()}
 CHAIN_ORDER = int(os.environ.get("CVFT_CHAIN_ORDER", "0"))      # 1: chains enqueued Flow first, LLM last (the caller's stream then carries the LLM) -- see forward()
 SIDE_STREAM_PRIORITY = int(os.environ.get("CVFT_SIDE_PRIO", "0"))      # priority of the side streams (the Flow chains in joint mode): -1 = high
 
@@ -189,6 +214,7 @@ class JointLLMFlowModel(nn.Module):
                 sd = torch.full((), c * float(share), dtype=torch.float32, device=device)
             seeds[(kind, k)] = sd
         results = {}
+        _chain_event(('fork',))
         for ci, (kind, k) in enumerate(reversed(chains)):
             st = None
             if use_streams and ci < len(chains) - 1:
@@ -204,7 +230,11 @@ class JointLLMFlowModel(nn.Module):
                     d = None if draws is None else {n_: v[part['_rows']] if '_rows' in part else v for n_, v in draws.items()}
                     r = self._forward_flow(part, device, d)
                 loss = r['loss']
+                _chain_event((kind, k, 'forward done'))
                 torch.autograd.backward([loss], [seeds[(kind, k)].to(loss.dtype)])
+                if CHAIN_FLUSH and HF.LoraGradSink.active is not None:
+                    HF.LoraGradSink.active.flush_chain()      # this chain's postponed adapter products, on its own stream
+                _chain_event((kind, k, 'backward done'))
                 share = part['_w_llm' if kind == 'llm' else '_w_flow']
                 results[(kind, k)] = (_scaled(loss.detach(), share), _scaled(r['acc'].detach(), share) if 'acc' in r else None)
             if st is not None:
@@ -213,6 +243,7 @@ class JointLLMFlowModel(nn.Module):
             if isinstance(v[0], tuple):
                 cur.wait_stream(v[1])
                 results[key] = v[0]
+        _chain_event(('join',))
         if do_llm:
             losses['llm_loss'] = _scaled(_total([results[('llm', k)][0] for k in range(len(parts['llm']))]), self.llm_loss_weight)
             if results[('llm', 0)][1] is not None:

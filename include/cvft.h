@@ -496,6 +496,9 @@ int cvft_block_link_bwd(const cvft_block_qkv_bwd_args* head, const cvft_block_ta
 /* Diagnostics (development only): cycle stamps of the default 128x128 LDS-DMA GEMM kernel (CVFT_GLDS_BIG=15 launches its
  * stamped build; tools/glds_stamps.py); host_out receives 256 uint64. */
 int cvft_debug_glds_stamps(unsigned long long* host_out);
+/* Diagnostics: buf[slot] = the device's wall clock (s_memrealtime, 100 MHz ticks) when `stream` reaches this launch; usable
+ * inside a captured hipGraph (llm_flow_model.py, CVFT_CHAIN_EVENTS: when does each chain of the step end). */
+int cvft_debug_stamp(unsigned long long* buf, int slot, void* stream);
 /* fp8 groundwork (BASELINE configs[4]): one v_mfma_scale_f32_16x16x128_f8f6f4 product, C[16][16] = A[16][128] . B[16][128]^T on
  * OCP e4m3 bytes with unit block scales -- pins the operand layout the fp8 GEMM will use (tests/test_ops_gpu.py). */
 int cvft_debug_mfma_fp8_probe(const void* A, const void* B, float* C, void* stream);

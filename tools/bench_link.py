@@ -62,20 +62,21 @@ def main():
             q.U, q.ldu, q.Y, q.ldy = cb.ptr(U), 48, cb.ptr(Y), 1536
             return a, q, lpack
         state = {"k": 0}
+        nsets = int(os.environ.get("SETS", "4"))      # SETS=1: one weight set, L2-warm streams (what a perfect prefetch would give)
 
         def pair(wide):
-            a, q, _ = args(state["k"] % 4, wide)
+            a, q, _ = args(state["k"] % nsets, wide)
             state["k"] += 1
             cb.check(lib.cvft_block_tail_fwd(C.byref(a), cb.stream()), "tail")
             cb.check(lib.cvft_block_qkv_fwd(C.byref(q), cb.stream()), "head")
 
         def tail_only():
-            a, q, _ = args(state["k"] % 4, 0)
+            a, q, _ = args(state["k"] % nsets, 0)
             state["k"] += 1
             cb.check(lib.cvft_block_tail_fwd(C.byref(a), cb.stream()), "tail")
 
         def linked():
-            a, q, lpack = args(state["k"] % 4, 0)
+            a, q, lpack = args(state["k"] % nsets, 0)
             state["k"] += 1
             cb.check(lib.cvft_block_link_fwd(C.byref(a), C.byref(q), cb.ptr(lpack.W_fwd), cb.stream()), "link")
         t0 = timeit(tail_only)
@@ -111,13 +112,13 @@ def main():
         cache = {(k, w, l): bargs(k, w, l) for k in range(4) for (w, l) in ((0, 0), (1, 2))}
 
         def bpair(wide, lean):
-            b, t, _ = cache[(state["k"] % 4, wide, lean)]
+            b, t, _ = cache[(state["k"] % nsets, wide, lean)]
             state["k"] += 1
             cb.check(lib.cvft_block_qkv_bwd(C.byref(b), cb.stream()), "head bwd")
             cb.check(lib.cvft_block_tail_bwd(C.byref(t), cb.stream()), "tail bwd")
 
         def blinked():
-            b, t, lpack = cache[(state["k"] % 4, 0, 0)]
+            b, t, lpack = cache[(state["k"] % nsets, 0, 0)]
             state["k"] += 1
             cb.check(lib.cvft_block_link_bwd(C.byref(b), C.byref(t), cb.ptr(lpack.W_bwd), cb.stream()), "link bwd")
         b32, b64, bl = timeit(lambda: bpair(0, 0)), timeit(lambda: bpair(1, 2)), timeit(blinked)
