@@ -791,12 +791,271 @@ __global__ void __launch_bounds__(64 * NW) attn32_bwd_dq_kernel(AP<bf16_t> p) {
     attn32_bwd_dq_body<REL, DROP, NBUF, NW, false>(p, blockIdx.x);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// rel-pos dQ at TWO blocks per CU (two waves per SIMD): the same arithmetic as attn32_bwd_dq_body<true, DROP, 1> in 80 896 bytes of
+// LDS (was 122 880) and <= 256 registers, so that one block's LDS skew traffic, softmax and barriers overlap the other's MFMAs:
+//   * the forward-skew window holds 64 of the band's 96 columns at a time: band tiles 0 and 1 serve the step's first 32 keys; tile 2
+//     then overwrites tile 0's columns (ring of two 32-column halves) and serves the second 32 -- no band product is repeated;
+//   * the inverse-skew window (dS, bf16) lives in the SAME per-wave bytes: the g values are dead when dS is formed; its rows are
+//     cleared and rewritten every step (12 + 32 stores per lane);
+//   * the band of p rows is a ring of three 64-row tiles: a step moves the band by 64 rows, so ONE new tile is staged per step
+//     instead of three (two tiles of staging registers and two tile stores less).
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef REL2_PACKED
+#define REL2_PACKED 0
+#endif
+#ifndef REL2_SYNC
+#define REL2_SYNC 1
+#endif
+constexpr int SKH = 68;            // half-window row stride (dwords): 64 columns used; 67 l31 + const is conflict-free
+template <bool DROP>
+DEV void attn32_bwd_dq_rel2_body(const AP<bf16_t>& p, const int bid) {
+    using namespace a32;
+    constexpr int NT_ = 256, QB = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vs = Ks + TILE;
+    bf16_t* Pb = Vs + TILE;                                             // ring of three 64 x LDK tiles of p rows
+    float* Gs = reinterpret_cast<float*>(Pb + 192 * LDK);               // 4 x 32 x SKH (and, aliased, the dS window)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int L = p.L, nblk = (L + QB - 1) / QB;
+    int bh, blk;
+    block_map(bid, nblk, p.B * p.H, bh, blk);
+    if (p.causal) blk = nblk - 1 - blk;             // longest blocks first
+    const int i0 = blk * QB, hh = bh % p.H, b = bh / p.H;
+    const int iw = i0 + 32 * w, i = iw + l31;
+    const size_t rowbase = (size_t)b * L;
+    const bf16_t* qg = p.q + rowbase * p.ld + hh * 64;
+    const bf16_t* kg = p.k + rowbase * p.ld + hh * 64;
+    const bf16_t* vg = p.v + rowbase * p.ld + hh * 64;
+    const bf16_t* dog = p.d_o + rowbase * p.ldo + hh * 64;
+    const bf16_t* og = p.o + rowbase * p.ldo + hh * 64;
+    const bf16_t* pg = p.p + hh * 64;
+    const int lb = p.len ? p.len[b] : L;
+    const DropCtx dc = drop_ctx<DROP>(p);
+
+    int jmax = min(L, lb);
+    if (p.causal) jmax = min(jmax, i0 + QB);
+    int jwv = jmax;
+    if (p.causal) jwv = min(jwv, iw + 32);
+    if (iw >= L) jwv = 0;
+    const int jlim = min(L, lb);
+    const int nt = (jmax + 63) >> 6;
+    const float c2 = p.scale * LOG2E;
+
+    bf16x8 qu[4], qv[4], dof[4];
+    float dsum = 0.f;
+    const bf16_t* olg = (p.o_lo ? p.o_lo : p.o) + rowbase * p.ldo + hh * 64;
+    const float lo_w = p.o_lo ? 1.f : 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bf16x8 f = gfrag(qg, i, L, p.ld, s, hf);
+        qu[s] = bias_frag(f, p.bu + hh * 64, s, hf);
+        qv[s] = bias_frag(f, p.bv + hh * 64, s, hf);
+        dof[s] = gfrag(dog, i, L, p.ldo, s, hf);
+        const bf16x8 of = gfrag(og, i, L, p.ldo, s, hf);
+        const bf16x8 lf = gfrag(olg, i, L, p.ldo, s, hf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)dof[s][e] * ((float)of[e] + lo_w * (float)lf[e]);
+    }
+    dsum = xh_sum(dsum);
+    if (hf == 0 && i < L) const_cast<float*>(p.delta)[((size_t)b * p.H + hh) * L + i] = dsum;
+    const float lse_raw = p.lse[((size_t)b * p.H + hh) * L + min(i, L - 1)];
+    const float lse2 = (i < L) ? lse_raw * LOG2E : __builtin_inff();
+
+    float* Gw = Gs + w * 32 * SKH + l31 * SKH;                          // this lane's row of the g half-window (fp32)
+    bf16_t* Rw = reinterpret_cast<bf16_t*>(Gs + w * 32 * SKH) + l31 * RSK;   // ... and of the dS window (bf16), same bytes
+
+    const int mb0 = (L - 1) - (i0 + 127);          // band row of logical tile 0 at step 0
+    Tile2 kr, vr, br;
+    {
+        Tile2 b0, b1;
+        tload<NT_>(kr, kg, p.ld, 0, L, tid);
+        tload<NT_>(vr, vg, p.ld, 0, L, tid);
+        tload<NT_>(b0, pg, p.ldp, mb0, 2 * L - 1, tid);
+        tload<NT_>(b1, pg, p.ldp, mb0 + 64, 2 * L - 1, tid);
+        tload<NT_>(br, pg, p.ldp, mb0 + 128, 2 * L - 1, tid);
+        tstore<NT_>(kr, Ks, tid);
+        tstore<NT_>(vr, Vs, tid);
+        tstore<NT_>(b0, Pb, tid);
+        tstore<NT_>(b1, Pb + 64 * LDK, tid);
+        tstore<NT_>(br, Pb + 128 * LDK, tid);
+    }
+    touch(qu);
+    touch(dof);
+    touch(qv);
+    if (!REL2_SYNC) {
+        tload<NT_>(kr, kg, p.ld, 64, L, tid);
+        tload<NT_>(vr, vg, p.ld, 64, L, tid);
+        tload<NT_>(br, pg, p.ldp, mb0 + 192, 2 * L - 1, tid);
+    }
+    __syncthreads();
+
+    f32x16 dqacc[2];
+    dqacc[0] = zero16();
+    dqacc[1] = zero16();
+    int t3 = 0;                                     // t % 3: ring slot of this step's logical band tile 0
+
+    for (int t = 0; t < nt; ++t) {
+        const int j0 = 64 * t;
+        if (j0 < jwv) {
+            // this wave's 96 band rows = 32-row chunks 3 - w + {0, 1, 2} of the six the ring holds; chunk c sits in slot (t3 + c / 2) % 3
+            const bf16_t* Pc[3];
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                const int c = 3 - w + mt;
+                int slot = t3 + (c >> 1);
+                slot = slot >= 3 ? slot - 3 : slot;
+                Pc[mt] = Pb + (slot * 64 + (c & 1) * 32) * LDK;
+            }
+            f32x16 s[2], dp[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                s[kt] = zero16();
+                dp[kt] = zero16();
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss) {
+                    s[kt] = mfma(ld_row(Ks, 32 * kt, ss, lane), qu[ss], s[kt]);
+                    dp[kt] = mfma(ld_row(Vs, 32 * kt, ss, lane), dof[ss], dp[kt]);
+                }
+            }
+            // band tiles 0, 1 -> window halves 0, 1 -> keys 0..31; band tile 2 -> half 0 -> keys 32..63 (columns taken modulo 64)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                f32x16 g = zero16();
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss) g = mfma(ld_row(Pc[mt], 0, ss, lane), qv[ss], g);
+                if (mt == 2) {
+                    LDS_FENCE();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[0][r] += Gw[(31 - l31) + rowof(r) + 4 * hf];
+                    LDS_FENCE();
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x4 v4 = {g[4 * e], g[4 * e + 1], g[4 * e + 2], g[4 * e + 3]};
+                    *reinterpret_cast<f32x4*>(Gw + 32 * (mt & 1) + 8 * e + 4 * hf) = v4;
+                }
+            }
+            LDS_FENCE();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[1][r] += Gw[((31 - l31) + 32 + rowof(r) + 4 * hf) & 63];
+            LDS_FENCE();
+            const bool interior = (j0 + 63 < jlim) && (!p.causal || j0 + 63 <= iw);
+            const unsigned long long ib = (((unsigned long long)b * p.H + hh) * L + i) * L;
+            if (REL2_PACKED && interior && !DROP) {      // packed form: p = exp2(s c2 - lse), dS = p (dP scale - delta scale)
+                const f32x2 c2v = {c2, c2}, lv = {lse2, lse2}, scv = {p.scale, p.scale}, dsv = {dsum * p.scale, dsum * p.scale};
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2 x = {s[kt][r], s[kt][r + 1]};
+                        x = x * c2v - lv;
+                        const f32x2 pv = {ex2(x[0]), ex2(x[1])};
+                        f32x2 d = {dp[kt][r], dp[kt][r + 1]};
+                        d = d * scv - dsv;
+                        d = d * pv;
+                        s[kt][r] = d[0];
+                        s[kt][r + 1] = d[1];
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = j0 + 32 * kt + rowof(r) + 4 * hf;
+                        float x = s[kt][r] * c2;
+                        if (!interior) {      // (wave-uniform; the per-element part is selects only, no branches)
+                            const bool valid = (j < jlim) & (!p.causal | (j <= i));
+                            x = valid ? x : NINF;
+                        }
+                        const float pv = ex2(x - lse2);      // masked positions: exp2(-inf) = exact 0
+                        float dpe = dp[kt][r];
+                        if (DROP) dpe *= attn_keep_scale(dc.key, ib + (unsigned long long)j, dc.thr, dc.inv);
+                        s[kt][r] = pv * (dpe - dsum) * p.scale;      // dS
+                    }
+            }
+            const bf16x8 db0 = pack8<0>(s[0]), db1 = pack8<1>(s[0]), db2 = pack8<0>(s[1]), db3 = pack8<1>(s[1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dqacc[dt] = mfma(ld_tr(Ks, 0, 32 * dt, lane), db0, dqacc[dt]);
+                dqacc[dt] = mfma(ld_tr(Ks, 16, 32 * dt, lane), db1, dqacc[dt]);
+                dqacc[dt] = mfma(ld_tr(Ks, 32, 32 * dt, lane), db2, dqacc[dt]);
+                dqacc[dt] = mfma(ld_tr(Ks, 48, 32 * dt, lane), db3, dqacc[dt]);
+            }
+            // dQ_i += sum_j dS[i,j] p[L-1-i+j]: dS through the inverse shift (column jl -> 31 - l31 + jl); the row is cleared first
+            // (the g values sat in these bytes), 48 columns per lane half
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const bf16x4 z = {0, 0, 0, 0};
+                *reinterpret_cast<bf16x4*>(Rw + 48 * hf + 4 * c) = z;
+            }
+            LDS_FENCE();
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Rw[(31 - l31) + 32 * kt + rowof(r) + 4 * hf] = (bf16_t)s[kt][r];
+            LDS_FENCE();
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) {
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(Rw + 16 * kk + 4 * hf);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Rw + 16 * kk + 8 + 4 * hf);
+                const bf16x8 dk8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) dqacc[dt] = mfma(ld_tr(Pc[kk >> 1], 16 * (kk & 1), 32 * dt, lane), dk8, dqacc[dt]);
+            }
+            LDS_FENCE();
+        }
+        __syncthreads();
+        // publish step t + 1: K / V, and the ONE new band tile into the slot this step's logical tile 0 leaves.
+        // REL2_SYNC: the tiles are requested only now (no staging registers live across the step: the block fits 256 registers
+        // without spills); the wait is the other resident block's time
+        if (REL2_SYNC) {
+            if (t + 1 < nt) {
+                tload<NT_>(kr, kg, p.ld, 64 * (t + 1), L, tid);
+                tload<NT_>(vr, vg, p.ld, 64 * (t + 1), L, tid);
+                tload<NT_>(br, pg, p.ldp, mb0 + 64 * (t + 1) + 128, 2 * L - 1, tid);
+                tstore<NT_>(kr, Ks, tid);
+                tstore<NT_>(vr, Vs, tid);
+                tstore<NT_>(br, Pb + t3 * 64 * LDK, tid);
+            }
+            t3 = t3 == 2 ? 0 : t3 + 1;
+        } else {
+            tstore<NT_>(kr, Ks, tid);
+            tstore<NT_>(vr, Vs, tid);
+            tstore<NT_>(br, Pb + t3 * 64 * LDK, tid);
+            t3 = t3 == 2 ? 0 : t3 + 1;
+            tload<NT_>(kr, kg, p.ld, 64 * (t + 2), L, tid);
+            tload<NT_>(vr, vg, p.ld, 64 * (t + 2), L, tid);
+            tload<NT_>(br, pg, p.ldp, mb0 + 64 * (t + 2) + 128, 2 * L - 1, tid);
+        }
+        __syncthreads();
+    }
+
+    if (i < L) {
+        bf16_t* drow = p.dq + (rowbase + i) * p.ldg + hh * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                st4(drow + 32 * dt + 8 * e + 4 * hf, dqacc[dt][4 * e], dqacc[dt][4 * e + 1], dqacc[dt][4 * e + 2],
+                    dqacc[dt][4 * e + 3]);
+    }
+}
+template <bool DROP>
+__global__ void __launch_bounds__(256, 2) attn32_bwd_dq_rel2_kernel(AP<bf16_t> p) {
+    attn32_bwd_dq_rel2_body<DROP>(p, blockIdx.x);
+}
+
 // =====================================================================================================================
 // backward dK, dV: block = 4 waves x 32 keys, 64 queries per step.  OWN_DELTA: delta = rowsum(dO * O) of each staged
 // query tile is formed here from the prefetch registers instead of read from the dQ kernel's output -- the two backward
 // roles then have no dependency and can share one launch (attn32_bwd_fused_kernel).
 // =====================================================================================================================
-template <bool REL, bool DROP, int NBUF, bool OWN_DELTA, int NW = 4, bool WHOLE = false>
+// LEAN (attn32_bwd_dkv_rel2_kernel: two blocks per CU, 256 registers): no staging registers live across a step (the next tiles are
+// requested behind the step's barrier: the wait is the other resident block's time) and no packed-softmax twin of the element loop
+template <bool REL, bool DROP, int NBUF, bool OWN_DELTA, int NW = 4, bool WHOLE = false, bool LEAN = false>
 DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
     static_assert(NW == 4 || (NW == 8 && !REL), "eight-wave blocks: additive-bias (estimator) form only");
@@ -936,7 +1195,7 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
             touch(pa);
             touch(pb_);
         }
-        A32_KV_PREFETCH(ibeg + 64);
+        if (!LEAN) A32_KV_PREFETCH(ibeg + 64);
         __syncthreads();
         }
         float* Gw = Gs + w * 32 * SK2;
@@ -993,7 +1252,7 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
                         lq[e] = *reinterpret_cast<const f32x4*>(lsc + 32 * qt + 8 * e + 4 * hf);
                         dq4[e] = *reinterpret_cast<const f32x4*>(dlc + 32 * qt + 8 * e + 4 * hf);
                     }
-                    if (interior && !DROP) {      // packed form (del_s holds delta * scale)
+                    if (interior && !DROP && !LEAN) {      // packed form (del_s holds delta * scale)
                         const f32x2 c2v = {c2, c2}, scv = {p.scale, p.scale};
                         f32x2 cs2 = {0.f, 0.f};
 #pragma unroll
@@ -1057,8 +1316,15 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
             }
             if constexpr (!WHOLE) {
             if (NBUF == 1) __syncthreads();
-            A32_KV_PUBLISH((t + 1) % NBUF, ibeg + 64 * (t + 1));
-            A32_KV_PREFETCH(ibeg + 64 * (t + 2));
+            if (LEAN) {
+                if (t + 1 < nt) {
+                    A32_KV_PREFETCH(ibeg + 64 * (t + 1));
+                    A32_KV_PUBLISH((t + 1) % NBUF, ibeg + 64 * (t + 1));
+                }
+            } else {
+                A32_KV_PUBLISH((t + 1) % NBUF, ibeg + 64 * (t + 1));
+                A32_KV_PREFETCH(ibeg + 64 * (t + 2));
+            }
             __syncthreads();
             }
         }
@@ -1089,6 +1355,11 @@ template <bool REL, bool DROP, int NBUF>
 __global__ void __launch_bounds__(256) attn32_bwd_dkv_kernel(AP<bf16_t> p) {
     attn32_bwd_dkv_body<REL, DROP, NBUF, false>(p, blockIdx.x);
 }
+// the rel-pos dK/dV role at two blocks per CU: the LEAN form of the body, 256-register budget
+template <bool DROP, int NBUF>
+__global__ void __launch_bounds__(256, 2) attn32_bwd_dkv_rel2_kernel(AP<bf16_t> p) {
+    attn32_bwd_dkv_body<true, DROP, NBUF, false, 4, false, true>(p, blockIdx.x);
+}
 
 // Both backward roles in ONE launch (blocks [0, nq): dQ, blocks [nq, 2 nq): dK/dV with its own delta): at the estimator's
 // sizes a role alone is one 4-wave block per CU (T = 250: 256 blocks), i.e. one wave per SIMD with every latency
@@ -1107,6 +1378,7 @@ static size_t smem_fwd(bool rel, int nbuf) { return (size_t)nbuf * 2 * TILE * 2 
 static size_t smem_dq(bool rel, int nbuf) {
     return (size_t)nbuf * 2 * TILE * 2 + (rel ? 192 * LDK * 2 + 4 * 32 * SKW * 4 + 4 * 32 * RSK * 2 : 0);
 }
+static size_t smem_dq_rel2() { return (size_t)2 * TILE * 2 + 192 * LDK * 2 + 4 * 32 * SKH * 4; }      // 80 896 bytes: two blocks per CU
 static size_t smem_dkv(bool rel, int nbuf) { return (size_t)nbuf * 2 * TILE * 2 + nbuf * 2 * 64 * 4 + (rel ? 4 * 32 * SK2 * 4 : 0); }
 
 template <typename K>
@@ -1190,12 +1462,19 @@ int cvft_attn32_bwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
         if (rc) return rc;
         return launch(attn32_bwd_dkv_kernel<false, false, 2>, smem_dkv(false, 2), p, st, "attn32_bwd_dkv");
     }
+    // the dQ role at two blocks per CU (attn32_bwd_dq_rel2_body); CVFT_ATTN_DQ2=0: the one-block-per-CU form
+    static const int dq2 = getenv("CVFT_ATTN_DQ2") ? atoi(getenv("CVFT_ATTN_DQ2")) : 1;
+    static const int dkv2 = getenv("CVFT_ATTN_DKV2") ? atoi(getenv("CVFT_ATTN_DKV2")) : 0;
     if (p.drop_p > 0.f) {
-        rc = launch(attn32_bwd_dq_kernel<true, true, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel_drop");
+        rc = dq2 ? launch(attn32_bwd_dq_rel2_kernel<true>, smem_dq_rel2(), p, st, "attn32_bwd_dq_rel2_drop")
+                 : launch(attn32_bwd_dq_kernel<true, true, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel_drop");
         if (rc) return rc;
+        if (dkv2) return launch(attn32_bwd_dkv_rel2_kernel<true, 1>, smem_dkv(true, 1), p, st, "attn32_bwd_dkv_rel2_drop");
         return launch(attn32_bwd_dkv_kernel<true, true, 2>, smem_dkv(true, 2), p, st, "attn32_bwd_dkv_rel_drop");
     }
-    rc = launch(attn32_bwd_dq_kernel<true, false, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel");
+    rc = dq2 ? launch(attn32_bwd_dq_rel2_kernel<false>, smem_dq_rel2(), p, st, "attn32_bwd_dq_rel2")
+             : launch(attn32_bwd_dq_kernel<true, false, 1>, smem_dq(true, 1), p, st, "attn32_bwd_dq_rel");
     if (rc) return rc;
+    if (dkv2) return launch(attn32_bwd_dkv_rel2_kernel<false, 1>, smem_dkv(true, 1), p, st, "attn32_bwd_dkv_rel2");
     return launch(attn32_bwd_dkv_kernel<true, false, 2>, smem_dkv(true, 2), p, st, "attn32_bwd_dkv_rel");
 }
