@@ -818,7 +818,10 @@ DEV void attn32_bwd_dq_rel2_body(const AP<bf16_t>& p, const int bid) {
     bf16_t* Pb = Vs + TILE;                                             // ring of three 64 x LDK tiles of p rows
     float* Gs = reinterpret_cast<float*>(Pb + 192 * LDK);               // 4 x 32 x SKH (and, aliased, the dS window)
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+    // (scalar wave index: the ring-slot pointers and the wave's key limit stay in SGPRs -- 248 registers, no spill; the dropout
+    //  instantiation allocates better with the vector form: 248 / 0 against 256 / 13 spills.  tools/isa_census.py shows both.)
+    const int w = DROP ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = p.L, nblk = (L + QB - 1) / QB;
     int bh, blk;
     block_map(bid, nblk, p.B * p.H, bh, blk);
