@@ -14,11 +14,12 @@ top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 
 # workgroups one CU holds at once (csrc: dynamic LDS of the launch / __launch_bounds__ / registers)
 RESIDENCY = [("gemm_p256", 1),                      # 160 KB ring
-             ("block_tail", 1), ("block_qkv", 1),   # 155 KB (32-row forms), 512 registers or >= 82 KB and 8 waves (64-row forms)
+             ("block_tail", 1), ("block_qkv", 1), ("block_link", 1),   # 155 KB (32-row forms), 512 registers or >= 82 KB and 8 waves (64-row forms)
              ("gemm_glds_kernelILi128ELi128", 2),   # 64 KB, 8 waves
              ("gemm_glds_kernelILi96ELi256", 1),    # 135 KB
              ("gemm_glds_kernelILi64ELi64", 3),     # 48-64 KB ring, 4 waves
              ("attn32_bwd_dq_kernelILb1", 1),       # 123 KB (rel-pos windows)
+             ("attn32_bwd_dq_rel2", 2),             # 80 896 bytes, 248 registers
              ("attn32_bwd_dkv_kernelILb1", 2),      # 71 KB, 336 registers -> one per SIMD and block
              ("attn32_bwd_fused", 2), ("attn32_fwd", 2),
              ("lora_rank_mfma", 4), ("gemm_kernelI", 4), ("skinny", 2)]
