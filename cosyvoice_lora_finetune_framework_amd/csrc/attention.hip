@@ -787,7 +787,10 @@ extern "C" int cvft_attn_bias_bwd(int dtype, int B, int H, int T_, const void* q
                                   const float* lse, const void* o_lo, float* delta, void* dq, void* dk, void* dv, int ldg, void* stream) {
     if (check_common("cvft_attn_bias_bwd", dtype, B, H, T_, ld, ldo, q, k, v)) return -1;
     CVFT_CHECK_ARG(!o_lo || (dtype == CVFT_BF16 && (((uintptr_t)o_lo) & 15) == 0), "cvft_attn_bias_bwd: o_lo is a bf16 buffer (16-byte aligned) or NULL");
-    CVFT_CHECK_ARG(o && d_o && lse && delta && dq && dk && dv && ldg >= H * 64, "cvft_attn_bias_bwd: bad args");
+    CVFT_CHECK_ARG(d_o && lse && delta && dq && dk && dv && ldg >= H * 64, "cvft_attn_bias_bwd: bad args");
+    // o == NULL: delta holds rowsum(dO . O) on entry (formed by the producer of dO); bf16 fused kernels only
+    CVFT_CHECK_ARG(o || (dtype == CVFT_BF16 && !o_lo && !attn_v1() && al8(dq, dk, dv, d_o) && ldg % 4 == 0),
+                   "cvft_attn_bias_bwd: o == NULL (delta given) needs bf16, no o_lo, 8-byte aligned gradients");
     CVFT_CHECK_ARG((((uintptr_t)d_o) & 15) == 0, "cvft_attn_bias_bwd: dO must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CVFT_F32) {
@@ -799,7 +802,7 @@ extern "C" int cvft_attn_bias_bwd(int dtype, int B, int H, int T_, const void* q
     AP<bf16_t> a = make_ap<bf16_t>(B, H, T_, q, k, v, ld, nullptr, 0, nullptr, nullptr, klen, 0, scale);
     a.ldo = ldo; a.lse = (float*)lse; a.d_o = (const bf16_t*)d_o; a.delta = delta;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.iso = (iso_len > 0 && iso_len < T_) ? iso_len : 0;
-    if (!attn_v1() && al8(dq, dk, dv, o) && ldg % 4 == 0) {
+    if (!o || (!attn_v1() && al8(dq, dk, dv, o) && ldg % 4 == 0)) {
         a.o = (bf16_t*)o;
         a.o_lo = (bf16_t*)o_lo;
         return cvft_attn32_bwd(a, 0, st);

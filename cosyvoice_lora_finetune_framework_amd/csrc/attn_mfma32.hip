@@ -533,9 +533,12 @@ __global__ void __launch_bounds__(64 * NW) attn32_fwd_kernel(AP<bf16_t> p) {
 // =====================================================================================================================
 // backward dQ: block = 4 waves x 32 queries, 64 keys per step
 // =====================================================================================================================
-template <bool REL, bool DROP, int NBUF, int NW = 4, bool WHOLE = false>
+// PRE: delta arrives in p.delta (rowsum(dO . O), formed by whoever produced dO: the estimator block's tail backward) -- the O / O_lo
+// rows are not read and nothing is published
+template <bool REL, bool DROP, int NBUF, int NW = 4, bool WHOLE = false, bool PRE = false>
 DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
+    static_assert(!PRE || !REL, "precomputed delta: additive-bias (estimator) form only");
     static_assert(NW == 4 || (NW == 8 && !REL), "eight-wave blocks: additive-bias (estimator) form only");
     static_assert(!WHOLE || !REL, "whole-sequence staging: additive-bias (estimator) form only");
     constexpr int NT_ = 64 * NW, QB = 32 * NW;
@@ -592,14 +595,20 @@ DEV void attn32_bwd_dq_body(const AP<bf16_t>& p, const int bid) {
             qv[s] = bias_frag(f, p.bv + hh * 64, s, hf);
         }
         dof[s] = gfrag(dog, i, L, p.ldo, s, hf);
-        const bf16x8 of = gfrag(og, i, L, p.ldo, s, hf);
-        const bf16x8 lf = gfrag(olg, i, L, p.ldo, s, hf);
+        if (!PRE) {
+            const bf16x8 of = gfrag(og, i, L, p.ldo, s, hf);
+            const bf16x8 lf = gfrag(olg, i, L, p.ldo, s, hf);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dsum += (float)dof[s][e] * ((float)of[e] + lo_w * (float)lf[e]);
+            for (int e = 0; e < 8; ++e) dsum += (float)dof[s][e] * ((float)of[e] + lo_w * (float)lf[e]);
+        }
     }
-    // delta[i] = sum_d dO[i][d] O[i][d]; published for the dK/dV kernel, which runs after this one on the stream
-    dsum = xh_sum(dsum);
-    if (hf == 0 && i < L) const_cast<float*>(p.delta)[((size_t)b * p.H + hh) * L + i] = dsum;
+    if (PRE) {
+        dsum = p.delta[((size_t)b * p.H + hh) * L + min(i, L - 1)];
+    } else {
+        // delta[i] = sum_d dO[i][d] O[i][d]; published for the dK/dV kernel, which runs after this one on the stream
+        dsum = xh_sum(dsum);
+        if (hf == 0 && i < L) const_cast<float*>(p.delta)[((size_t)b * p.H + hh) * L + i] = dsum;
+    }
     const float lse_raw = p.lse[((size_t)b * p.H + hh) * L + min(i, L - 1)];
     const float lse2 = (i < L) ? lse_raw * LOG2E : __builtin_inff();
 
@@ -1062,7 +1071,7 @@ template <bool REL, bool DROP, int NBUF, bool OWN_DELTA, int NW = 4, bool WHOLE 
 DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
     using namespace a32;
     static_assert(NW == 4 || (NW == 8 && !REL), "eight-wave blocks: additive-bias (estimator) form only");
-    static_assert(!WHOLE || (!REL && OWN_DELTA), "whole-sequence staging: additive-bias (estimator) form with its own delta only");
+    static_assert(!WHOLE || !REL, "whole-sequence staging: additive-bias (estimator) form only");
     constexpr int NT_ = 64 * NW, QB = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
@@ -1166,23 +1175,30 @@ DEV void attn32_bwd_dkv_body(const AP<bf16_t>& p, const int bid) {
         }                                                                                  \
     } while (0)
         if constexpr (WHOLE) {      // (see attn32_fwd_body) all Q / dO tiles (+ lse, delta) once, barrier-free step loop
-            Tile2 qa4[NBUF], da4[NBUF], oa4[NBUF], la4[NBUF];
-            float ls4[NBUF];
+            Tile2 qa4[NBUF], da4[NBUF], oa4[OWN_DELTA ? NBUF : 1], la4[OWN_DELTA ? NBUF : 1];
+            float ls4[NBUF], dl4[NBUF];
 #pragma unroll
             for (int t = 0; t < NBUF; ++t) {
                 tload<NT_>(qa4[t], qg, p.ld, 64 * t, L, tid);
                 tload<NT_>(da4[t], dog, p.ldo, 64 * t, L, tid);
-                tload<NT_>(oa4[t], og, p.ldo, 64 * t, L, tid);
-                tload<NT_>(la4[t], olg, p.ldo, 64 * t, L, tid);
-                ls4[t] = p.lse[((size_t)b * p.H + hh) * L + min(64 * t + (tid & 63), L - 1)];
+                if (OWN_DELTA) {
+                    tload<NT_>(oa4[t], og, p.ldo, 64 * t, L, tid);
+                    tload<NT_>(la4[t], olg, p.ldo, 64 * t, L, tid);
+                }
+                const size_t li = ((size_t)b * p.H + hh) * L + min(64 * t + (tid & 63), L - 1);
+                ls4[t] = p.lse[li];
+                dl4[t] = OWN_DELTA ? 0.f : p.delta[li];
             }
 #pragma unroll
             for (int t = 0; t < NBUF; ++t) {
                 qr[0] = qa4[t][0]; qr[1] = qa4[t][1];
                 dor[0] = da4[t][0]; dor[1] = da4[t][1];
-                orr[0] = oa4[t][0]; orr[1] = oa4[t][1];
-                olr[0] = la4[t][0]; olr[1] = la4[t][1];
+                if (OWN_DELTA) {
+                    orr[0] = oa4[t][0]; orr[1] = oa4[t][1];
+                    olr[0] = la4[t][0]; olr[1] = la4[t][1];
+                }
                 lse_n = ls4[t];
+                del_n = dl4[t];
                 A32_KV_PUBLISH(t, 64 * t);
             }
             touch(kf);
@@ -1367,10 +1383,11 @@ __global__ void __launch_bounds__(256, 2) attn32_bwd_dkv_rel2_kernel(AP<bf16_t> 
 // Both backward roles in ONE launch (blocks [0, nq): dQ, blocks [nq, 2 nq): dK/dV with its own delta): at the estimator's
 // sizes a role alone is one 4-wave block per CU (T = 250: 256 blocks), i.e. one wave per SIMD with every latency
 // exposed; together they put two waves on a SIMD, and one launch boundary per attention backward disappears.
-template <bool REL, bool DROP, int NBUF, int NW = 4, bool WHOLE = false>
+// PRE: delta is an INPUT (p.delta; p.o == nullptr): neither role reads O
+template <bool REL, bool DROP, int NBUF, int NW = 4, bool WHOLE = false, bool PRE = false>
 __global__ void __launch_bounds__(64 * NW) attn32_bwd_fused_kernel(AP<bf16_t> p, int nq) {
-    if ((int)blockIdx.x < nq) attn32_bwd_dq_body<REL, DROP, NBUF, NW, WHOLE>(p, blockIdx.x);
-    else attn32_bwd_dkv_body<REL, DROP, NBUF, true, NW, WHOLE>(p, blockIdx.x - nq);
+    if ((int)blockIdx.x < nq) attn32_bwd_dq_body<REL, DROP, NBUF, NW, WHOLE, PRE>(p, blockIdx.x);
+    else attn32_bwd_dkv_body<REL, DROP, NBUF, !PRE, NW, WHOLE>(p, blockIdx.x - nq);
 }
 
 // =====================================================================================================================
@@ -1436,6 +1453,25 @@ int cvft_attn32_bwd(const AP<bf16_t>& p, int rel, hipStream_t st) {
         if (split < 0) {
             const char* e = getenv("CVFT_ATTN_BWD_SPLIT");
             split = (e && e[0] == '1') ? 1 : 0;
+        }
+        if (p.o == nullptr) {      // delta precomputed by the producer of dO (include/cvft.h): the fused launch, neither role reads O
+            if (split || est_waves() == 8) {
+                cvft_set_error("cvft_attn_bias_bwd: o == NULL (delta given) is not available with CVFT_ATTN_BWD_SPLIT=1 / CVFT_ATTN_NW=8");
+                return -1;
+            }
+            const int nq = ((p.L + 127) / 128) * p.H * p.B;
+            if (est_whole() && p.L <= 256) {
+                const size_t sm = smem_dq(false, 4) > smem_dkv(false, 4) ? smem_dq(false, 4) : smem_dkv(false, 4);
+                if (set_smem(attn32_bwd_fused_kernel<false, false, 4, 4, true, true>, sm, "attn32_bwd_fused_whole_pre")) return -2;
+                hipLaunchKernelGGL((attn32_bwd_fused_kernel<false, false, 4, 4, true, true>), dim3(2u * nq), dim3(256), sm, st, p, nq);
+                CVFT_LAUNCH_CHECK("attn32_bwd_fused_whole_pre");
+                return 0;
+            }
+            const size_t sm = smem_dq(false, 2) > smem_dkv(false, 2) ? smem_dq(false, 2) : smem_dkv(false, 2);
+            if (set_smem(attn32_bwd_fused_kernel<false, false, 2, 4, false, true>, sm, "attn32_bwd_fused_pre")) return -2;
+            hipLaunchKernelGGL((attn32_bwd_fused_kernel<false, false, 2, 4, false, true>), dim3(2u * nq), dim3(256), sm, st, p, nq);
+            CVFT_LAUNCH_CHECK("attn32_bwd_fused_pre");
+            return 0;
         }
         if (!split && est_waves() == 8) {
             const size_t sm = smem_dq(false, 2) > smem_dkv(false, 2) ? smem_dq(false, 2) : smem_dkv(false, 2);

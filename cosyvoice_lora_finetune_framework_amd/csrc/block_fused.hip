@@ -277,6 +277,7 @@ struct TailBwd {
     const bf16x8* Wst; int wave_frags; int F;
     bf16_t* dx1;
     bf16_t* dout; int lddo;
+    const bf16_t* ao; const bf16_t* ao_lo; int ldao; float* delta; int T;      // (optional: delta for the attention backward, cvft.h)
 };
 
 // W1^T product of one hidden tile: g = W2^T dy (accumulator layout), zs = the tile's saved pre-activations -> dz = g act'(z),
@@ -419,12 +420,28 @@ __device__ __forceinline__ void bt_bwd_body(const TailBwd& a, char* smem, bf16x8
         }
     if (BF_TOUCH && !LINK && bf_touch_fold(touched) == 0x7fc07fc1u && a.M < 0) a.dx1[0] = (bf16_t)0.f;  // (keeps the prefetch loads alive; never true)
     if (CR == 0) return;
+    // delta for the attention backward that consumes dout (optional, cvft.h)
+    const bool wdel = a.delta != nullptr;
+    const bf16_t* aol = a.ao_lo ? a.ao_lo : a.ao;         // (no residual: the same values, weighted 0 -- unconditional loads)
+    const float lo_w = a.ao_lo ? 1.f : 0.f;
     __syncthreads();
     // ---- do = dx1 Wo: wave w owns output features [w*DI/4, (w+1)*DI/4): 2 feature tiles per round, stream order [ks][f2]
     bf16x8 dxf[BF_KS];
     bf_tile_read(smem, lane, dxf);
 #pragma unroll
     for (int r = 0; r < CR; ++r) {
+        // (the attention output's values of this lane's row and this round's 64 columns: requested in front of the round's products)
+        bf16x4 ob[2][4], lb[2][4];
+        if (wdel) {
+#pragma unroll
+            for (int f2 = 0; f2 < 2; ++f2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const size_t off = (size_t)row * a.ldao + 32 * (wave * 2 * CR + 2 * r + f2) + 8 * g + 4 * h;
+                    ob[f2][g] = *reinterpret_cast<const bf16x4*>(a.ao + off);
+                    lb[f2][g] = *reinterpret_cast<const bf16x4*>(aol + off);
+                }
+        }
         f32x16 acc[2] = {zero16(), zero16()};
 #pragma unroll
         for (int j = 0; j < BF_RING; ++j) {
@@ -432,16 +449,23 @@ __device__ __forceinline__ void bt_bwd_body(const TailBwd& a, char* smem, bf16x8
             if (r + 1 < CR) ring[j] = nx[j * 64];
         }
         nx += BF_RING * 64;
-        if (rvalid) {
+        float part = 0.f;
 #pragma unroll
-            for (int f2 = 0; f2 < 2; ++f2)
+        for (int f2 = 0; f2 < 2; ++f2)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 d;
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 d;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) d[i] = (bf16_t)acc[f2][4 * g + i];
-                    *reinterpret_cast<bf16x4*>(a.dout + (size_t)row * a.lddo + 32 * (wave * 2 * CR + 2 * r + f2) + 8 * g + 4 * h) = d;
+                for (int i = 0; i < 4; ++i) d[i] = (bf16_t)acc[f2][4 * g + i];
+                if (rvalid) *reinterpret_cast<bf16x4*>(a.dout + (size_t)row * a.lddo + 32 * (wave * 2 * CR + 2 * r + f2) + 8 * g + 4 * h) = d;
+                if (wdel) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) part += (float)d[i] * ((float)ob[f2][g][i] + lo_w * (float)lb[f2][g][i]);
                 }
+            }
+        if (wdel) {      // round r of wave w is head w CR + r (64 columns = its two feature tiles); the two lane halves hold 16 + 16 of each tile
+            part += __shfl_xor(part, 32);
+            if (h == 0 && rvalid) a.delta[((size_t)(row / a.T) * (2 * CR) * 2 + (wave * CR + r)) * a.T + row % a.T] = part;
         }
     }
 }
@@ -568,6 +592,20 @@ extern "C" int cvft_block_link_fwd(const cvft_block_tail_args* p, const cvft_blo
     return 0;
 }
 
+// the optional delta output of the tail backward (cvft.h): checked and copied into a kernel argument block
+template <typename P>
+static int tail_delta_args(const cvft_block_tail_bwd_args* p, const P*& ao, const P*& ao_lo, int& ldao, float*& delta, int& T, const char* who) {
+    ao = nullptr; ao_lo = nullptr; ldao = 0; delta = nullptr; T = 1;
+    if (!p->delta) return 0;
+    if (!(p->dout && p->DI == 512 && p->attn_o && p->T > 0 && p->M % p->T == 0 && p->ldao % 4 == 0 && p->ldao >= p->DI &&
+          (reinterpret_cast<uintptr_t>(p->attn_o) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->attn_o_lo) & 15) == 0 && (p->lean == 0 || p->lean == 2))) {
+        cvft_set_error("%s: delta needs dout with DI == 512, attn_o (16-byte aligned, ldao %% 4 == 0), M == B * T, form 0 or 2", who);
+        return -1;
+    }
+    ao = (const P*)p->attn_o; ao_lo = (const P*)p->attn_o_lo; ldao = p->ldao; delta = p->delta; T = p->T;
+    return 0;
+}
+
 template <int ACT, int CR, bool DROP>
 static int launch_link_bwd(const QkvBwd& q, const TailBwd& a, hipStream_t st) {
     static int ready = 0;
@@ -604,6 +642,7 @@ extern "C" int cvft_block_link_bwd(const cvft_block_qkv_bwd_args* q, const cvft_
     a.M = p->M; a.x1 = (const bf16_t*)p->x1; a.dy = (const bf16_t*)p->dy; a.gamma = p->gamma; a.mean = p->mean; a.rstd = p->rstd;
     a.z = (const bf16_t*)p->z; a.Wst = nullptr; a.wave_frags = p->F / 4 + p->DI / 8; a.F = p->F;
     a.dx1 = (bf16_t*)p->dx1; a.dout = (bf16_t*)p->dout; a.lddo = p->lddo;
+    if (tail_delta_args(p, a.ao, a.ao_lo, a.ldao, a.delta, a.T, "cvft_block_link_bwd")) return -1;
     const bool erf = p->act == CVFT_ACT_GELU_ERF, drop = q->p > 0.f;
     hipStream_t st = (hipStream_t)stream;
     const int rc = erf ? (drop ? launch_link_bwd<CVFT_ACT_GELU_ERF, 2, true>(h, a, st) : launch_link_bwd<CVFT_ACT_GELU_ERF, 2, false>(h, a, st))
@@ -622,6 +661,11 @@ extern "C" int cvft_block_tail_bwd(const cvft_block_tail_bwd_args* p, void* stre
     CVFT_CHECK_ARG(al16(p->x1) && al16(p->dy) && al16(p->gamma) && al16(p->z) && al16(p->W_bwd) && al16(p->dx1), "cvft_block_tail_bwd: operands must be 16-byte aligned");
     if (p->lean) {
         CVFT_CHECK_ARG(p->lean == 1 || (p->lean == 2 && p->F >= 256), "cvft_block_tail_bwd: lean must be 0, 1 or 2 (2: F >= 256)");
+        {
+            const bf16_t* t0; const bf16_t* t1; int t2, t4; float* t3;      // (validates the optional delta request: forms 0 and 2 only)
+            if (tail_delta_args(p, t0, t1, t2, t3, t4, "cvft_block_tail_bwd")) return -1;
+            CVFT_CHECK_ARG(!p->delta || p->ldao % 8 == 0, "cvft_block_tail_bwd: the wide form reads attn_o in 16-byte pieces (ldao %% 8 == 0)");
+        }
         CVFT_CHECK_ARG(p->lean == 1 || !p->dout || p->lddo % 8 == 0, "cvft_block_tail_bwd: the wide form stores dout in 16-byte pieces (lddo %% 8 == 0)");
         const int rc = p->lean == 2 ? block_tail_wide_bwd_launch(p, DI, stream) : block_tail_lean_bwd_launch(p, DI, stream);
         if (rc) return rc;
@@ -632,6 +676,7 @@ extern "C" int cvft_block_tail_bwd(const cvft_block_tail_bwd_args* p, void* stre
     a.M = p->M; a.x1 = (const bf16_t*)p->x1; a.dy = (const bf16_t*)p->dy; a.gamma = p->gamma; a.mean = p->mean; a.rstd = p->rstd;
     a.z = (const bf16_t*)p->z; a.Wst = (const bf16x8*)p->W_bwd; a.wave_frags = p->F / 4 + p->DI / 8; a.F = p->F;
     a.dx1 = (bf16_t*)p->dx1; a.dout = (bf16_t*)p->dout; a.lddo = p->lddo;
+    if (tail_delta_args(p, a.ao, a.ao_lo, a.ldao, a.delta, a.T, "cvft_block_tail_bwd")) return -1;
     const bool erf = p->act == CVFT_ACT_GELU_ERF;
     int rc;
     hipStream_t st = (hipStream_t)stream;

@@ -477,6 +477,7 @@ struct WideBwd {
     const bf16x8* Wst; int wave_frags; int F;
     bf16_t* dx1;
     bf16_t* dout; int lddo;
+    const bf16_t* ao; const bf16_t* ao_lo; int ldao; float* delta; int T;      // (optional: delta for the attention backward, cvft.h)
 };
 
 // Stream per wave w ("wide"): with H1(r) = W2^T of hidden tile 4 r + w (16 fragments [ks]) and H2(r) = W1^T of its two feature
@@ -668,14 +669,40 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
                     const int c = 32 * (wave * NF + f) + 8 * g + 4 * h;
                     *reinterpret_cast<bf16x4*>(OUT + t * 32 * PITCH + m * PITCH + (((c >> 3) ^ (m & 15)) << 4) + ((c & 7) << 1)) = d;
                 }
-        __syncthreads();
         constexpr int CPR = CR > 0 ? 32 * CR : 32;     // 16-byte chunks per row
+        constexpr int NIT = 8 * (CR > 0 ? CR : 1);
+        // delta for the attention backward that consumes dout (optional): this thread's chunks of the attention output, requested
+        // in front of the barrier the store loop waits behind (a chunk = 8 columns; 8 consecutive lanes = one head's 64)
+        const bool wdel = a.delta != nullptr;
+        bf16x8 ob[NIT], lb[NIT];
+        if (wdel) {
+            const bf16_t* aol = a.ao_lo ? a.ao_lo : a.ao;
 #pragma unroll
-        for (int i = 0; i < 8 * (CR > 0 ? CR : 1); ++i) {
+            for (int i = 0; i < NIT; ++i) {
+                const int q = i * 256 + threadIdx.x;
+                const int r = min(m0 + q / CPR, a.M - 1), ch = q % CPR;
+                ob[i] = *reinterpret_cast<const bf16x8*>(a.ao + (size_t)r * a.ldao + 8 * ch);
+                lb[i] = *reinterpret_cast<const bf16x8*>(aol + (size_t)r * a.ldao + 8 * ch);
+            }
+        }
+        const float lo_w = a.ao_lo ? 1.f : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
             const int q = i * 256 + threadIdx.x;
             const int r = q / CPR, ch = q % CPR;
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(OUT + (r >> 5) * 32 * PITCH + (r & 31) * PITCH + ((ch ^ (r & 15)) << 4));
             if (m0 + r < a.M) *reinterpret_cast<bf16x8*>(a.dout + (size_t)(m0 + r) * a.lddo + 8 * ch) = v;
+            if (wdel) {
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part += (float)v[e] * ((float)ob[i][e] + lo_w * (float)lb[i][e]);
+                part += __shfl_xor(part, 1);
+                part += __shfl_xor(part, 2);
+                part += __shfl_xor(part, 4);
+                const int row = m0 + r;
+                if ((ch & 7) == 0 && row < a.M) a.delta[((size_t)(row / a.T) * (CPR / 8) + (ch >> 3)) * a.T + row % a.T] = part;
+            }
         }
         BF_STAMP(27);
     }
@@ -722,6 +749,8 @@ int block_tail_wide_bwd_launch(const cvft_block_tail_bwd_args* p, int DI, void* 
     a.M = p->M; a.x1 = (const bf16_t*)p->x1; a.dy = (const bf16_t*)p->dy; a.gamma = p->gamma; a.mean = p->mean; a.rstd = p->rstd;
     a.z = (const bf16_t*)p->z; a.Wst = (const bf16x8*)p->W_bwd; a.wave_frags = p->F / 4 + p->DI / 8; a.F = p->F;
     a.dx1 = (bf16_t*)p->dx1; a.dout = (bf16_t*)p->dout; a.lddo = p->lddo;
+    // (the optional delta output: checked by the caller, cvft_block_tail_bwd)
+    a.ao = (const bf16_t*)p->attn_o; a.ao_lo = (const bf16_t*)p->attn_o_lo; a.ldao = p->ldao; a.delta = p->delta; a.T = p->T > 0 ? p->T : 1;
     const bool erf = p->act == CVFT_ACT_GELU_ERF;
     hipStream_t st = (hipStream_t)stream;
     if (DI == 0) return erf ? launch_wide_bwd<CVFT_ACT_GELU_ERF, 0>(a, st) : launch_wide_bwd<CVFT_ACT_GELU_TANH, 0>(a, st);

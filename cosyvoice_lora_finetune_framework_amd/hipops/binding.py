@@ -49,7 +49,9 @@ class BlockTailBwdArgs(C.Structure):
     """mirror of cvft_block_tail_bwd_args (include/cvft.h)"""
     _fields_ = [("M", C.c_int), ("x1", C.c_void_p), ("dy", C.c_void_p), ("gamma", C.c_void_p), ("mean", C.c_void_p),
                 ("rstd", C.c_void_p), ("z", C.c_void_p), ("W_bwd", C.c_void_p), ("F", C.c_int), ("DI", C.c_int),
-                ("act", C.c_int), ("dx1", C.c_void_p), ("dout", C.c_void_p), ("lddo", C.c_int), ("lean", C.c_int)]
+                ("act", C.c_int), ("dx1", C.c_void_p), ("dout", C.c_void_p), ("lddo", C.c_int),
+                ("attn_o", C.c_void_p), ("attn_o_lo", C.c_void_p), ("ldao", C.c_int), ("delta", C.c_void_p), ("T", C.c_int),
+                ("lean", C.c_int)]
 
 
 class BlockQkvArgs(C.Structure):

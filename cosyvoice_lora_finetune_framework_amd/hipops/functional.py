@@ -387,6 +387,8 @@ _H_PRE_V = "_cvft_pre_v"              # on dxm:   (V, Bt data_ptr, scale)
 _H_FORK = "_cvft_fork"                # on x read by both convolutions of a ResnetBlock1D:   token of the "take" conv
 _H_LINK = "_cvft_link"                # on the block output a linked tail launch wrote:   the NEXT block's head products (_QkvHead)
 _H_LINK_BWD = "_cvft_link_bwd"        # on the dx a linked head backward returns:   the _LinkRec whose tail backward ran in that launch
+_H_ATTN_O = "_cvft_attn_o"            # on the estimator attention's output o:   (o_lo or None, B, H, T) for the block tail that consumes o
+_H_DELTA = "_cvft_delta"              # on the do a block tail backward returns:   delta [B, H, T] = rowsum(do . (o + o_lo)) per head
 
 
 def _hand(t: torch.Tensor, name: str, value) -> None:
@@ -1482,6 +1484,7 @@ class BlockTailFn(torch.autograd.Function):
         a.x1, a.gamma, a.beta, a.eps = ptr(x1), ptr(pack.gamma), ptr(pack.beta), pack.eps
         a.b1, a.F, a.b2, a.act = ptr(pack.b1), pack.F, ptr(pack.b2), ACT[act]
         a.z, a.mean, a.rstd, a.out = ptr(z), ptr(mean), ptr(rstd), ptr(out)
+        att = _take_hand(o, _H_ATTN_O) if o is not None else None
         head = None
         if link is not None and fwd_form == 0 and o is not None and pack.DI == 512 and 256 <= pack.F <= 1024:
             # the NEXT block's norm1 + q|k|v head rides in the same launch (csrc/block_fused.hip, block_link_fwd_kernel); its products
@@ -1499,13 +1502,20 @@ class BlockTailFn(torch.autograd.Function):
             with _Bracket("block_tail_fwd", 2.0 * M * 256 * (2 * pack.F + (pack.DI if o is not None else 0)),
                           2.0 * (M * (3 * 256 + pack.DI) + 256 * (2 * pack.F + pack.DI))):
                 check(lib().cvft_block_tail_fwd(C.byref(a), stream()), "cvft_block_tail_fwd")
-        ctx.save_for_backward(x1, z, mean, rstd)
+        ctx.attn_dims = None
+        if att is not None and att[1] * att[3] == M and att[2] * 64 == pack.DI and o.stride(0) % 8 == 0:
+            ctx.attn_dims = att[1:]                     # (B, H, T): backward forms the attention backward's delta next to do
+            ctx.save_for_backward(x1, z, mean, rstd, o, att[0])
+        else:
+            ctx.save_for_backward(x1, z, mean, rstd)
         ctx.pack, ctx.act, ctx.has_o = pack, act, o is not None
         return out
 
     @staticmethod
     def tail_bwd_args(ctx, dy, lean: int, want_do: bool):
-        x1, z, mean, rstd = ctx.saved_tensors
+        """-> (argument block, dx1, do, delta): delta [B, H, T] (or None) is written next to do when the forward saw the estimator
+        attention's hand-over (`_H_ATTN_O`) -- forms 0 and 2 of the kernels"""
+        x1, z, mean, rstd, *att = ctx.saved_tensors
         pack = ctx.pack
         M = x1.shape[0]
         a = cb.BlockTailBwdArgs()
@@ -1514,10 +1524,15 @@ class BlockTailFn(torch.autograd.Function):
         a.M, a.x1, a.dy, a.gamma, a.mean, a.rstd, a.z = M, ptr(x1), ptr(dy), ptr(pack.gamma), ptr(mean), ptr(rstd), ptr(z)
         a.W_bwd, a.F, a.DI, a.act, a.dx1 = ptr((pack.W_bwd, pack.W_bwd_lean, pack.W_bwd_wide)[lean]), pack.F, pack.DI, ACT[ctx.act], ptr(dx1)
         a.lean = int(lean)
+        delta = None
         if want_do:
             do = torch.empty((M, pack.DI), dtype=x1.dtype, device=x1.device)
             a.dout, a.lddo = ptr(do), do.stride(0)
-        return a, dx1, do
+            if att and ctx.attn_dims is not None and lean in (0, 2) and pack.DI == 512:
+                B, H, T = ctx.attn_dims
+                delta = torch.empty((B, H, T), dtype=torch.float32, device=x1.device)
+                a.attn_o, a.attn_o_lo, a.ldao, a.delta, a.T = ptr(att[0]), ptr(att[1]), att[0].stride(0), ptr(delta), T
+        return a, dx1, do, delta
 
     @staticmethod
     def backward(ctx, dy):
@@ -1529,10 +1544,12 @@ class BlockTailFn(torch.autograd.Function):
         pack = ctx.pack
         dy = _c(dy)
         M = dy.shape[0]
-        a, dx1, do = BlockTailFn.tail_bwd_args(ctx, dy, ctx.lean, ctx.has_o and ctx.needs_input_grad[0])
+        a, dx1, do, delta = BlockTailFn.tail_bwd_args(ctx, dy, ctx.lean, ctx.has_o and ctx.needs_input_grad[0])
         with _Bracket("block_tail_bwd", 2.0 * M * 256 * (2 * pack.F + (pack.DI if do is not None else 0)),
                       2.0 * (M * (3 * 256 + pack.F + pack.DI) + 256 * (2 * pack.F + pack.DI))):
             check(lib().cvft_block_tail_bwd(C.byref(a), stream()), "cvft_block_tail_bwd")
+        if delta is not None:
+            _hand(do, _H_DELTA, delta)
         return do, dx1, None, None, None
 
 
@@ -1648,11 +1665,13 @@ class BlockQkvFn(torch.autograd.Function):
                 and 256 <= tctx.pack.F <= 1024):
             # the PREVIOUS block's tail backward rides in this launch (csrc/block_fused.hip, block_link_bwd_kernel): dx is its dy
             a.wide, a.W_bwd = 0, ptr(pack.W_bwd)
-            ta, dx1, do = BlockTailFn.tail_bwd_args(tctx, dx, 0, True)
+            ta, dx1, do, tdelta = BlockTailFn.tail_bwd_args(tctx, dx, 0, True)
             tp = tctx.pack
             with _Bracket("block_link_bwd", 2.0 * M * N3 * (256 + 48) + 2.0 * M * 48 * 256 + 2.0 * M * 256 * (2 * tp.F + tp.DI),
                           2.0 * (M * (N3 + 6 * 256 + tp.F + tp.DI) + 256 * (N3 + 2 * tp.F + tp.DI))):
                 check(lib().cvft_block_link_bwd(C.byref(a), C.byref(ta), ptr(rec.lpack.W_bwd), stream()), "cvft_block_link_bwd")
+            if tdelta is not None:
+                _hand(do, _H_DELTA, tdelta)
             rec.results = (dx1, do)
             _hand(dx, _H_LINK_BWD, rec)
         else:
@@ -1736,6 +1755,10 @@ def block_tail_lean() -> int:
     if BLOCK_LEAN in ("0", "1", "2", "3", "4"):
         return int(BLOCK_LEAN)
     return 3 if lib().cvft_concurrent_chains() >= 3 else 0
+# The attention backward's delta = rowsum(dO . (O + O_lo)) formed by the launch that PRODUCES dO, the block tail's backward (it holds the
+# dO tile it is about to store; cvft_block_tail_bwd_args.delta), so that neither attention backward role loads O / O_lo: per launch
+# 34.8 -> 33.1 us at T = 250 and 98.3 -> 64.8 us at T = 500 (B = 16, tools/bench_attn.py).  "0" off.
+TAIL_DELTA = _os.environ.get("CVFT_TAIL_DELTA", "1") != "0"
 # The tail of block i and the head of block i + 1 in one launch (cvft_block_link_fwd; 32-row forms): "0" off, "1" / "auto" (default) on.
 # Graph-timed per boundary at M = 2000 (tools/bench_link.py): tail + 64-row head 47.4 us, tail + 32-row head on two workgroups per row
 # tile 40.4 us, linked 43.1 us -- a workgroup's time is its weight stream (2 MB at ~50 GB/s per CU), which the link does not shorten:
@@ -2049,19 +2072,27 @@ class AttnBiasFn(torch.autograd.Function):
                                            o.stride(0), ptr(lse), ptr(o_lo), stream()), "cvft_attn_bias_fwd")
         ctx.save_for_backward(q, k, v, o, lse, o_lo)
         ctx.args = (B, H, T, klen, scale, int(iso_len))
+        if TAIL_DELTA and q.dtype == torch.bfloat16:
+            _hand(o, _H_ATTN_O, (o_lo, B, H, T))          # for the block tail that consumes o: its backward can form delta (below)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse, o_lo = ctx.saved_tensors
         B, H, T, klen, scale, iso_len = ctx.args
+        pre = _take_hand(do, _H_DELTA)
         do = _c(do)
         dqkv = torch.empty((B * T, 3 * H * 64), dtype=q.dtype, device=q.device)
         dq, dk, dv = dqkv[:, :H * 64], dqkv[:, H * 64:2 * H * 64], dqkv[:, 2 * H * 64:]
-        delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+        if pre is not None and tuple(pre.shape) == (B, H, T) and q.dtype == torch.bfloat16:
+            # delta = rowsum(do . (o + o_lo)) came with do from the launch that produced it (the block tail's backward): neither
+            # backward role reads o (cvft_attn_bias_bwd with o == NULL)
+            delta, po, plo = pre, None, None
+        else:
+            delta, po, plo = torch.empty((B, H, T), dtype=torch.float32, device=q.device), o, o_lo
         with _Bracket("attn_bias_bwd", 10.0 * B * H * T * T * 64, 8.0 * B * T * H * 64 * q.element_size()):    # S, dP, dV, dK, dQ
-            check(lib().cvft_attn_bias_bwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, iso_len, ptr(o),
-                                           ptr(do), o.stride(0), ptr(lse), ptr(o_lo), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+            check(lib().cvft_attn_bias_bwd(dt(q), B, H, T, ptr(q), ptr(k), ptr(v), q.stride(0), ptr(klen), scale, iso_len, ptr(po),
+                                           ptr(do), o.stride(0), ptr(lse), ptr(plo), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                            dqkv.stride(0), stream()), "cvft_attn_bias_bwd")
         return dq, dk, dv, None, None, None, None, None, None
 

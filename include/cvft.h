@@ -232,6 +232,8 @@ int cvft_attn_bias_bwd(int dtype, int B, int H, int T, const void* q, const void
                        const int32_t* klen, float scale, int iso_len, const void* o, const void* d_o, int ldo,
                        const float* lse, const void* o_lo /* the forward's, or NULL */, float* delta /*[B][H][T] ws*/,
                        void* dq, void* dk, void* dv, int ldg, void* stream);
+/* (o == NULL, bf16: delta is an INPUT -- rowsum over each head's columns of dO . (O + O_lo), formed by the producer of dO
+ * (cvft_block_tail_bwd / cvft_block_link_bwd, `delta`) -- and neither backward role reads the forward's output.) */
 
 /* ---------------------------------------------------------------------------------
  * Fused relative-position attention (Transformer-XL / ESPnet), head_dim 64:
@@ -429,6 +431,10 @@ typedef struct {
     const void* W_bwd; int F; int DI; int act;
     void* dx1;                           /* [M][256] gradient at x1 (= gradient of x0 through the residual) */
     void* dout; int lddo;                /* dout [M][DI] = dx1 . to_out.weight, or NULL (not wanted / DI == 0) */
+    /* optional (forms 0 and 2, with dout): delta[(b * DI/64 + h) * T + t] = sum over head h's 64 columns of dout[b T + t] . (attn_o +
+       attn_o_lo)[b T + t] -- what the attention backward that consumes dout needs of its own output (cvft_attn_bias_bwd with o ==
+       NULL); attn_o [M][ldao] is the attention output the forward's `o` was, attn_o_lo its rounding residual or NULL; M == B * T */
+    const void* attn_o; const void* attn_o_lo; int ldao; float* delta; int T;
     int lean;                            /* as in cvft_block_tail_args; lean W_bwd, wave w: natural(W2^T, w, ks); per round r:
                                             [natural(W2^T, 4 (r+1) + w, ks)], natural(W1^T, 2 w + c2, 8 r + k') in order [k'][c2];
                                             natural(Wo^T, (DI/128) w + f, ks) in order [ks][f];  2: the same groups in the lagged

@@ -218,6 +218,7 @@ def test_linked_block_launches_equal_separate_launches():
         HF.BLOCK_LINK, HF.BLOCK_LINK_BWD = keep
     assert taken[0] == 0 and taken[1] >= 2 * 36, taken
     assert taken_bwd[0] == 0 and taken_bwd[1] == taken[1], (taken, taken_bwd)      # every linked boundary also ran linked backwards
+    assert HF.HANDS_TAKEN.get(HF._H_DELTA, 0) >= 2 * 48, HF.HANDS_TAKEN      # the attention backwards took delta from the tails' backward
     for i in range(2):
         for k in ("loss", "llm_loss", "flow_loss", "grad_norm"):
             assert abs(res[0][0][i][k] - res[1][0][i][k]) <= 1e-6 * abs(res[0][0][i][k]), (i, k, res[0][0][i], res[1][0][i])

@@ -356,3 +356,84 @@ def test_block_link_bwd_equals_head_then_tail_bitwise(M, Fh, p, act):
     for k in res[True]:
         assert torch.equal(res[True][k], res[False][k]), (k, rel(res[True][k], res[False][k]))
     assert float(res[True]["do"].float().abs().max()) > 1e-3 and torch.isfinite(res[True]["do"].float()).all()
+
+
+@pytest.mark.parametrize("form", ["tail32", "tail64", "link"])
+@pytest.mark.parametrize("M,T,with_lo", [(64, 32, True), (250, 125, True), (4000, 500, False), (2000, 250, True)])
+def test_tail_backward_delta_for_the_attention_backward(M, T, with_lo, form):
+    """cvft_block_tail_bwd / cvft_block_link_bwd also form delta[b, h, t] = sum over head h's 64 columns of dout . (attn_o + attn_o_lo)
+    -- what the attention backward that consumes dout needs of its own output (it is then called with o == NULL) -- from the dout
+    tile they are about to store: against the same sum taken in fp64 from the STORED dout, every form that offers it (32-row,
+    64-row, the linked launch), ragged row tiles, with and without the residual; the other outputs do not change."""
+    from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
+    from cosyvoice_lora_finetune_framework_amd.hipops import functional as HF
+    from cosyvoice_lora_finetune_framework_amd.hipops.blockpack import BlockLinkPack, BlockQkvPack, BlockTailPack
+    import ctypes as C
+    d = lambda t: t.to(DEV)
+    Fh, B = 1024, M // T
+    w = _weights(512, Fh, seed=M)
+    wd = {k: d(v) for k, v in w.items()}
+    tpack = BlockTailPack(wd["wo"], wd["bo"], wd["gamma"], wd["beta"], 1e-5, wd["w1"], wd["b1"], wd["w2"], wd["b2"])
+    wq, x, dY, dres = _qkv_case(M, 0.0, seed=M + 7)
+    hpack = BlockQkvPack(d(wq["wqkv"]), d(wq["bias"]), d(wq["gamma"]), d(wq["beta"]), 1e-5)
+    lpack = BlockLinkPack(tpack, hpack)
+    A = torch.cat(wq["A"], 0).to(torch.bfloat16)
+    Bb = torch.zeros(1536, 48)
+    for t in range(3):
+        Bb[512 * t:512 * (t + 1), 16 * t:16 * (t + 1)] = wq["B"][t]
+    At, Bbt = d(A.t().contiguous()), d(Bb.to(torch.bfloat16).t().contiguous())
+    g = torch.Generator().manual_seed(M + 1)
+    o = d(torch.randn(M, 512, generator=g).to(torch.bfloat16))
+    o_lo = d((torch.randn(M, 512, generator=g) * 2 ** -9).to(torch.bfloat16)) if with_lo else None
+    x0 = d((torch.randn(M, 256, generator=g) * 2.0 + 0.3).to(torch.bfloat16))
+    dy = d(torch.randn(M, 256, generator=g).to(torch.bfloat16))
+    bfz = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=DEV)
+    x1, out, z = bfz(M, 256), bfz(M, 256), bfz(-(-M // 64) * 64 * Fh)
+    mean, rstd = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+    a = _tail_args(cb, M, o, x0, tpack, x1, out, mean, rstd, z, HF.ACT["gelu_erf"])
+    cb.check(cb.lib().cvft_block_tail_fwd(C.byref(a), cb.stream()), "tail fwd")
+    of = out.float()
+    mean2, rstd2 = of.mean(1).contiguous(), (of.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    dYd, dresd = d(dY.to(torch.bfloat16)), d(dres.to(torch.bfloat16))
+    res = {}
+    for want in (False, True):
+        V, dx, dx1, do = bfz(M, 48), bfz(M, 256), bfz(M, 256), bfz(M, 512)
+        delta = torch.full((B, 8, T), 7.0, device=DEV)
+        t = cb.BlockTailBwdArgs()
+        t.M, t.x1, t.gamma, t.mean, t.rstd, t.z = M, cb.ptr(x1), cb.ptr(tpack.gamma), cb.ptr(mean), cb.ptr(rstd), cb.ptr(z)
+        t.F, t.DI, t.act, t.dx1, t.dout, t.lddo = Fh, 512, HF.ACT["gelu_erf"], cb.ptr(dx1), cb.ptr(do), 512
+        if want:
+            t.attn_o, t.attn_o_lo, t.ldao, t.delta, t.T = cb.ptr(o), cb.ptr(o_lo), 512, cb.ptr(delta), T
+        if form == "link":
+            b = cb.BlockQkvBwdArgs()
+            b.M, b.dY, b.lddy, b.dres, b.x = M, cb.ptr(dYd), 1536, cb.ptr(dresd), cb.ptr(out)
+            b.gamma, b.mean, b.rstd, b.W_bwd, b.N3, b.wide = cb.ptr(hpack.gamma), cb.ptr(mean2), cb.ptr(rstd2), cb.ptr(hpack.W_bwd), 1536, 0
+            b.At, b.ldat, b.Bbt, b.ldbt, b.alpha, b.p = cb.ptr(At), 48, cb.ptr(Bbt), 1536, 2.0, 0.0
+            b.V, b.ldv, b.dx = cb.ptr(V), 48, cb.ptr(dx)
+            t.dy, t.W_bwd, t.lean = cb.ptr(dx), cb.ptr(tpack.W_bwd), 0
+            keep = (b,)
+            cb.check(cb.lib().cvft_block_link_bwd(C.byref(b), C.byref(t), cb.ptr(lpack.W_bwd), cb.stream()), "link bwd")
+        else:
+            lean = 0 if form == "tail32" else 2
+            t.dy, t.W_bwd, t.lean = cb.ptr(dy), cb.ptr(tpack.W_bwd if lean == 0 else tpack.W_bwd_wide), lean
+            cb.check(cb.lib().cvft_block_tail_bwd(C.byref(t), cb.stream()), "tail bwd")
+        torch.cuda.synchronize()
+        res[want] = (dx1, do, delta)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])      # asking for delta changes nothing else
+    assert float(res[False][2].min()) == 7.0                                                          # ... and not asking leaves it alone
+    do64 = res[True][1].double().view(B, T, 8, 64)
+    oo = (o.double() + (o_lo.double() if with_lo else 0.0)).view(B, T, 8, 64)
+    ref = (do64 * oo).sum(-1).permute(0, 2, 1)                                                         # [B, H, T]
+    err = float((res[True][2].double() - ref).abs().max() / (ref.abs().max() + 1e-30))
+    assert err < 1e-5, err
+
+
+def test_tail_backward_delta_refuses_the_lean_form():
+    from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
+    import ctypes as C
+    t = cb.BlockTailBwdArgs()
+    w = torch.zeros(1024, device=DEV)
+    for f in ("x1", "dy", "gamma", "mean", "rstd", "z", "W_bwd", "dx1", "dout", "attn_o", "delta"):
+        setattr(t, f, cb.ptr(w))
+    t.M, t.F, t.DI, t.act, t.lddo, t.ldao, t.T, t.lean = 64, 1024, 512, 3, 512, 512, 32, 1
+    assert cb.lib().cvft_block_tail_bwd(C.byref(t), cb.stream()) != 0

@@ -241,6 +241,38 @@ def test_attn_bias(dtype, T, lens):
     assert rel(qd.grad.reshape(B, T, -1), qr.grad) < TOL[dtype] * 3
 
 
+@pytest.mark.parametrize("T,lens", [(250, [250, 200, 31, 250]), (500, [500, 420, 77, 500]), (96, [96, 1, 50, 96])])
+def test_attn_bias_backward_with_delta_given(T, lens):
+    """cvft_attn_bias_bwd with o == NULL: delta = rowsum(dO . (O + O_lo)) per head is an INPUT (the producer of dO formed it: the
+    estimator block's tail backward) and neither role reads the forward's output -- against the same call with o / o_lo given
+    (which forms delta itself): the gradients agree to the fp32 summation order of delta (both the whole-sequence and the
+    per-step staging forms, ragged key lengths)."""
+    from cosyvoice_lora_finetune_framework_amd.hipops import binding as cb
+    B, H = len(lens), 8
+    g = torch.Generator().manual_seed(T)
+    q, k, v, do = (torch.randn(B * T, H * 64, generator=g).to(torch.bfloat16).to(DEV) for _ in range(4))
+    klen = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    o, o_lo = torch.empty_like(q), torch.empty_like(q)
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=DEV)
+    cb.check(cb.lib().cvft_attn_bias_fwd(cb.dt(q), B, H, T, cb.ptr(q), cb.ptr(k), cb.ptr(v), H * 64, cb.ptr(klen), 0.125, 0, cb.ptr(o), H * 64,
+                                         cb.ptr(lse), cb.ptr(o_lo), cb.stream()), "fwd")
+    res = []
+    for given in (False, True):
+        dqkv = torch.zeros((B * T, 3 * H * 64), dtype=torch.bfloat16, device=DEV)
+        dq, dk, dv = dqkv[:, :H * 64], dqkv[:, H * 64:2 * H * 64], dqkv[:, 2 * H * 64:]
+        if given:
+            delta = (do.float() * (o.float() + o_lo.float())).view(B, T, H, 64).sum(-1).permute(0, 2, 1).contiguous()
+            po, plo = None, None
+        else:
+            delta, po, plo = torch.empty((B, H, T), dtype=torch.float32, device=DEV), o, o_lo
+        cb.check(cb.lib().cvft_attn_bias_bwd(cb.dt(q), B, H, T, cb.ptr(q), cb.ptr(k), cb.ptr(v), H * 64, cb.ptr(klen), 0.125, 0, cb.ptr(po),
+                                             cb.ptr(do), H * 64, cb.ptr(lse), cb.ptr(plo), cb.ptr(delta), cb.ptr(dq), cb.ptr(dk), cb.ptr(dv),
+                                             3 * H * 64, cb.stream()), "bwd")
+        torch.cuda.synchronize()
+        res.append(dqkv)
+    assert torch.isfinite(res[1].float()).all()
+    assert rel(res[1], res[0]) < 2e-3, rel(res[1], res[0])          # (bf16 outputs: a last-place flip where delta's sum order differs)
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T,lens,iso", [(50, [50, 33], 7), (131, [131, 64], 64), (131, [131, 40], 65), (64, [64, 1], 1),
                                         (200, [200, 150], 199), (96, [96, 96], 96)])
