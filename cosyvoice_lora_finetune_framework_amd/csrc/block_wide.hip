@@ -637,6 +637,24 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[t][f] = zero16();
+        constexpr int CPR = CR > 0 ? 32 * CR : 32;     // 16-byte chunks per row
+        constexpr int NIT = 8 * (CR > 0 ? CR : 1);
+        // delta for the attention backward that consumes dout (optional, cvft.h): this thread's chunks of the attention output (a chunk
+        // = 8 columns; 8 consecutive lanes = one head's 64), requested in front of the projection's products: they arrive under the
+        // first half of them (requested any earlier -- in front of the LayerNorm backward -- the kernel spills 40 registers)
+        const bool wdel = a.delta != nullptr;
+        bf16x8 ob[NIT], lb[NIT];
+        if (wdel) {
+            const bf16_t* aol = a.ao_lo ? a.ao_lo : a.ao;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int q = i * 256 + threadIdx.x;
+                const int r = min(m0 + q / CPR, a.M - 1), ch = q % CPR;
+                ob[i] = *reinterpret_cast<const bf16x8*>(a.ao + (size_t)r * a.ldao + 8 * ch);
+                lb[i] = *reinterpret_cast<const bf16x8*>(aol + (size_t)r * a.ldao + 8 * ch);
+            }
+        }
+        const float lo_w = a.ao_lo ? 1.f : 0.f;
         bf16x8 xq[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) xq[0][t] = bw_frag256(XT + t * 16384, m, h, 0);
@@ -669,23 +687,6 @@ __global__ __launch_bounds__(256, 1) void block_tail_wide_bwd_kernel(WideBwd a) 
                     const int c = 32 * (wave * NF + f) + 8 * g + 4 * h;
                     *reinterpret_cast<bf16x4*>(OUT + t * 32 * PITCH + m * PITCH + (((c >> 3) ^ (m & 15)) << 4) + ((c & 7) << 1)) = d;
                 }
-        constexpr int CPR = CR > 0 ? 32 * CR : 32;     // 16-byte chunks per row
-        constexpr int NIT = 8 * (CR > 0 ? CR : 1);
-        // delta for the attention backward that consumes dout (optional): this thread's chunks of the attention output, requested
-        // in front of the barrier the store loop waits behind (a chunk = 8 columns; 8 consecutive lanes = one head's 64)
-        const bool wdel = a.delta != nullptr;
-        bf16x8 ob[NIT], lb[NIT];
-        if (wdel) {
-            const bf16_t* aol = a.ao_lo ? a.ao_lo : a.ao;
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int q = i * 256 + threadIdx.x;
-                const int r = min(m0 + q / CPR, a.M - 1), ch = q % CPR;
-                ob[i] = *reinterpret_cast<const bf16x8*>(a.ao + (size_t)r * a.ldao + 8 * ch);
-                lb[i] = *reinterpret_cast<const bf16x8*>(aol + (size_t)r * a.ldao + 8 * ch);
-            }
-        }
-        const float lo_w = a.ao_lo ? 1.f : 0.f;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
