@@ -1773,16 +1773,16 @@ def block_link_on() -> bool:
 
 
 # ... and the same boundary backwards (cvft_block_link_bwd: block i + 1's head backward + block i's tail backward), wherever the
-# forward ran linked: "0" off, "1" on, "auto" (default) = on unless >= 3 chains share the chip.  Per boundary (M = 2000): head + tail
-# backward in their 32-row forms 43.9 us, 64-row forms 49.8 us, linked 40.4 us; but the joint step runs the 64-row pair on HALF the
-# CUs, and there CU-time counts: joint 20.67 / 20.67 (pair of 64-row launches) -> 20.90 / 20.89 ms (linked)
+# forward ran linked: "0" off, "1" / "auto" (default) on.  Per boundary (M = 2000): head + tail backward in their 32-row forms 43.9 us,
+# 64-row forms 49.8 us, linked 40.4 us.  In the joint step the alternative is the 64-row pair on HALF the CUs, and which wins depends
+# on who ends the step: while the LLM chain ended with the Flow chains the linked form LOST (20.67 / 20.67 -> 20.90 / 20.89 ms); since the
+# rel-pos dQ role and the delta hand-over took ~1.2 ms off the LLM chain's end (tools: CVFT_CHAIN_EVENTS) the Flow chains end the step
+# and their latency counts: 20.38 / 20.39 / 20.31 -> 20.30 / 20.18 / 20.22 ms (three same-box pairs).  flow_only: 14.55 -> 14.47.
 BLOCK_LINK_BWD = _os.environ.get("CVFT_BLOCK_LINK_BWD", "auto")
 
 
 def block_link_bwd_on() -> bool:
-    if BLOCK_LINK_BWD in ("0", "1"):
-        return BLOCK_LINK_BWD == "1"
-    return lib().cvft_concurrent_chains() < 3
+    return BLOCK_LINK_BWD != "0"
 
 
 BLOCK_QKV_FUSE = _os.environ.get("CVFT_BLOCK_QKV_FUSE", "1") != "0"      # first half of the block (norm1 + stacked LoRA q|k|v)
