@@ -92,22 +92,23 @@ def trace_summary(workload, batch, frames):
 
 
 def trace_kernel_time(workload, batch, frames):
-    """{bracket label: kernel ms per step} of this configuration's REAL step -- three chains on three streams -- from the committed
-    kernel trace of this build (profiles/*step_summary.json: top_kernels), or None (no record, or made on other kernel sources).
+    """{bracket label: chip-equivalent ms per step} of this configuration's REAL step -- three chains on three streams -- from the
+    committed kernel trace of this build (profiles/*cu_time.json, tools/cu_time.py: kernel time x the share of the 256 CUs a launch
+    holds -- the quantity the step's time follows), or None (no record, or made on other kernel sources).
     Used only to CHOOSE which kernel the roofline record is about: the instrumented step that measures it runs the chains one
     after the other on one stream, where the chip-filling GEMMs are faster than in the step and the row-tile chain kernels are not."""
     import glob
     import re
-    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*step_summary*.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*cu_time*.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         if d.get("workload") == workload and d.get("batch") == batch and d.get("frames") == frames:
-            if _stale(d, f) or "top_kernels" not in d:
+            if _stale(d, f) or "kernels" not in d:
                 return None
             out = {}
-            for k in d["top_kernels"]:
+            for k in d["kernels"]:
                 n = k["kernel"]
                 m = re.search(r"gemm_glds_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi0ELi(\d+)E", n)
                 if m:
@@ -119,7 +120,7 @@ def trace_kernel_time(workload, batch, frames):
                     if not m:
                         continue
                     lab = m.group(1) + "_" + m.group(2)
-                out[lab] = out.get(lab, 0.0) + k["ms_per_step"]
+                out[lab] = out.get(lab, 0.0) + k["chip_ms_per_step"]
             return out
     return None
 
@@ -531,7 +532,7 @@ def main():
                         "mfma_busy": busy, "mfma_busy_source": busy_src, "alg_bytes_per_launch": g["bytes"] / g["n"],
                         "launches_per_step": g["n"], "avg_launch_us": g["ms"] * 1e3 / g["n"],
                         "alg_gflop_per_launch": g["flop"] / g["n"] / 1e9, "intensity_flop_per_byte": g["flop"] / max(g["bytes"], 1.0)}
-            # dominant = most kernel time in the REAL step (this build's committed trace); without one, most time in the instrumented step
+            # dominant = most CU-time in the REAL step (this build's committed trace); without one, most time in the instrumented step
             tk = trace_kernel_time(a.workload, B, T)
             cand = {k: v for k, v in (tk or {}).items() if k in groups}
             if cand:
@@ -540,7 +541,7 @@ def main():
             else:
                 name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
             roof = line(name, g)
-            roof["chosen_by"] = ("kernel time per step in this build's trace (profiles/*step_summary.json): " +
+            roof["chosen_by"] = ("chip-equivalent kernel time per step (time x share of the 256 CUs held) in this build's trace (profiles/*cu_time.json): " +
                                  ", ".join(f"{k} {v:.2f} ms" for k, v in sorted(cand.items(), key=lambda kv: -kv[1])[:4])) if cand \
                 else "time in the instrumented single-stream step"
             roof["event_pair_overhead_us"] = evt_ms * 1e3

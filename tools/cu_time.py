@@ -2,9 +2,13 @@
 """CU-time per kernel of the steady-state step from a rocprofv3 --kernel-trace csv: duration x the share of the chip's 256 CUs
 a launch can hold at once (workgroups / workgroups-per-CU by its LDS, VGPR and thread footprint, capped at 256 CUs).  With three
 chains sharing the chip the step time follows the SUM of CU-time: a latency-bound kernel on 63 CUs costs a
-quarter of a chip-filling one of the same duration.   usage: cu_time.py <kernel_trace.csv> [nsteps=5] [top=30]"""
+quarter of a chip-filling one of the same duration.   usage: cu_time.py <kernel_trace.csv> [nsteps=5] [top=30] [OUT.json workload batch frames]
+(OUT.json: per-kernel kernel ms and chip-equivalent ms per step + the identity of the kernel sources; bench.py picks the kernel its
+roofline record is about by chip ms)"""
 import collections
 import csv
+import json
+import os
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -75,3 +79,12 @@ print(f"kernel time {tot_k:.2f} ms/step, chip-equivalent CU-time {tot_c:.2f} ms/
 print(f"{'kernel':72s} {'n/step':>7s} {'avg us':>8s} {'CUs':>6s} {'kern ms':>8s} {'chip ms':>8s} {'share':>6s}")
 for key, v in ct.most_common(top):
     print(f"{key:72s} {n[key] / nsteps:7.1f} {kt[key] / n[key] / 1e3:8.1f} {cu_sum[key] / n[key]:6.0f} {kt[key] / nsteps / 1e6:8.3f} {v / nsteps / 1e6:8.3f} {100 * v / sum(ct.values()):5.1f}%  [first launch: wgs {first[key][0]}, per CU {first[key][1]}, threads {first[key][2]}, grid {first[key][3]}, lds {first[key][4]}, vgpr {first[key][5]}]")
+
+if len(sys.argv) > 7:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from cosyvoice_lora_finetune_framework_amd.build_id import csrc_sha16
+    doc = {"csrc_sha16": csrc_sha16(), "workload": sys.argv[5], "batch": int(sys.argv[6]), "frames": int(sys.argv[7]), "steps_averaged": nsteps,
+           "kernel_ms_per_step": tot_k, "chip_ms_per_step": tot_c,
+           "kernels": [{"kernel": k, "launches_per_step": n[k] / nsteps, "ms_per_step": kt[k] / nsteps / 1e6, "chip_ms_per_step": v / nsteps / 1e6,
+                        "cus": cu_sum[k] / n[k]} for k, v in ct.most_common()]}
+    json.dump(doc, open(sys.argv[4], "w"), indent=1)

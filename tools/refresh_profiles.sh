@@ -9,10 +9,12 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/prof.log 2>&1
 cp "$(find $OUT/prof -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
 python tools/step_summary.py "$(find $OUT/prof -name '*kernel_trace.csv' | head -1)" $OUT/step_summary.json joint 16 500
-python tools/cu_time.py "$(find $OUT/prof -name '*kernel_trace.csv' | head -1)" 5 40 > $OUT/cu_time.txt || true
+python tools/cu_time.py "$(find $OUT/prof -name '*kernel_trace.csv' | head -1)" 5 40 $OUT/cu_time.json joint 16 500 > $OUT/cu_time.txt || true
 rm -rf $OUT/prof
-# (the bench line takes launches / kernel time per step from the newest profiles/*step_summary*.json: this build's trace first)
+# (the bench line takes launches / kernel time per step from the newest profiles/*step_summary*.json, and WHICH kernel its roofline record
+# is about from the newest profiles/*cu_time.json: this build's trace first)
 cp $OUT/step_summary.json profiles/r4_step_summary.json
+cp $OUT/cu_time.json profiles/r4_cu_time.json
 python tools/counters.py collect $OUT/counters > $OUT/counters.log 2>&1
 python tools/counters.py summarise $OUT/counters $OUT/counters.json > $OUT/counters.txt
 F=$(find $OUT/counters/fetch -name '*counter_collection.csv' | head -1)
@@ -23,13 +25,14 @@ python tools/pmc_traffic.py $F $W 'gemm_p256_kernel' 'gemm_p256_kernel<bf16,256,
 python tools/pmc_traffic.py $F $W 'gemm_glds_kernelILi96ELi256ELi3ELi4ELi0ELi3ELb1ELb0ELb0' 'gemm_glds_kernel<bf16,96,256,3,4,ns3,regepi>' $OUT/pmc_traffic_96x256.json || true
 python tools/pmc_traffic.py $F $W 'block_tail_fwd_kernel' 'block_tail_fwd' $OUT/pmc_traffic_block_tail_fwd.json || true
 python tools/pmc_traffic.py $F $W 'block_link_fwd_kernel' 'block_link_fwd' $OUT/pmc_traffic_block_link_fwd.json || true
+python tools/pmc_traffic.py $F $W 'block_link_bwd_kernel' 'block_link_bwd' $OUT/pmc_traffic_block_link_bwd.json || true
 python tools/pmc_traffic.py $F $W 'block_qkv_wide_fwd_kernel' 'block_qkv_wide_fwd' $OUT/pmc_traffic_block_qkv_fwd.json || true
 python tools/pmc_traffic.py $F $W 'block_tail_wide_bwd_kernel' 'block_tail_wide_bwd' $OUT/pmc_traffic_block_tail_wide_bwd.json || true
 rm -rf $OUT/counters
 # (the bench line quotes this build's counter records: they go into profiles/ BEFORE the line is made)
 cp $OUT/counters.json profiles/r4_counters.json; cp $OUT/counters.txt profiles/r4_counters.txt
 cp $OUT/pmc_traffic.json profiles/r4_pmc_traffic.json; cp $OUT/pmc_traffic_128x128.json profiles/r4_pmc_traffic_128x128.json
-for k in p256 96x256 block_tail_fwd block_link_fwd block_qkv_fwd block_tail_wide_bwd; do [ -f $OUT/pmc_traffic_$k.json ] && cp $OUT/pmc_traffic_$k.json profiles/r4_pmc_traffic_$k.json; done
+for k in p256 96x256 block_tail_fwd block_link_fwd block_link_bwd block_qkv_fwd block_tail_wide_bwd; do [ -f $OUT/pmc_traffic_$k.json ] && cp $OUT/pmc_traffic_$k.json profiles/r4_pmc_traffic_$k.json; done
 CVFT_BENCH_DUMP_PROFILE=$OUT/insitu_gemm_table.txt python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.log 2>&1
 tail -1 $OUT/bench_n1.log > $OUT/bench_n1.json
 python bench.py --workload flow_only --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_flow_only_b8.json
