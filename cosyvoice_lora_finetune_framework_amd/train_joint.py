@@ -20,6 +20,7 @@ from typing import Dict, Iterable, List, Optional
 import torch
 
 from . import dp
+from . import llm_flow_model as _J
 from .config import DATA_DIR, JOINT_TRAINING_CONFIG, MI355X_CONFIG, OUTPUT_DIR, PRETRAINED_MODEL_DIR, TRAIN_CONFIG
 from .hipops.functional import LoraGradSink
 from .modules import Numerics
@@ -341,6 +342,7 @@ class _Prefetcher:
         self.t.join(timeout=30)
 
 
+GRAPH_OPT = os.environ.get('CVFT_GRAPH_OPT', '1') != '0'      # the optimiser step inside the captured micro-step (_StepGraph)
 _TIMING = [] if os.environ.get('CVFT_TRAINER_TIMING') else None      # diagnostic: per-replay (events, host stamps), read by bench.py
 
 
@@ -349,16 +351,30 @@ class _StepGraph:
     batch lives in static device buffers that the trainer refreshes before every replay; the per-rank loss weights (DP)
     and the injected CFM draws are static inputs too."""
 
-    def __init__(self, module, packed: _PackedBatch, draws, w: torch.Tensor, accum: int, flat_g: torch.Tensor):
+    def __init__(self, module, packed: _PackedBatch, draws, w: torch.Tensor, accum: int, flat_g: torch.Tensor, opt=None):
+        """opt (a FlatAdamW, or None): the optimiser step -- clip, AdamW, bf16 shadows -- and the gradient reset are captured BEHIND
+        the backward in the same graph (`self.steps_optimizer`).  Why: a captured step with parallel branches keeps the host inside
+        hipGraphLaunch until the graph has all but finished (tools/dbg/replay_blocking.py: a three-branch graph's replay call
+        returns after 5 ms of a 5.5 ms graph, a linear one's after 0.4 ms), so everything the host enqueues between two replays
+        runs with the chip idle: the optimiser's six launches were 0.11 ms of every step.  Its learning rate and step count are
+        device scalars (optim.FlatAdamW.lr_dev / step_dev), so the captured launches stay valid."""
         self.slab = packed.slab.clone()              # static inputs: one slab, the batch tree is views into it
         self.batch, self.draws, self.w = packed.bind(self.slab), draws, w
         model, dev = module.model, module.device
         keys = [k for k in ("llm", "flow") if (k == "llm" and module.training_mode in ('joint', 'llm_only')) or
                 (k == "flow" and module.training_mode in ('joint', 'flow_only'))]
+        self.steps_optimizer = opt is not None
+        state = {"opt": False}
 
         def run():
-            return _fwd_bwd(model, self.batch, dev, self.draws, keys, self.w, accum)
+            out = _fwd_bwd(model, self.batch, dev, self.draws, keys, self.w, accum)
+            if state["opt"]:
+                opt.step(1.0)
+                opt.zero_grad()
+            return out
 
+        if self.steps_optimizer and opt.tiles is None:
+            opt.refresh_shadows()                    # (builds the shadow tile table on the host: not inside a capture)
         saved = flat_g.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -372,8 +388,12 @@ class _StepGraph:
         # thread_local: the prefetch thread (allocations, host -> device copies on the copy stream) and, under DP, the
         # RCCL watchdog keep running during capture; in the default "global" mode any such call from another thread
         # invalidates the capture
+        state["opt"] = self.steps_optimizer          # (the warm-up passes above ran without it)
+        count = opt.step_count if self.steps_optimizer else 0
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = run()
+        if self.steps_optimizer:
+            opt.step_count = count                   # (step() counted the capture; replay() counts the steps that run)
         flat_g.copy_(saved)                          # the warm-up run accumulated once; capture itself executes nothing
 
     @staticmethod
@@ -614,7 +634,8 @@ class Trainer:
                 if 0 < self.max_graphs <= len(self._graphs):
                     self._retire_oldest()
                 if len(self._graphs) < self.max_graphs:
-                    g = self._graphs[key] = _StepGraph(module, prepared, draws, w.clone(), self.accum, opt.flat_g)
+                    g = self._graphs[key] = _StepGraph(module, prepared, draws, w.clone(), self.accum, opt.flat_g,
+                                                       opt if self._graph_steps_optimizer(module) else None)
                     g.dims = prepared.dims
                     self._layouts.append(prepared.dims)
                     if os.environ.get('CVFT_TRAINER_DEBUG'):
@@ -623,10 +644,18 @@ class Trainer:
             if g is not None:
                 self._last_used[key] = self._micro_steps
                 self.graph_stats["replays"] += 1
+                self._optimizer_ran = g.steps_optimizer
+                if g.steps_optimizer:
+                    opt.step_count += 1
                 return g.replay(prepared, draws, w)
             batch = prepared.tree
         self.graph_stats["eager"] += 1
         return _fwd_bwd(module.model, batch, dev, draws, keys, w, self.accum)
+
+    def _graph_steps_optimizer(self, module) -> bool:
+        """the captured step ends with the optimiser step when every micro-step is an optimiser step, no other rank's gradients are
+        waited for and nobody asked to see the gradients first (CVFT_GRAPH_OPT=0: never)"""
+        return (GRAPH_OPT and self.accum == 1 and self.world == 1 and getattr(module, "on_before_optimizer_step", None) is None)
 
     def _retire_oldest(self):
         """Free the capture slot of the least recently replayed step if it is old enough (see `evict_after`): its graph, its
@@ -683,6 +712,7 @@ class Trainer:
                     # A rank whose batch failed to decode (collate_fn -> None) still takes part in every collective of the
                     # step with a zero-weight contribution: no rank ever skips an all-reduce the others enter (the prefetch
                     # thread has already exchanged this batch's denominators: _exchange_weights).
+                    self._optimizer_ran = False
                     w = ones
                     if wx is not None:
                         w, w_ready = wx
@@ -691,22 +721,31 @@ class Trainer:
                             w.record_stream(torch.cuda.current_stream())
                     if batch is not None:
                         draws = self.draws_fn(epoch, bi, batch) if self.draws_fn else None
+                        _J._chain_event(('step begin',))            # (diagnostic stamps: CVFT_CHAIN_EVENTS, llm_flow_model.py)
+                        self._optimizer_ran = False
+                        if self.use_graph and self._graph_steps_optimizer(module):
+                            opt.set_lr(module.lr_at(self.global_step, total_steps))      # (a captured step may end with the optimiser's)
                         losses = self._micro_step(module, opt, batch, draws, w, prepared, ready)
+                        _J._chain_event(('micro-step done',))
                         ep_sum += torch.stack([losses[k].float() if k in losses else ep_sum.new_zeros(()) for k in keys])
                         ep_cnt += 1
                     rec = None
                     if (bi + 1) % self.accum == 0 or bi + 1 == nb:
                         lr = module.lr_at(self.global_step, total_steps)
-                        opt.set_lr(lr)
-                        gscale = dp.allreduce_flat_grads(opt.flat_g)
-                        hook = getattr(module, "on_before_optimizer_step", None)      # (Lightning's module hook of that name)
-                        if hook is not None:
-                            hook(opt)
-                        opt.step(gscale)
+                        gscale = 1.0
+                        if not self._optimizer_ran:          # (else: the captured step just ran clip + AdamW + shadows + the reset)
+                            opt.set_lr(lr)
+                            gscale = dp.allreduce_flat_grads(opt.flat_g)
+                            hook = getattr(module, "on_before_optimizer_step", None)      # (Lightning's module hook of that name)
+                            if hook is not None:
+                                hook(opt)
+                            opt.step(gscale)
                         if self.log_every and self.global_step % self.log_every == 0 and losses is not None:
                             rec = dict(epoch=epoch, step=self.global_step, lr=lr, grad_norm=float(opt.grad_norm(gscale)),
                                        **{k: float(losses[k]) for k in keys if k in losses})
-                        opt.zero_grad()
+                        if not self._optimizer_ran:
+                            opt.zero_grad()
+                        _J._chain_event(('optimiser done',))
                         self.global_step += 1
                         if self.on_step_end is not None:
                             self.on_step_end(self)

@@ -165,6 +165,51 @@ def test_trainer_graph_path_equals_eager_path(tiny_meta):
     assert max(rel(finals[1][k], finals[0][k]) for k in finals[0]) < 1e-5
 
 
+def test_captured_step_with_the_optimizer_inside_equals_eager(tiny_meta):
+    """accumulate_grad_batches = 1, one rank, no gradient hook: the captured micro-step ends with the optimiser step (clip, AdamW,
+    bf16 shadows, gradient reset -- train_joint._StepGraph, CVFT_GRAPH_OPT), its learning rate and step count being device scalars
+    set / advanced per replay.  Against the eager trainer and against the captured step WITHOUT the optimiser: per-step losses,
+    learning rates, gradient norms, final LoRA tensors and the optimiser's step count, over a warm-up + cosine schedule, with a
+    layout captured mid-run."""
+    from cosyvoice_lora_finetune_framework_amd import train_joint as TJ
+    from cosyvoice_lora_finetune_framework_amd.llm_flow_model import JointLLMFlowModel
+    from cosyvoice_lora_finetune_framework_amd.modules import Numerics
+    from cosyvoice_lora_finetune_framework_amd.synthetic import cfm_draws, synth_batch
+    from cosyvoice_lora_finetune_framework_amd.train_joint import JointLightningModule, Trainer
+    num = Numerics(dtype=torch.float32)
+    shapes = [(24, 5, 10), (24, 7, 10), (20, 5, 8), (24, 5, 10), (20, 5, 8), (24, 9, 10)]
+    runs = {}
+    keep = TJ.GRAPH_OPT
+    try:
+        for name, use_graph, graph_opt in (("eager", False, False), ("graph", True, False), ("graph+opt", True, True)):
+            TJ.GRAPH_OPT = graph_opt
+            flow = build_flow_product(tiny_meta["flow"], DEV, num)
+            llm = build_llm_product(tiny_meta["llm"], DEV, num)
+            jm = JointLLMFlowModel(llm, flow, 'joint', llm_loss_weight=2.0, flow_loss_weight=1.0)
+            module = JointLightningModule('joint', learning_rate=1e-3, min_lr=1e-5, warmup_steps=3, weight_decay=0.01, model=jm, numerics=num)
+            batches = [synth_batch([T, max(4, T - 5)], text_lens=[Lx, max(2, Lx - 2)], token_lens=[Lt, max(3, Lt - 3)],
+                                   seed=500 + i, text_vocab=100, speech_vocab=50) for i, (T, Lx, Lt) in enumerate(shapes)]
+            tr = Trainer(max_epochs=2, accumulate_grad_batches=1, gradient_clip_val=1.0, train_mode=False, log_every_n_steps=1,
+                         save_checkpoints=False, use_graph=use_graph,
+                         draws_fn=lambda ep, bi, b: cfm_draws(2, b["speech_feat"].shape[1], 1000 * ep + bi))
+            tr.fit(module, batches)
+            runs[name] = (tr.history, {k: v.detach().clone() for k, v in jm.named_parameters() if v.requires_grad},
+                          tr.optimizer.step_count, float(tr.optimizer.step_dev), dict(tr.graph_stats),
+                          any(g.steps_optimizer for g in tr._graphs.values()))
+    finally:
+        TJ.GRAPH_OPT = keep
+    assert runs["graph+opt"][5] and not runs["graph"][5]                       # the optimiser really was inside / outside the graph
+    assert runs["graph+opt"][4]["replays"] == 12 and runs["graph+opt"][4]["eager"] == 0, runs["graph+opt"][4]
+    for name in ("graph", "graph+opt"):
+        h, fin, cnt, dev_cnt = runs[name][:4]
+        assert cnt == dev_cnt == runs["eager"][2] == 12, (name, cnt, dev_cnt)
+        assert len(h) == len(runs["eager"][0]) == 12
+        for a, b in zip(runs["eager"][0], h):
+            for k in ("loss", "llm_loss", "flow_loss", "lr", "grad_norm"):
+                assert abs(a[k] - b[k]) <= 1e-5 * abs(a[k]) + 1e-9, (name, k, a, b)
+        assert max(rel(fin[k], runs["eager"][1][k]) for k in fin) < 1e-5, name
+
+
 def test_trainer_sub_batch_chains_equal_one_chain(tiny_meta):
     """The bench's configuration in small: batches of 8 (>= 2 x SPLIT_MIN_PART, so the Flow branch runs as two concurrent
     half-batch chains on the same adapters), rank-16 adapters (matrix-core / slab LoRA-gradient path with the trainer's
