@@ -42,7 +42,11 @@ LOSS_FUSE = os.environ.get("CVFT_LOSS_FUSE", "1") != "0"      # 0: the plain op-
 # directions); 0 (default): forward(), then ONE backward of the total, the reference's order.  Measured neutral, same box, 40 steps:
 # joint 21.28 / 21.36 (1) vs 21.33 / 21.34 ms (0), flow_only 14.29 vs 14.27, llm_only 13.38 vs 13.31 -- the step is bound by the
 # chip's CU-time, an idle chain is another chain's CUs
-CHAIN_BWD = os.environ.get("CVFT_CHAIN_BWD", "0") != "0"
+# Every chain's backward issued right behind its own forward on the chain's stream (forward_backward), and the chain's postponed
+# adapter products flushed there too: "0" = the reference's order (forward of all chains, one weighted total, one backward).  Neutral
+# while the optimiser ran outside the captured step (21.28 / 21.36 vs 21.33 / 21.34); with it inside, the step's single-stream tail
+# behind the join is what the chains' own flush shortens: 20.13 / 20.20 / 20.19 -> 20.02 / 20.05 / 20.10 ms (three same-box pairs).
+CHAIN_BWD = os.environ.get("CVFT_CHAIN_BWD", "1") != "0"
 CHAIN_FLUSH = os.environ.get("CVFT_CHAIN_FLUSH", "1") != "0"      # (with CHAIN_BWD: LoraGradSink.flush_chain behind each chain's backward)
 # Diagnostic: with CVFT_CHAIN_EVENTS=1 (and CVFT_CHAIN_BWD=1) forward_backward drops a clock stamp (cvft_debug_stamp: a one-thread
 # kernel node, HIP refuses timing events inside a captured graph) at the fork, behind every chain's forward and backward, and at the
