@@ -46,7 +46,14 @@ LOSS_FUSE = os.environ.get("CVFT_LOSS_FUSE", "1") != "0"      # 0: the plain op-
 # adapter products flushed there too: "0" = the reference's order (forward of all chains, one weighted total, one backward).  Neutral
 # while the optimiser ran outside the captured step (21.28 / 21.36 vs 21.33 / 21.34); with it inside, the step's single-stream tail
 # behind the join is what the chains' own flush shortens: 20.13 / 20.20 / 20.19 -> 20.02 / 20.05 / 20.10 ms (three same-box pairs).
-CHAIN_BWD = os.environ.get("CVFT_CHAIN_BWD", "1") != "0"
+# "auto" (default): on in the joint mode; the single-branch modes lose 0.03 ms with it (flow_only 14.25 -> 14.28, llm_only 12.82 -> 12.86).
+CHAIN_BWD = os.environ.get("CVFT_CHAIN_BWD", "auto")
+
+
+def chain_bwd_on(model) -> bool:
+    if CHAIN_BWD in ("0", "1"):
+        return CHAIN_BWD == "1"
+    return getattr(model, "training_mode", None) == 'joint'
 CHAIN_FLUSH = os.environ.get("CVFT_CHAIN_FLUSH", "1") != "0"      # (with CHAIN_BWD: LoraGradSink.flush_chain behind each chain's backward)
 # Diagnostic: with CVFT_CHAIN_EVENTS=1 (and CVFT_CHAIN_BWD=1) forward_backward drops a clock stamp (cvft_debug_stamp: a one-thread
 # kernel node, HIP refuses timing events inside a captured graph) at the fork, behind every chain's forward and backward, and at the

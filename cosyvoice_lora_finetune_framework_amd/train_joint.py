@@ -68,7 +68,7 @@ def _fwd_bwd(model, batch, dev, draws, keys, w, accum: int):
     offers it (JointLLMFlowModel.forward_backward, CVFT_CHAIN_BWD: no join of all chains between the two directions), else the
     reference's order: forward, weighted total, one backward."""
     from . import llm_flow_model as J
-    if J.CHAIN_BWD and hasattr(model, "forward_backward"):
+    if hasattr(model, "forward_backward") and J.chain_bwd_on(model):
         with LoraGradSink():
             losses = model.forward_backward(batch, dev, draws, w, accum)
         return {k: v.detach() for k, v in losses.items()}
