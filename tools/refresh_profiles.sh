@@ -45,5 +45,6 @@ python bench.py --graph 0 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 
 python bench.py --frames 1000 --rank-lora 64 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_cfg4_bf16.json
 python bench.py --frames 1000 --rank-lora 64 --fp8 1 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -1 > $OUT/bench_cfg4_fp8.json
 # the driver's N = 2 launch line with both ranks on this one GPU over gloo (rehearsal of the launch path, not a scaling number)
-CVFT_SINGLE_DEVICE=1 CVFT_DIST_BACKEND=gloo timeout -k 10 280 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 4 --warmup 2 --no-roofline 2>&1 | grep "^{" | tail -1 > $OUT/bench_dp2_one_gpu_gloo.json
+CVFT_SINGLE_DEVICE=1 CVFT_DIST_BACKEND=gloo timeout -k 10 280 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 4 --warmup 2 --no-roofline > $OUT/bench_dp2.log 2>&1 || true
+grep "^{" $OUT/bench_dp2.log | tail -1 > $OUT/bench_dp2_one_gpu_gloo.json || true      # (an empty file = the launch failed: bench_dp2.log says why)
 echo refreshed
